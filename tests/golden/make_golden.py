@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE.
+
+Runs only in the build container (needs /root/reference, which never travels to
+the GPU box); the fixtures it writes are committed, the reference is not.
+
+How the reference is run: /root/reference/scTagger.py is loaded with importlib
+exactly as it lies on disk.  Its top-of-file imports name three third-party
+modules (edlib, pysam, ahocorasick) that are not installed here and are not
+touched by the match_trie path (scTagger.py:758-790 and callees :526-716); three
+EMPTY module objects are registered under those names so the import statement
+succeeds.  Nothing of the reference's text is copied: the outputs are data.
+
+Fixture families:
+  g1  cfg1: 1000 segs x 100 barcodes, e<=1              (-t 1, -t 4)
+  g2  1500 segs x 300 barcodes, e<=2                     (-t 1, -t 5)
+  g3  hand-made ties / palindrome / N / lower-case / empty / short rows
+      (-t 1, 4, 16; e = 0, 1, 2)
+  g4  Trie.query unit vectors (json)
+  g5  300 segs x 25000 barcodes, e<=2                    (-t 8)
+  g6  bl=12, e<=3, 400 segs x 60 barcodes                (-t 1, -t 4)
+  g7  ragged segment lengths 0..45, 500 segs x 200 barcodes, e<=2 (-t 1, -t 16)
+  g8  get_matches_prefix / run_get_matches_prefix return values (json) on g3
+"""
+import contextlib
+import gzip
+import importlib.util
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from sctagger_amd import synth  # noqa: E402
+
+REF = "/root/reference/scTagger.py"
+
+
+def load_reference():
+    for m in ("edlib", "pysam", "ahocorasick"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    import matplotlib
+    matplotlib.use("Agg")
+    spec = importlib.util.spec_from_file_location("scTagger_ref", REF)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["scTagger_ref"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def run_match_trie(mod, lr, sr, out, e, bl, t):
+    argv = ["scTagger.py", "match_trie", "-lr", lr, "-sr", sr, "-mr", str(e),
+            "-bl", str(bl), "-t", str(t), "-o", out]
+    old = sys.argv
+    sys.argv = argv
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            mod.main()
+    finally:
+        sys.argv = old
+
+
+def expected(mod, name, lr, sr, e, bl, t):
+    tmp = os.path.join(HERE, "_tmp_out.tsv.gz")
+    run_match_trie(mod, lr, sr, tmp, e, bl, t)
+    with gzip.open(tmp, "rb") as f:
+        data = f.read()
+    os.remove(tmp)
+    out = os.path.join(HERE, "%s.e%d.t%d.expected.tsv" % (name, e, t))
+    with open(out, "wb") as f:
+        f.write(data)
+    print("  %s: %d rows" % (os.path.basename(out), data.count(b"\n")), file=sys.stderr)
+
+
+def synth_pair(name, nseg, nbc, bl, seed, seg_len=22, gz_bc=False):
+    bc = synth.make_barcodes(nbc, bl=bl, seed=seed)
+    segs, offs = synth.make_segments(nseg, bc, seg_len=seg_len, seed=seed)
+    lr = os.path.join(HERE, name + ".lr.tsv")
+    sr = os.path.join(HERE, name + ".sr.tsv")
+    synth.write_segments_tsv(lr, segs, offs, seed=seed)
+    synth.write_barcodes_tsv(sr, bc, seed=seed)
+    if gz_bc:
+        with open(sr, "rb") as f, gzip.GzipFile(sr + ".gz", "wb", mtime=0) as g:
+            g.write(f.read())
+        os.remove(sr)
+        sr += ".gz"
+    return lr, sr
+
+
+G3_BARCODES = [
+    "ACGTACGTACGTACGT",   # 0 reverse-complement palindrome -> reported twice
+    "AAAAAAAAAAAAAAAA",   # 1 low complexity
+    "TTTTTTTTTTTTTTTT",   # 2 rc of 1 -> ties
+    "GATTACAGATTACAGA",   # 3
+    "GATTACAGATTACAGA",   # 4 duplicate of 3 -> distinct bid
+    "ACGTNCGTACGTACGA",   # 5 N in a barcode (N -> A for matching, N kept by rev_compl)
+    "acgtacgtacgtacgt",   # 6 lower-case barcode (every byte -> A)
+    "CCCCGGGGCCCCGGGG",   # 7 palindrome-ish (rc == itself)
+    "TGCATGCATGCATGCA",   # 8 palindrome
+    "CAGTCAGTCAGTCAGG",   # 9
+    "AAAAAAAAAAAAAAAC",   # 10 near 1
+    "GGGGGGGGGGGGGGGG",   # 11
+]
+
+G3_SEGMENTS = [
+    "TCTACGTACGTACGTACGTGGA",          # exact palindrome hit
+    "GGNAAAAAAAAAAAAAAAGG",            # N inside: t-dependent
+    "aaaaaaaaaaaaaaaaaaaaaa",          # all lower-case: matches at t=1, vanishes at t>1
+    "",                                # empty row
+    "ACGTACG",                         # shorter than bl-e
+    "AAAAAAAAAAAAAA",                  # exactly bl-2
+    "AAAAAAAAAAAAAAA",                 # bl-1
+    "AAAAAAAAAAAAAAAAAAAAAA",          # poly-A: ties 1 and 2(rc) and 6, 10 at e>0
+    "TTTTTTTTTTTTTTTTTTTTTT",          # poly-T
+    "TCTGATTACAGATTACAGATCC",          # duplicate barcodes 3 and 4
+    "TCTGATTACAGTTACAGATCCG",          # one deletion
+    "TCTGATTACAGAATTACAGATC",          # one insertion
+    "TCTGATTACTGATTACAGATCC",          # one substitution
+    "TCTGATTACTGATTCAGATCCA",          # sub + del
+    "GGATCTGTAATCTGTAATCAGA",          # rc strand of 3
+    "TCTACGTACGTACGTACGAGGA",          # barcode 5 with N->A : ACGTACGTACGTACGA
+    "TCTTCGTACGTACGTNCGTAGG",          # rc of 5 as rev_compl writes it (N stays)
+    "TCTCCCCGGGGCCCCGGGGTTT",          # 7
+    "TGCATGCATGCATGCATGCATG",          # 8 periodic: several windows hit
+    "NNNNNNNNNNNNNNNNNNNNNN",          # all N -> all A at t=1
+    "TCTCAGTCAGTCAGTCAGGNNN",          # 9 then N tail
+    "NCTCAGTCAGTCAGTCAGGACG",          # N first
+    "TCNCAGTCAGTCAGTCAGGACG",          # N just before the barcode (start windows dropped at t>1)
+    "TCTCAGTCAGNCAGTCAGGACG",          # N inside the barcode copy
+    "ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT",  # long (44) periodic
+    "GGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGG",  # long poly-G (50)
+    "TCTGATTACAGATTACAGA",             # barcode at the very end
+    "GATTACAGATTACAGATCTTCT",          # barcode at the very start
+    "CATCATCATCATCATCATCATC",          # background
+    "TCTAAAAAAAAAAAAAAACGGG",          # 10
+    "tctgattacagattacagatcc",          # lower-case copy of a real hit
+    "TCTGATTACAGATTACAGAT C",          # a space (non-ACGT byte)
+]
+
+
+def write_g3():
+    lr = os.path.join(HERE, "g3.lr.tsv")
+    sr = os.path.join(HERE, "g3.sr.tsv")
+    with open(lr, "w") as f:
+        for i, s in enumerate(G3_SEGMENTS):
+            f.write("q%d\t%d\t%s\t%s\n" % (i, 0 if s else -1, "30" if s else "NA", s))
+    with open(sr, "w") as f:
+        for i, b in enumerate(G3_BARCODES):
+            f.write("%s\t%d\n" % (b, 100 - i))
+    return lr, sr
+
+
+def ragged_pair(name, nseg, nbc, seed):
+    """Segments of every length 0..45 with planted (edited) barcodes."""
+    rng = np.random.default_rng(seed)
+    bc = synth.make_barcodes(nbc, bl=16, seed=seed)
+    lr = os.path.join(HERE, name + ".lr.tsv")
+    sr = os.path.join(HERE, name + ".sr.tsv")
+    synth.write_barcodes_tsv(sr, bc, seed=seed)
+    base, offs = synth.make_segments(nseg, bc, seg_len=46, seed=seed)
+    with open(lr, "w") as f:
+        for i in range(nseg):
+            s = base[offs[i]:offs[i + 1]].tobytes().decode()
+            ln = int(rng.integers(0, 46))
+            st = int(rng.integers(0, 4))
+            s = s[st:st + ln]
+            f.write("r%d\t1\t%s\t%s\n" % (i, "25" if s else "NA", s))
+    return lr, sr
+
+
+def trie_unit_vectors(mod):
+    """G4: Trie.insert / Trie.query on tiny tries (duplicates preserved)."""
+    cases = []
+    specs = [
+        (2, 8, [("ACGTACGTAC", 0)], ["ACGTACGT", "ACGTACGA", "ACGAACGA", "ACTACGT", "AACGTACGT", "TTTTTTTT"]),
+        (1, 6, [("ACGTAC", 0), ("ACGTAG", 1), ("ACGTA", 2), ("CGTACG", 0)], ["ACGTAC", "ACGTA", "CGTAC", "ACGTTC"]),
+        (2, 5, [("AAAAAAA", 7), ("AAAAAAA", 7), ("AANAA", 3)], ["AAAAA", "AACAA", "CCCCC"]),
+        (0, 4, [("ACGT", 0), ("ACGT", 1), ("ACG", 2)], ["ACGT", "ACG", "ACGA"]),
+        (3, 7, [("GATTACAGAT", 5), ("GATTTACAG", 6)], ["GATTACA", "GTTACA", "CATTACAA"]),
+    ]
+    for e, bl, words, queries in specs:
+        t = mod.Trie(e, bl, capacity=4096)
+        for w, rid in words:
+            t.insert(w, rid)
+        cases.append({
+            "max_error": e, "barcode_length": bl, "inserts": words,
+            "size": int(t.size),
+            "queries": [{"barcode": q, "result": [[int(x) for x in lst] for lst in t.query(q)]} for q in queries],
+        })
+    with open(os.path.join(HERE, "g4.trie_unit.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+
+
+def seam_vectors(mod, lr, sr):
+    """G8: return values of get_matches_prefix / run_get_matches_prefix on g3."""
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        mod.read_sr_barcodes(sr)
+        mod.read_long_reads(lr)
+        for e in (1, 2):
+            for prefix in (b"", b"A", b"TC"):
+                r = mod.get_matches_prefix((e, prefix))
+                out["prefix:%d:%s" % (e, prefix.decode())] = sorted(
+                    [int(rid), int(d), sorted([int(b), bool(s)] for b, s in X)] for rid, (d, X) in r.items())
+            for t in (1, 3, 16):
+                r = mod.run_get_matches_prefix(e, t)
+                out["run:%d:%d" % (e, t)] = sorted(
+                    [int(rid), int(d), sorted([int(b), bool(s)] for b, s in X)] for rid, (d, X) in r.items())
+    with open(os.path.join(HERE, "g8.seam.json"), "w") as f:
+        json.dump(out, f)
+
+
+def main():
+    mod = load_reference()
+    lr, sr = synth_pair("g1", 1000, 100, 16, seed=1)
+    for t in (1, 4):
+        expected(mod, "g1", lr, sr, 1, 16, t)
+    lr, sr = synth_pair("g2", 1500, 300, 16, seed=2)
+    for t in (1, 5):
+        expected(mod, "g2", lr, sr, 2, 16, t)
+    lr, sr = write_g3()
+    for e in (0, 1, 2):
+        for t in (1, 4, 16):
+            expected(mod, "g3", lr, sr, e, 16, t)
+    seam_vectors(mod, lr, sr)
+    trie_unit_vectors(mod)
+    lr, sr = synth_pair("g6", 400, 60, 12, seed=6, seg_len=20)
+    for t in (1, 4):
+        expected(mod, "g6", lr, sr, 3, 12, t)
+    lr, sr = ragged_pair("g7", 500, 200, seed=7)
+    for t in (1, 16):
+        expected(mod, "g7", lr, sr, 2, 16, t)
+    lr, sr = synth_pair("g5", 300, 25000, 16, seed=5, gz_bc=True)
+    expected(mod, "g5", lr, sr, 2, 16, 8)
+
+
+if __name__ == "__main__":
+    main()
