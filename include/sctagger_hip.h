@@ -1,0 +1,120 @@
+/*
+ * sctagger_hip.h — C-ABI of libsctagger_hip.so, the MI355X (gfx950) implementation of scTagger's
+ * match_trie barcode-matching stage.
+ *
+ * The reference has no FFI: the seam this library replaces is the in-process call
+ *     run_get_matches_prefix(max_error, threads) -> dict[rid -> (e, set[(bid, strand)])]
+ * (reference scTagger.py:688-716) together with the worker it fans out to
+ * (get_matches_prefix :671-685, Trie :526-599, trie_search :643-668), reading the module globals
+ * barcodes / barcodes_rc (:631-640) and lr_segs / lr_segs_idxs (:616-627).
+ *
+ * Conventions: plain pointers and sizes only; every buffer named below is caller-owned unless the
+ * comment says otherwise; the library never frees caller memory; every call returns 0 or a negative
+ * SCT_E_* code and the message is available from sct_last_error() (thread-local); no exception
+ * crosses the boundary.  One context per device; a context is used by one host thread at a time
+ * (multi-GPU = one context, and one process or thread, per device).  There is no CPU fallback:
+ * without a usable HIP device sct_create fails.
+ */
+#ifndef SCTAGGER_HIP_H
+#define SCTAGGER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sct_ctx sct_ctx;
+
+enum {
+    SCT_OK = 0,
+    SCT_E_ARG = -1,         /* bad argument (NULL, negative size, bl/max_err out of range, byte >= 128) */
+    SCT_E_HIP = -2,         /* a HIP runtime call failed */
+    SCT_E_NODEV = -3,       /* no usable device */
+    SCT_E_STATE = -4,       /* call order (e.g. match before set_barcodes) */
+    SCT_E_UNSUPPORTED = -5  /* barcode length above SCT_MAX_BL */
+};
+
+#define SCT_MAX_BL 32       /* barcode length limit of the bit-parallel kernels */
+#define SCT_NO_HIT 0xFF     /* min_e value for a segment absent from the reference's result dict */
+
+/* Number of visible HIP devices (0 if none / runtime unusable). */
+int sct_device_count(void);
+
+/* Create / destroy a context bound to `device`. */
+int sct_create(int device, sct_ctx **out);
+void sct_destroy(sct_ctx *ctx);
+
+/* Last error message of the calling thread ("" if none). */
+const char *sct_last_error(void);
+
+/* Prefix length k the reference derives from -t: smallest k with 4^k >= threads (scTagger.py:689-697). */
+int sct_prefix_len(int threads);
+
+/*
+ * Replace the barcode set — the reference's read_sr_barcodes globals (scTagger.py:631-640).
+ *   bc  n*bl ASCII bytes, forward barcodes only, row i = barcodes[i]; the reverse-complement strings
+ *       are derived inside exactly as rev_compl does (:148-156: A<->T, C<->G, other bytes unchanged),
+ *       and every byte is then mapped as map_char does (:512-516: ACGT -> 0..3, anything else -> 0).
+ *   bl  barcode length (the reference asserts all barcodes have length -bl, :760-761), 1..SCT_MAX_BL.
+ * A byte >= 128 is rejected with SCT_E_ARG (the reference raises IndexError there).
+ */
+int sct_set_barcodes(sct_ctx *ctx, const char *bc, int32_t n, int32_t bl);
+
+/*
+ * The whole seam in one call: run_get_matches_prefix(max_error, threads) (scTagger.py:688-716).
+ *   segs, offs   the reference's lr_segs / lr_segs_idxs (:616-627) in CSR form: segment rid is
+ *                segs[offs[rid] .. offs[rid+1]); offs has n+1 non-decreasing entries, offs[0] == 0.
+ *                (int64 offsets; the reference's int32 RawArray overflows at 2^31 bytes.)
+ *   max_err      -mr; 0 <= max_err < bl (:143)
+ *   threads      -t; only its prefix length matters: for k = sct_prefix_len(threads) > 0 a window
+ *                whose first k bytes are not all in "ACGT" is not searched (raw-byte startswith, :681)
+ * Outputs:
+ *   min_e[n]       minimum edit distance over barcodes and strands, SCT_NO_HIT if the segment has
+ *                  no barcode within max_err (such rids are absent from the reference's dict)
+ *   hit_offs[n+1]  CSR offsets into *hits
+ *   *hits          library-allocated (release with sct_free_hits): for each segment the sorted list of
+ *                  (bid << 1 | strand), strand 1 = forward (True), 0 = reverse complement (False) —
+ *                  ascending order is exactly sorted(bids) of scTagger.py:789
+ *   *n_hits        total number of hits (== hit_offs[n])
+ */
+int sct_match(sct_ctx *ctx, const char *segs, const int64_t *offs, int64_t n, int32_t max_err, int32_t threads,
+              uint8_t *min_e, int64_t *hit_offs, uint32_t **hits, int64_t *n_hits);
+void sct_free_hits(sct_ctx *ctx, uint32_t *hits);
+
+/*
+ * The same path in three steps, for pipelining and for measuring with the inputs resident in HBM:
+ *   sct_upload_segments  host -> device copy of segs/offs (kept until the next upload)
+ *   sct_run              every kernel of the path on the resident segments; results stay on the device;
+ *                        *n_hits receives the total hit count (one 8-byte device->host read)
+ *   sct_download         device -> host copy of the results of the last sct_run; hits must hold
+ *                        n_hits entries
+ */
+int sct_upload_segments(sct_ctx *ctx, const char *segs, const int64_t *offs, int64_t n);
+int sct_run(sct_ctx *ctx, int32_t max_err, int32_t threads, int64_t *n_hits);
+int sct_download(sct_ctx *ctx, uint8_t *min_e, int64_t *hit_offs, uint32_t *hits);
+
+/* Block until everything queued on the context's stream has finished. */
+int sct_sync(sct_ctx *ctx);
+
+/*
+ * Options (key, value):
+ *   "force_exhaustive" 0|1   skip the seed-filter kernel and scan every barcode for every segment
+ *   "timing"           0|1   record HIP events around each kernel of sct_run (default 1)
+ */
+int sct_set_option(sct_ctx *ctx, const char *key, int64_t value);
+
+/*
+ * Per-kernel device time of the last sct_run, measured with HIP events on the context's stream.
+ * Fills up to cap entries of names[] (static strings) and ms[]; returns the number of kernels, or <0.
+ */
+int sct_last_timing(sct_ctx *ctx, const char **names, float *ms, int cap);
+
+/* Counters of the last sct_run: [0] segments on the seed-filter path, [1] segments on the exhaustive
+ * path, [2] segments on the restricted-start (non-ACGT, k>0) path, [3] total hits. Returns count or <0. */
+int sct_last_stats(sct_ctx *ctx, int64_t *out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCTAGGER_HIP_H */

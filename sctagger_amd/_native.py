@@ -1,0 +1,201 @@
+"""ctypes binding of libsctagger_hip.so (C-ABI: include/sctagger_hip.h).
+
+There is no fallback: if the shared library is missing or no MI355X is visible the
+calls raise.  The library is built in-tree by `__graft_entry__.build()` or
+`make -C sctagger_amd/csrc`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsctagger_hip.so")
+
+NO_HIT = 0xFF
+MAX_BL = 32
+
+# every symbol include/sctagger_hip.h declares
+EXPORTS = (
+    "sct_device_count", "sct_create", "sct_destroy", "sct_last_error", "sct_prefix_len", "sct_set_barcodes",
+    "sct_match", "sct_free_hits", "sct_upload_segments", "sct_run", "sct_download", "sct_sync", "sct_set_option",
+    "sct_last_timing", "sct_last_stats",
+)
+
+_lib = None
+
+
+class SctError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libsctagger_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load the shared library (once). Raises OSError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C sctagger_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    lib.sct_device_count.restype = ctypes.c_int
+    lib.sct_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    lib.sct_destroy.argtypes = [vp]
+    lib.sct_destroy.restype = None
+    lib.sct_last_error.restype = ctypes.c_char_p
+    lib.sct_prefix_len.argtypes = [ctypes.c_int]
+    lib.sct_set_barcodes.argtypes = [vp, vp, i32, i32]
+    lib.sct_match.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    lib.sct_free_hits.argtypes = [vp, vp]
+    lib.sct_free_hits.restype = None
+    lib.sct_upload_segments.argtypes = [vp, vp, vp, i64]
+    lib.sct_run.argtypes = [vp, i32, i32, ctypes.POINTER(i64)]
+    lib.sct_download.argtypes = [vp, vp, vp, vp]
+    lib.sct_sync.argtypes = [vp]
+    lib.sct_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+    lib.sct_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    lib.sct_last_stats.argtypes = [vp, ctypes.POINTER(i64), ctypes.c_int]
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return int(load().sct_device_count())
+
+
+def prefix_len(threads):
+    return int(load().sct_prefix_len(int(threads)))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Matcher:
+    """One context on one MI355X. Mirrors the state the reference keeps in module globals."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._ctx = ctypes.c_void_p()
+        self._check(self._lib.sct_create(int(device), ctypes.byref(self._ctx)))
+        self.device = int(device)
+        self.n_bc = 0
+        self.bl = 0
+        self.n_seg = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SctError(rc, self._lib.sct_last_error().decode("utf-8", "replace"))
+
+    def close(self):
+        if self._ctx:
+            self._lib.sct_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_option(self, key, value):
+        self._check(self._lib.sct_set_option(self._ctx, key.encode(), int(value)))
+
+    def set_barcodes(self, bc, bl=None):
+        """bc: uint8[n, bl] array, or a list of equal-length str/bytes (forward barcodes)."""
+        if not isinstance(bc, np.ndarray):
+            rows = [b.encode("latin-1") if isinstance(b, str) else bytes(b) for b in bc]
+            if bl is None:
+                bl = len(rows[0]) if rows else 16
+            if any(len(r) != bl for r in rows):
+                raise ValueError("all barcodes must have length %d" % bl)
+            bc = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), bl)
+        bc = np.ascontiguousarray(bc, dtype=np.uint8)
+        if bc.ndim != 2:
+            raise ValueError("barcodes must be a 2-D uint8 array")
+        n, w = bc.shape
+        if bl is None:
+            bl = w
+        if w != bl:
+            raise ValueError("barcode width %d != bl %d" % (w, bl))
+        self._check(self._lib.sct_set_barcodes(self._ctx, _ptr(bc), n, bl))
+        self.n_bc, self.bl = n, bl
+
+    @staticmethod
+    def _csr(segs, offs):
+        if isinstance(segs, (bytes, bytearray, memoryview)):
+            segs = np.frombuffer(segs, dtype=np.uint8)
+        segs = np.ascontiguousarray(segs, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        if offs.ndim != 1 or offs.size < 1:
+            raise ValueError("offs must hold n+1 entries")
+        if segs.size != int(offs[-1]):
+            raise ValueError("segs holds %d bytes but offs[-1] is %d" % (segs.size, int(offs[-1])))
+        return segs, offs
+
+    def match(self, segs, offs, max_err, threads=1):
+        """sct_match: -> (min_e uint8[n], hit_offs int64[n+1], hits uint32[total])."""
+        segs, offs = self._csr(segs, offs)
+        n = offs.size - 1
+        min_e = np.empty(n, dtype=np.uint8)
+        hit_offs = np.empty(n + 1, dtype=np.int64)
+        hp = ctypes.c_void_p()
+        nh = ctypes.c_int64()
+        self._check(self._lib.sct_match(self._ctx, _ptr(segs), _ptr(offs), n, int(max_err), int(threads),
+                                        _ptr(min_e), _ptr(hit_offs), ctypes.byref(hp), ctypes.byref(nh)))
+        try:
+            hits = np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_uint32)), shape=(max(nh.value, 1),))
+            hits = hits[:nh.value].copy()
+        finally:
+            self._lib.sct_free_hits(self._ctx, hp)
+        self.n_seg = n
+        return min_e, hit_offs, hits
+
+    def upload_segments(self, segs, offs):
+        segs, offs = self._csr(segs, offs)
+        self._check(self._lib.sct_upload_segments(self._ctx, _ptr(segs), _ptr(offs), offs.size - 1))
+        self.n_seg = offs.size - 1
+
+    def run(self, max_err, threads=1):
+        nh = ctypes.c_int64()
+        self._check(self._lib.sct_run(self._ctx, int(max_err), int(threads), ctypes.byref(nh)))
+        self._n_hits = nh.value
+        return nh.value
+
+    def download(self):
+        n = self.n_seg
+        min_e = np.empty(n, dtype=np.uint8)
+        hit_offs = np.empty(n + 1, dtype=np.int64)
+        hits = np.empty(max(self._n_hits, 1), dtype=np.uint32)
+        self._check(self._lib.sct_download(self._ctx, _ptr(min_e), _ptr(hit_offs), _ptr(hits)))
+        return min_e, hit_offs, hits[:self._n_hits]
+
+    def sync(self):
+        self._check(self._lib.sct_sync(self._ctx))
+
+    def last_timing(self):
+        """-> list of (kernel name, ms) of the last run, from HIP events on the library's stream."""
+        cap = 32
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_float * cap)()
+        k = self._lib.sct_last_timing(self._ctx, names, ms, cap)
+        if k < 0:
+            self._check(k)
+        return [(names[i].decode(), float(ms[i])) for i in range(min(k, cap))]
+
+    def last_stats(self):
+        out = (ctypes.c_int64 * 4)()
+        k = self._lib.sct_last_stats(self._ctx, out, 4)
+        if k < 0:
+            self._check(k)
+        return {"filter": out[0], "exhaustive": out[1], "restricted_start": out[2], "hits": out[3]}

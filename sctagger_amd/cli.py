@@ -1,0 +1,55 @@
+"""`scTagger.py match_trie` command line (reference scTagger.py:81-97, :140-143, :847-861).
+
+Flags, defaults and asserts are the reference's for this sub-command; `-m/--mem` and `-p/--plotfile`
+are accepted and unused, exactly as there.  Optional extras: `--devices` (GPU ids, one shard each) and
+`--gzip-level`.  The other scTagger sub-commands are outside this build's scope.
+"""
+import argparse
+import sys
+
+from . import match_trie as _mt
+
+OTHER_SUBCOMMANDS = ("extract_lr_bc", "extract_sr_bc", "extract_sr_bc_from_lr")
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description="scTagger match_trie on AMD MI355X")
+    subparsers = parser.add_subparsers(dest="subcommand")
+    subparsers.required = True
+    p = subparsers.add_parser("match_trie")
+    p.add_argument("-lr", "--long-read-segments", type=str, required=True, help="Long-read segments TSV file")
+    p.add_argument("-sr", "--short-read-barcodes", type=str, required=True, help="Short-read barcode list TSV file")
+    p.add_argument("-mr", "--max-error", default=2, type=int,
+                   help="Maximum number of errors allowed for barcode matching. Default: 2")
+    p.add_argument("-m", "--mem", default=16.0, type=float, help="Accepted for compatibility; unused. Default: 16.0")
+    p.add_argument("-bl", "--barcode-length", default=16, type=int, help="Length of barcodes. Default: 16")
+    p.add_argument("-t", "--threads", default=16, type=int,
+                   help="Reference thread count; here it only selects the reference's window-prefix length "
+                        "(affects segments with non-ACGT bytes). Default: 16")
+    p.add_argument("-p", "--plotfile", default=None, type=str, help="Accepted for compatibility; unused")
+    p.add_argument("-o", "--outfile", type=str, default=None,
+                   help="Path to output file; gzipped if it ends with 'gz'. Default: stdout")
+    p.add_argument("--devices", type=int, nargs="+", default=None, help="GPU ids to shard the segments over. Default: 0")
+    p.add_argument("--gzip-level", type=int, default=6, help="gzip level of the output. Default: 6")
+    for name in OTHER_SUBCOMMANDS:
+        subparsers.add_parser(name, add_help=False)
+    args, rest = parser.parse_known_args(argv)
+    if args.subcommand != "match_trie":
+        parser.error("sub-command %r is not part of this build (match_trie only)" % args.subcommand)
+    if rest:
+        parser.error("unrecognized arguments: %s" % " ".join(rest))
+    # reference :140-143
+    assert args.mem > 0
+    assert args.barcode_length > 0
+    assert args.barcode_length > args.max_error >= 0
+    return args
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    print(args, file=sys.stderr)
+    _mt.match_trie(args)
+
+
+if __name__ == "__main__":
+    main()

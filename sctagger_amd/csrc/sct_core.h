@@ -1,0 +1,151 @@
+// sct_core.h — bit-parallel primitives shared by the device kernels and the host-side table builder.
+//
+// Everything here is plain integer arithmetic written once and compiled twice: by hipcc into the gfx950
+// kernels, and by the host compiler for the seed-table construction in sct_set_barcodes (and, in
+// tests/host_core_check.cpp, for a CPU check of the very same arithmetic against a brute-force DP).
+//
+// Encoding (reference scTagger.py:512-516 map_char): A,C,G,T -> 0..3, any other byte -> 0.  Sequences
+// are held as two bit-planes: lo bit i = low bit of the code of character i, hi bit i = its high bit.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SCT_HD __host__ __device__ __forceinline__
+#else
+#define SCT_HD static inline
+#endif
+
+SCT_HD uint32_t sct_code(uint8_t b) { return b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 0u; }
+SCT_HD bool sct_is_acgt(uint8_t b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
+
+// ---------------------------------------------------------------------------------------------------
+// Myers / Hyyro bit-vector column step, pattern vertical (bit i = pattern row i+1), text streamed.
+// Semi-global: free start in the text (horizontal delta 0 enters row 0), the pattern is matched whole.
+// After the step `score` is D[m][j], the best distance of the pattern to any substring ending at j.
+// Bits above m-1 never influence lower bits (carries and shifts only move upward), so Eq need not be
+// masked to m bits.
+// ---------------------------------------------------------------------------------------------------
+template <typename W>
+struct MyersState {
+    W Pv, Mv;
+    int score;
+};
+
+template <typename W>
+SCT_HD void myers_init(MyersState<W> &s, int m) {
+    s.Pv = ~(W)0;
+    s.Mv = 0;
+    s.score = m;
+}
+
+// lo/hi: pattern bit-planes; c: text code 0..3; m: pattern length (1..bits of W)
+template <typename W>
+SCT_HD void myers_step(MyersState<W> &s, W lo, W hi, uint32_t c, int m) {
+    const W ml = (W)0 - (W)(c & 1u);
+    const W mh = (W)0 - (W)(c >> 1);
+    const W Eq = ~(lo ^ ml) & ~(hi ^ mh);
+    const W Xv = Eq | s.Mv;
+    const W Xh = ((((Eq & s.Pv) + s.Pv)) ^ s.Pv) | Eq;
+    W Ph = s.Mv | ~(Xh | s.Pv);
+    W Mh = s.Pv & Xh;
+    s.score += (int)((Ph >> (m - 1)) & 1);
+    s.score -= (int)((Mh >> (m - 1)) & 1);
+    Ph <<= 1;
+    Mh <<= 1;
+    s.Pv = Mh | ~(Xv | Ph);
+    s.Mv = Ph & Xv;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Transposed Wu-Manber automaton for short texts (L <= 31): bit i of R_d = "some substring of the text
+// ending at position i matches the pattern prefix consumed so far with <= d edits".  The pattern is the
+// streamed dimension (bl steps), so no per-column score tracking is needed: after the last pattern
+// character the answer is the smallest d with R_d != 0.
+//   tls, ths  text bit-planes shifted left by one (bit i+1 = plane bit of text[i])
+//   ve        bits 1..L (positions that have a character before them), va = bits 0..L
+// Transitions per pattern character p: match (advance both, text char == p), substitution (advance
+// both), deletion of p (advance the pattern only), insertion (advance the text only).
+// ---------------------------------------------------------------------------------------------------
+template <int E>
+SCT_HD int wm_verify(uint32_t tls, uint32_t ths, uint32_t ve, uint32_t va, uint32_t plo, uint32_t phi, int bl) {
+    uint32_t R0 = va, R1 = va, R2 = va;
+    for (int j = 0; j < bl; j++) {
+        const uint32_t ml = 0u - ((plo >> j) & 1u);
+        const uint32_t mh = 0u - ((phi >> j) & 1u);
+        const uint32_t Em = ~(tls ^ ml) & ~(ths ^ mh) & ve;
+        const uint32_t s0 = R0 << 1;
+        const uint32_t n0 = s0 & Em;
+        if (E >= 1) {
+            const uint32_t s1 = R1 << 1;
+            const uint32_t n1 = (s1 & Em) | s0 | R0 | (n0 << 1);
+            if (E >= 2) {
+                const uint32_t s2 = R2 << 1;
+                R2 = (s2 & Em) | s1 | R1 | (n1 << 1);
+            }
+            R1 = n1;
+        }
+        R0 = n0;
+    }
+    if (R0 & va) return 0;
+    if (E >= 1 && (R1 & va)) return 1;
+    if (E >= 2 && (R2 & va)) return 2;
+    return E + 1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Seed families of the filter kernel (bl = 16, max_err <= 2).  The barcode is cut into four quarters
+// q0..q3 of 4 characters.  With <= 2 edits at least two quarters are copied unedited; attributing an
+// insertion to the quarter on its left, two untouched quarters a < b sit in the text 4(b-a)+delta apart,
+// delta = insertions - deletions in the quarters between them.  Enumerating the cases:
+//   adjacent pairs (0,1) (1,2) (2,3): delta = 0 -> an exact 8-mer at barcode offset 0 / 4 / 8
+//   (0,2) and (1,3): exactly one edit in between (two would leave an adjacent untouched pair) -> |delta| <= 1
+//   (0,3): one edit in q1 and one in q2 -> |delta| <= 2
+// so every barcode within 2 edits of some substring shares one of these six 16-bit keys with the text.
+// With <= 1 edit one half is untouched (families H1, H2); with 0 edits H1 alone suffices.
+// Keys are built from the bit-planes: low byte from the lo plane, high byte from the hi plane.
+// ---------------------------------------------------------------------------------------------------
+enum { SCT_F_H1 = 0, SCT_F_H2 = 1, SCT_F_MID = 2, SCT_F_02 = 3, SCT_F_13 = 4, SCT_F_03 = 5, SCT_NFAM = 6 };
+#define SCT_KEYS 65536
+
+SCT_HD uint32_t sct_key8(uint32_t lo, uint32_t hi, int t) {  // 8 consecutive characters starting at t
+    return ((lo >> t) & 0xFFu) | (((hi >> t) & 0xFFu) << 8);
+}
+SCT_HD uint32_t sct_key44(uint32_t lo, uint32_t hi, int t, int t2) {  // 4 characters at t and 4 at t2
+    const uint32_t l = ((lo >> t) & 0xFu) | (((lo >> t2) & 0xFu) << 4);
+    const uint32_t h = ((hi >> t) & 0xFu) | (((hi >> t2) & 0xFu) << 4);
+    return l | (h << 8);
+}
+// key of a 16-character barcode for family f
+SCT_HD uint32_t sct_pattern_key(int f, uint32_t plo, uint32_t phi) {
+    switch (f) {
+    case SCT_F_H1: return sct_key8(plo, phi, 0);
+    case SCT_F_H2: return sct_key8(plo, phi, 8);
+    case SCT_F_MID: return sct_key8(plo, phi, 4);
+    case SCT_F_02: return sct_key44(plo, phi, 0, 8);
+    case SCT_F_13: return sct_key44(plo, phi, 4, 12);
+    default: return sct_key44(plo, phi, 0, 12);
+    }
+}
+
+// Enumerate every (family, key) lookup the filter makes for a text of `len` characters (planes lo/hi).
+// The H1/H2/MID families share one 8-mer key per position, 02/13 share one pair key; the kernel and the
+// host-side completeness test both go through this function.
+template <int E, typename F>
+SCT_HD void sct_for_each_seed(uint32_t lo, uint32_t hi, int len, F &&fn) {
+    for (int t = 0; t + 8 <= len; t++) {
+        const uint32_t k = sct_key8(lo, hi, t);
+        fn(SCT_F_H1, k);
+        if (E >= 1) fn(SCT_F_H2, k);
+        if (E >= 2) fn(SCT_F_MID, k);
+    }
+    if (E >= 2) {
+        for (int d = -1; d <= 1; d++)
+            for (int t = 0; t + 12 + d <= len; t++) {
+                const uint32_t k = sct_key44(lo, hi, t, t + 8 + d);
+                fn(SCT_F_02, k);
+                fn(SCT_F_13, k);
+            }
+        for (int d = -2; d <= 2; d++)
+            for (int t = 0; t + 16 + d <= len; t++) fn(SCT_F_03, sct_key44(lo, hi, t, t + 12 + d));
+    }
+}

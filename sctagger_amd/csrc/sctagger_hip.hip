@@ -1,0 +1,862 @@
+// sctagger_hip.hip — gfx950 kernels and the C-ABI (include/sctagger_hip.h) of the match_trie path.
+//
+// What is computed (reference scTagger.py:643-716, observable semantics in SURVEY.md §8(a)-Q): for every
+// long-read segment the minimum infix edit distance (<= max_err) to any barcode on either strand, and the
+// sorted list of all (bid, strand) at that minimum.  The reference gets there with a trie of segment windows
+// and a recursive DFS per barcode; none of that is imitated here.
+//
+// Device data (all in HBM, resident for the life of the context / upload):
+//   patterns   np = 2*n_bc entries, index p = bid*2 + strand (strand 1 = forward, 0 = reverse complement, so
+//              ascending p is the reference's sorted(bids) order), stored as bit-planes uint2{lo, hi}
+//   seed tables (bl == 16): six families x (65536+1 offsets, np pattern ids), see sct_core.h
+//   segments   the caller's CSR bytes + int64 offsets, plus per segment the packed bit-planes {lo, hi, meta}
+//   results    min_e u8[n], cnt u32[n], slots u32[n][8] (filter path), hit_offs i64[n+1], hits u32[total]
+//
+// Kernels:
+//   k_pack        ASCII -> bit-planes, routes each segment to the filter / exhaustive / restricted-start path
+//   k_filter<E>   one lane per segment: seed lookups + transposed Wu-Manber verification (bl = 16, e <= 2)
+//   k_scan<...>   one wave per segment, lanes = barcodes: Myers bit-vector over every barcode (any bl <= 32,
+//                 any max_err) or, for segments with non-ACGT bytes when the reference's prefix length k > 0,
+//                 a plain DP whose row 0 encodes the allowed window starts; count pass + fill pass
+//   k_sum_* / k_offsets   exclusive scan of the per-segment hit counts into the CSR offsets
+//   k_fill        copies the filter path's slot lists into the CSR hit array
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sctagger_hip.h"
+#include "sct_core.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(SCT_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static constexpr int K_SLOTS = 8;          // hits kept per segment by the filter kernel before it defers
+static constexpr uint32_t CNT_DEFER = 0xFFFFFFFFu;
+static constexpr int META_NONACGT = 1 << 8;
+static constexpr int META_LONG = 1 << 9;   // more than 31 characters: not representable in the filter's planes
+
+// ------------------------------------------------------------------------------------------------------------
+// k_pack: one lane per segment. ASCII -> bit-planes of the first 31 characters, flags, and routing.
+//   route 0: filter path; route 1: exhaustive Myers scan; route 2: restricted-start DP scan
+// Segments shorter than bl - max_err cannot match anything (every window the reference inserts is at least
+// that long, scTagger.py:681) and are finished here.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_pack(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, int64_t n, int bl,
+                       int max_err, int prefix_len, int filter_ok, uint32_t *__restrict__ lo_out,
+                       uint32_t *__restrict__ hi_out, uint32_t *__restrict__ meta_out, uint8_t *__restrict__ min_e,
+                       uint32_t *__restrict__ cnt, int32_t *__restrict__ list_scan, int32_t *__restrict__ list_dp,
+                       uint32_t *__restrict__ counters) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t b0 = offs[r];
+    const int64_t len = offs[r + 1] - b0;
+    uint32_t lo = 0, hi = 0;
+    bool nonacgt = false;
+    const int head = len < 31 ? (int)len : 31;
+    for (int i = 0; i < head; i++) {
+        const uint8_t b = segs[b0 + i];
+        const uint32_t c = sct_code(b);
+        lo |= (c & 1u) << i;
+        hi |= (c >> 1) << i;
+        nonacgt |= !sct_is_acgt(b);
+    }
+    for (int64_t i = head; i < len; i++) nonacgt |= !sct_is_acgt(segs[b0 + i]);
+    uint32_t meta = (uint32_t)(len < 255 ? len : 255);
+    if (nonacgt) meta |= META_NONACGT;
+    if (len > 31) meta |= META_LONG;
+    lo_out[r] = lo;
+    hi_out[r] = hi;
+    meta_out[r] = meta;
+    if (len < bl - max_err) {
+        min_e[r] = SCT_NO_HIT;
+        cnt[r] = 0;
+        return;
+    }
+    if (nonacgt && prefix_len > 0) {
+        const uint32_t k = atomicAdd(&counters[1], 1u);
+        list_dp[k] = (int32_t)r;
+        cnt[r] = CNT_DEFER;
+    } else if (!filter_ok || len > 31) {
+        const uint32_t k = atomicAdd(&counters[0], 1u);
+        list_scan[k] = (int32_t)r;
+        cnt[r] = CNT_DEFER;
+    } else {
+        cnt[r] = 0;  // filter path fills it in
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_filter<E>: one lane per segment (bl == 16, max_err == E <= 2, <= 31 characters, routed here by k_pack).
+// For every seed lookup of sct_for_each_seed the lane walks the bucket of pattern ids sharing that key and
+// verifies each candidate with the transposed Wu-Manber automaton; it keeps the running minimum and up to
+// K_SLOTS distinct pattern ids at that minimum.  More than K_SLOTS ties defer the segment to the scan path.
+// ------------------------------------------------------------------------------------------------------------
+template <int E>
+struct FilterLane {
+    const uint32_t *__restrict__ tab_off;
+    const uint32_t *__restrict__ tab_ent;
+    const uint2 *__restrict__ pat;
+    int np;
+    uint32_t tls, ths, ve, va;
+    int best;
+    int nh;
+    uint32_t h[K_SLOTS];
+
+    __device__ __forceinline__ void add_hit(uint32_t pid) {
+        bool dup = false;
+#pragma unroll
+        for (int i = 0; i < K_SLOTS; i++) dup |= (i < nh) && (h[i] == pid);
+        if (dup) return;
+#pragma unroll
+        for (int i = 0; i < K_SLOTS; i++)
+            if (i == nh) h[i] = pid;
+        nh++;  // may run past K_SLOTS: that is the defer signal
+    }
+
+    __device__ __forceinline__ void operator()(int f, uint32_t key) {
+        const uint32_t *off = tab_off + (size_t)f * (SCT_KEYS + 1) + key;
+        const uint32_t s = off[0], e = off[1];
+        const uint32_t *ent = tab_ent + (size_t)f * np;
+        for (uint32_t k = s; k < e; k++) {
+            const uint32_t pid = ent[k];
+            const uint2 p = pat[pid];
+            const int d = wm_verify<E>(tls, ths, ve, va, p.x, p.y, 16);
+            if (d < best) {
+                best = d;
+                nh = 0;
+            }
+            if (d == best && d <= E) add_hit(pid);
+        }
+    }
+};
+
+template <int E>
+__global__ void __launch_bounds__(256)
+k_filter(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
+         int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
+         const uint2 *__restrict__ pat, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
+         uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan, uint32_t *__restrict__ counters) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (cnt[r] == CNT_DEFER) return;  // routed to a scan path by k_pack
+    const uint32_t meta = meta_in[r];
+    const int len = (int)(meta & 0xFF);
+    if (len < 16 - E) return;  // finished by k_pack
+    const uint32_t lo = lo_in[r], hi = hi_in[r];
+    FilterLane<E> L;
+    L.tab_off = tab_off;
+    L.tab_ent = tab_ent;
+    L.pat = pat;
+    L.np = np;
+    L.tls = lo << 1;
+    L.ths = hi << 1;
+    L.va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
+    L.ve = L.va & ~1u;
+    L.best = E + 1;
+    L.nh = 0;
+#pragma unroll
+    for (int i = 0; i < K_SLOTS; i++) L.h[i] = 0;
+    sct_for_each_seed<E>(lo, hi, len, L);
+    if (L.nh > K_SLOTS) {
+        const uint32_t k = atomicAdd(&counters[0], 1u);
+        list_scan[k] = (int32_t)r;
+        cnt[r] = CNT_DEFER;
+        return;
+    }
+    if (L.nh == 0) {
+        min_e[r] = SCT_NO_HIT;
+        cnt[r] = 0;
+        return;
+    }
+    // sort the (few) pattern ids ascending: odd-even transposition network on registers
+    if (L.nh > 1) {
+#pragma unroll
+        for (int i = 0; i < K_SLOTS; i++)
+            if (i >= L.nh) L.h[i] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int round = 0; round < K_SLOTS; round++) {
+#pragma unroll
+            for (int i = round & 1; i + 1 < K_SLOTS; i += 2) {
+                const uint32_t a = L.h[i], b = L.h[i + 1];
+                L.h[i] = a < b ? a : b;
+                L.h[i + 1] = a < b ? b : a;
+            }
+        }
+    }
+    min_e[r] = (uint8_t)L.best;
+    cnt[r] = (uint32_t)L.nh;
+#pragma unroll
+    for (int i = 0; i < K_SLOTS; i++)
+        if (i < L.nh) slots[(size_t)r * K_SLOTS + i] = L.h[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_scan<DP, FILL>: one wave per listed segment, lanes = patterns (64 per step), text wave-uniform.
+//   DP = false: Myers bit-vector (free start anywhere);  DP = true: plain DP, row 0 carries the allowed starts
+//   FILL = false: writes min_e / cnt;  FILL = true: writes the pattern ids at the minimum, ascending
+// The text is loaded 64 characters at a time, one per lane, and broadcast column by column with readlane.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static constexpr int DP_BIG = 100;
+
+template <bool DP, bool FILL>
+__global__ void __launch_bounds__(256)
+k_scan(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const int32_t *__restrict__ list,
+       const uint32_t *__restrict__ list_count, int64_t n_all, const uint2 *__restrict__ pat, int np, int bl,
+       int max_err, int prefix_len, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
+       const int64_t *__restrict__ hit_offs, uint32_t *__restrict__ hits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t n_list = list ? (int64_t)*list_count : n_all;
+    for (int64_t w = wave; w < n_list; w += n_waves) {
+        const int64_t r = list ? (int64_t)list[w] : w;
+        const int64_t b0 = offs[r];
+        const int64_t len = offs[r + 1] - b0;
+        if (len < bl - max_err) {  // only reachable when list == nullptr (k_pack filters otherwise)
+            if (!FILL && lane == 0) {
+                min_e[r] = SCT_NO_HIT;
+                cnt[r] = 0;
+            }
+            continue;
+        }
+        int target = 0;
+        int64_t out_base = 0;
+        if (FILL) {
+            target = min_e[r];
+            if (target == SCT_NO_HIT) continue;
+            out_base = hit_offs[r];
+        }
+        int lane_best = max_err + 1;
+        uint32_t lane_cnt = 0;
+        uint32_t written = 0;  // wave-uniform
+        for (int p0 = 0; p0 < np; p0 += 64) {
+            const int p = p0 + lane;
+            const bool pvalid = p < np;
+            const uint2 pp = pvalid ? pat[p] : make_uint2(0, 0);
+            int d;
+            if (!DP) {
+                MyersState<uint32_t> s;
+                myers_init(s, bl);
+                int best = bl;
+                for (int64_t c0 = 0; c0 < len; c0 += 64) {
+                    const int64_t ci = c0 + lane;
+                    const uint32_t my = ci < len ? sct_code(segs[b0 + ci]) : 0u;
+                    const int ncol = (int)(len - c0 < 64 ? len - c0 : 64);
+                    for (int j = 0; j < ncol; j++) {
+                        const uint32_t c = __builtin_amdgcn_readlane(my, j);
+                        myers_step<uint32_t>(s, pp.x, pp.y, c, bl);
+                        best = min(best, s.score);
+                    }
+                }
+                d = best;
+            } else {
+                // col[i] = D[i][j] for i = 0..bl, in registers.  Row 0 is the distance back to the nearest text
+                // position at which the reference would start a window (scTagger.py:679-682): a window may start at
+                // position s iff s + k <= len and its first k raw bytes are all in "ACGT" (k = prefix_len).  Letting a
+                // window start at s lowers D[0][s] to 0, and through vertical moves D[i][s] to at most i.
+                int col[SCT_MAX_BL + 1];
+#pragma unroll
+                for (int i = 0; i <= SCT_MAX_BL; i++) col[i] = DP_BIG;
+                int best = DP_BIG;
+                for (int64_t c0 = 0; c0 < len; c0 += 64) {
+                    const int64_t ci = c0 + lane;
+                    uint32_t my = 0;
+                    bool al = false;
+                    if (ci < len) {
+                        my = sct_code(segs[b0 + ci]);
+                        al = ci + prefix_len <= len;
+                        for (int q = 0; q < prefix_len && al; q++) al = sct_is_acgt(segs[b0 + ci + q]);
+                    }
+                    const uint64_t almask = __ballot(al);
+                    const int ncol = (int)(len - c0 < 64 ? len - c0 : 64);
+                    for (int j = 0; j < ncol; j++) {
+                        const uint32_t c = __builtin_amdgcn_readlane(my, j);
+                        if ((almask >> j) & 1) {
+#pragma unroll
+                            for (int i = 0; i <= SCT_MAX_BL; i++) col[i] = min(col[i], i);
+                        }
+                        int diag = col[0];
+                        col[0] = min(col[0] + 1, DP_BIG);
+#pragma unroll
+                        for (int i = 1; i <= SCT_MAX_BL; i++) {
+                            if (i <= bl) {
+                                const uint32_t pc = ((pp.x >> (i - 1)) & 1u) | (((pp.y >> (i - 1)) & 1u) << 1);
+                                const int up = col[i];
+                                const int v = min(min(diag + (pc != c ? 1 : 0), up + 1), col[i - 1] + 1);
+                                diag = up;
+                                col[i] = min(v, DP_BIG);
+                                if (i == bl) best = min(best, col[i]);
+                            }
+                        }
+                    }
+                }
+                d = best;
+            }
+            const bool ok = pvalid && d <= max_err;
+            if (!FILL) {
+                if (ok) {
+                    if (d < lane_best) {
+                        lane_best = d;
+                        lane_cnt = 0;
+                    }
+                    if (d == lane_best) lane_cnt++;
+                }
+            } else {
+                const bool hit = ok && d == target;
+                const uint64_t m = __ballot(hit);
+                if (hit) {
+                    const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    hits[out_base + written + before] = (uint32_t)p;
+                }
+                written += (uint32_t)__popcll(m);
+            }
+        }
+        if (!FILL) {
+            const int wb = wave_min(lane_best);
+            const uint32_t total = wave_sum(lane_best == wb ? lane_cnt : 0u);
+            if (lane == 0) {
+                if (wb <= max_err) {
+                    min_e[r] = (uint8_t)wb;
+                    cnt[r] = total;
+                } else {
+                    min_e[r] = SCT_NO_HIT;
+                    cnt[r] = 0;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// exclusive scan of cnt[n] (u32) into hit_offs[n+1] (i64): per-block sums, one-block scan of the sums, offsets
+// ------------------------------------------------------------------------------------------------------------
+static constexpr int SCAN_ITEMS = 8;                       // per thread
+static constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;        // elements per block
+
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *total, uint64_t *lds /* >= 5 */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    uint64_t base = 0;
+    for (int i = 0; i < w; i++) base += lds[i];
+    if (threadIdx.x == blockDim.x - 1) lds[4] = base + inc;
+    __syncthreads();
+    *total = lds[4];
+    const uint64_t r = base + inc - v;
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_sum_blocks(const uint32_t *__restrict__ cnt, int64_t n, uint64_t *__restrict__ sums) {
+    __shared__ uint64_t lds[8];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < n) s += cnt[base + i];
+    uint64_t total;
+    block_exclusive_scan(s, &total, lds);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) k_scan_sums(uint64_t *__restrict__ sums, int64_t nb, uint64_t *__restrict__ total_out) {
+    __shared__ uint64_t lds[8];
+    uint64_t carry = 0;
+    for (int64_t c0 = 0; c0 < nb; c0 += 256) {
+        const int64_t i = c0 + threadIdx.x;
+        const uint64_t v = i < nb ? sums[i] : 0;
+        uint64_t total;
+        const uint64_t ex = block_exclusive_scan(v, &total, lds);
+        if (i < nb) sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(256) k_offsets(const uint32_t *__restrict__ cnt, int64_t n, const uint64_t *__restrict__ sums,
+                                                  const uint64_t *__restrict__ total, int64_t *__restrict__ hit_offs) {
+    __shared__ uint64_t lds[8];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = base + i < n ? cnt[base + i] : 0u;
+        s += v[i];
+    }
+    uint64_t tot;
+    uint64_t run = sums[blockIdx.x] + block_exclusive_scan(s, &tot, lds);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) hit_offs[base + i] = (int64_t)run;
+        run += v[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) hit_offs[n] = (int64_t)*total;
+}
+
+// filter path: slots -> CSR
+__global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ slots,
+                                               const int64_t *__restrict__ hit_offs, const uint32_t *__restrict__ route_cnt,
+                                               int64_t n, uint32_t *__restrict__ hits) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (route_cnt[r] == CNT_DEFER) return;  // written by the scan path's fill pass
+    const uint32_t c = cnt[r];
+    const int64_t o = hit_offs[r];
+    for (uint32_t i = 0; i < c; i++) hits[o + i] = slots[(size_t)r * K_SLOTS + i];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap && p) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(SCT_E_HIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T *as() const { return (T *)p; }
+};
+
+struct TimedKernel {
+    const char *name;
+    hipEvent_t a, b;
+};
+
+struct sct_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // barcodes
+    int n_bc = 0, bl = 0, np = 0;
+    bool have_bc = false, have_tables = false;
+    DevBuf pat, tab_off, tab_ent;
+    // segments
+    int64_t n_seg = -1, seg_bytes = 0;
+    DevBuf segs, offs;
+    // work / results
+    DevBuf lo, hi, meta, min_e, cnt, route, slots, list_scan, list_dp, counters, hit_offs, sums, total, hits;
+    int64_t n_hits = 0;
+    bool have_result = false;
+    // options
+    bool force_exhaustive = false, timing = true;
+    // timing
+    std::vector<TimedKernel> timed;
+    std::vector<std::pair<const char *, float>> last_ms;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+    int64_t stats[4] = {0, 0, 0, 0};
+
+    hipEvent_t ev() {
+        if (pool_used == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[pool_used++];
+    }
+};
+
+struct Timer {
+    sct_ctx *c;
+    TimedKernel t{};
+    bool on;
+    Timer(sct_ctx *c_, const char *name) : c(c_), on(c_->timing) {
+        if (!on) return;
+        t.name = name;
+        t.a = c->ev();
+        t.b = c->ev();
+        if (!t.a || !t.b) { on = false; return; }
+        (void)hipEventRecord(t.a, c->stream);
+    }
+    ~Timer() {
+        if (!on) return;
+        (void)hipEventRecord(t.b, c->stream);
+        c->timed.push_back(t);
+    }
+};
+
+extern "C" const char *sct_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sct_prefix_len(int threads) {
+    int k = 0;
+    long long n = 1;
+    while (threads > n) {
+        n *= 4;
+        k++;
+    }
+    return k;
+}
+
+extern "C" int sct_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int sct_create(int device, sct_ctx **out) {
+    if (!out) return fail(SCT_E_ARG, "sct_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(SCT_E_NODEV, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(SCT_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    sct_ctx *c = new sct_ctx();
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(SCT_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return SCT_OK;
+}
+
+extern "C" void sct_destroy(sct_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
+                      &c->cnt, &c->route, &c->slots, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
+                      &c->total, &c->hits};
+    for (DevBuf *b : bufs) b->release();
+    for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int sct_sync(sct_ctx *c) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SCT_OK;
+}
+
+extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
+    if (!c || !key) return fail(SCT_E_ARG, "sct_set_option: NULL argument");
+    if (!strcmp(key, "force_exhaustive")) c->force_exhaustive = value != 0;
+    else if (!strcmp(key, "timing")) c->timing = value != 0;
+    else return fail(SCT_E_ARG, "unknown option '%s'", key);
+    return SCT_OK;
+}
+
+// rev_compl of the reference (scTagger.py:148-156) on raw bytes
+static inline uint8_t comp_byte(uint8_t b) {
+    switch (b) {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'T': return 'A';
+    default: return b;
+    }
+}
+
+extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t bl) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    if (n < 0 || (n > 0 && !bc)) return fail(SCT_E_ARG, "sct_set_barcodes: bad barcode buffer");
+    if (bl < 1) return fail(SCT_E_ARG, "barcode length must be positive (got %d)", bl);
+    if (bl > SCT_MAX_BL) return fail(SCT_E_UNSUPPORTED, "barcode length %d exceeds the supported maximum %d", bl, SCT_MAX_BL);
+    if ((int64_t)n * 2 > 0x7FFFFFFF) return fail(SCT_E_ARG, "too many barcodes");
+    const uint8_t *b = (const uint8_t *)bc;
+    for (int64_t i = 0; i < (int64_t)n * bl; i++)
+        if (b[i] >= 128) return fail(SCT_E_ARG, "barcode %lld contains byte 0x%02x >= 128", (long long)(i / bl), b[i]);
+    HIPCHK(hipSetDevice(c->device));
+    const int np = 2 * n;
+    std::vector<uint2> pat((size_t)np);
+    for (int i = 0; i < n; i++) {
+        const uint8_t *s = b + (size_t)i * bl;
+        uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
+        for (int j = 0; j < bl; j++) {
+            const uint32_t cf = sct_code(s[j]);
+            const uint32_t cr = sct_code(comp_byte(s[bl - 1 - j]));
+            flo |= (cf & 1u) << j;
+            fhi |= (cf >> 1) << j;
+            rlo |= (cr & 1u) << j;
+            rhi |= (cr >> 1) << j;
+        }
+        pat[(size_t)2 * i + 0] = make_uint2(rlo, rhi);  // strand 0 = reverse complement (False sorts first)
+        pat[(size_t)2 * i + 1] = make_uint2(flo, fhi);  // strand 1 = forward
+    }
+    if (c->pat.ensure(sizeof(uint2) * (size_t)(np ? np : 1))) return SCT_E_HIP;
+    if (np) HIPCHK(hipMemcpyAsync(c->pat.p, pat.data(), sizeof(uint2) * (size_t)np, hipMemcpyHostToDevice, c->stream));
+    c->have_tables = false;
+    if (bl == 16) {
+        // seed tables: counting sort of the pattern ids by key, per family (ids ascending inside a bucket)
+        std::vector<uint32_t> off((size_t)SCT_NFAM * (SCT_KEYS + 1), 0u), ent((size_t)SCT_NFAM * (np ? np : 1));
+        for (int f = 0; f < SCT_NFAM; f++) {
+            uint32_t *o = off.data() + (size_t)f * (SCT_KEYS + 1);
+            for (int p = 0; p < np; p++) o[sct_pattern_key(f, pat[p].x, pat[p].y) + 1]++;
+            for (int k = 0; k < SCT_KEYS; k++) o[k + 1] += o[k];
+            std::vector<uint32_t> cur(o, o + SCT_KEYS);
+            uint32_t *e = ent.data() + (size_t)f * np;
+            for (int p = 0; p < np; p++) e[cur[sct_pattern_key(f, pat[p].x, pat[p].y)]++] = (uint32_t)p;
+        }
+        if (c->tab_off.ensure(off.size() * sizeof(uint32_t))) return SCT_E_HIP;
+        if (c->tab_ent.ensure(ent.size() * sizeof(uint32_t))) return SCT_E_HIP;
+        HIPCHK(hipMemcpyAsync(c->tab_off.p, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->tab_ent.p, ent.data(), ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->have_tables = true;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_bc = n;
+    c->bl = bl;
+    c->np = np;
+    c->have_bc = true;
+    c->have_result = false;
+    return SCT_OK;
+}
+
+extern "C" int sct_upload_segments(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    if (n < 0 || !offs) return fail(SCT_E_ARG, "sct_upload_segments: bad offsets");
+    if (n >= 0x7FFFFFF0) return fail(SCT_E_ARG, "at most 2^31-16 segments per call (shard the input)");
+    if (offs[0] != 0) return fail(SCT_E_ARG, "offs[0] must be 0");
+    for (int64_t i = 0; i < n; i++)
+        if (offs[i + 1] < offs[i]) return fail(SCT_E_ARG, "offs must be non-decreasing (row %lld)", (long long)i);
+    const int64_t bytes = offs[n];
+    if (bytes > 0 && !segs) return fail(SCT_E_ARG, "segs is NULL");
+    const uint8_t *s = (const uint8_t *)segs;
+    uint8_t acc = 0;
+    for (int64_t i = 0; i < bytes; i++) acc |= s[i];
+    if (acc & 0x80) {
+        for (int64_t i = 0; i < bytes; i++)
+            if (s[i] >= 128) return fail(SCT_E_ARG, "segment bytes contain 0x%02x >= 128 at offset %lld", s[i], (long long)i);
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->segs.ensure((size_t)bytes + 64)) return SCT_E_HIP;
+    if (c->offs.ensure(sizeof(int64_t) * (size_t)(n + 1))) return SCT_E_HIP;
+    if (bytes) HIPCHK(hipMemcpyAsync(c->segs.p, segs, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->offs.p, offs, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_seg = n;
+    c->seg_bytes = bytes;
+    c->have_result = false;
+    return SCT_OK;
+}
+
+static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_hits_out) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    if (!c->have_bc) return fail(SCT_E_STATE, "sct_run before sct_set_barcodes");
+    if (c->n_seg < 0) return fail(SCT_E_STATE, "sct_run before sct_upload_segments");
+    if (max_err < 0 || max_err >= c->bl) return fail(SCT_E_ARG, "need 0 <= max_err < barcode length (got %d, bl %d)", max_err, c->bl);
+    if (threads < 1) return fail(SCT_E_ARG, "threads must be >= 1");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t n = c->n_seg;
+    const int np = c->np, bl = c->bl;
+    const int prefix_len = sct_prefix_len(threads);
+    const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0;
+    const size_t n1 = (size_t)(n ? n : 1);
+    if (c->lo.ensure(4 * n1) || c->hi.ensure(4 * n1) || c->meta.ensure(4 * n1) || c->min_e.ensure(n1) ||
+        c->cnt.ensure(4 * n1) || c->route.ensure(4 * n1) || c->list_scan.ensure(4 * n1) || c->list_dp.ensure(4 * n1) ||
+        c->counters.ensure(64) || c->hit_offs.ensure(8 * (n1 + 1)) || c->total.ensure(8))
+        return SCT_E_HIP;
+    if (filter_ok && c->slots.ensure(4 * n1 * K_SLOTS)) return SCT_E_HIP;
+    const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (c->sums.ensure(8 * (size_t)(nb ? nb : 1))) return SCT_E_HIP;
+    c->timed.clear();
+    c->pool_used = 0;
+    c->have_result = false;
+    hipStream_t st = c->stream;
+    HIPCHK(hipMemsetAsync(c->counters.p, 0, 64, st));
+    uint32_t *counters = c->counters.as<uint32_t>();
+    if (n > 0) {
+        {
+            Timer t(c, "k_pack");
+            k_pack<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), n, bl, max_err, prefix_len,
+                                                       filter_ok ? 1 : 0, c->lo.as<uint32_t>(), c->hi.as<uint32_t>(),
+                                                       c->meta.as<uint32_t>(), c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(),
+                                                       c->list_scan.as<int32_t>(), c->list_dp.as<int32_t>(), counters);
+        }
+        if (filter_ok) {
+            Timer t(c, "k_filter");
+            const unsigned g = blocks_for(n, 256);
+#define LAUNCH_FILTER(E)                                                                                              \
+    k_filter<E><<<g, 256, 0, st>>>(c->lo.as<uint32_t>(), c->hi.as<uint32_t>(), c->meta.as<uint32_t>(), n,              \
+                                   c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->pat.as<uint2>(), np,       \
+                                   c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(),             \
+                                   c->list_scan.as<int32_t>(), counters)
+            if (max_err == 0) LAUNCH_FILTER(0);
+            else if (max_err == 1) LAUNCH_FILTER(1);
+            else LAUNCH_FILTER(2);
+#undef LAUNCH_FILTER
+        }
+        // remember which rows were deferred (cnt is about to be overwritten by the scan path's count pass)
+        HIPCHK(hipMemcpyAsync(c->route.p, c->cnt.p, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
+        const unsigned scan_grid = 256 * 8;  // grid-stride over the lists: 8 blocks of 4 waves per CU
+        {
+            Timer t(c, "k_scan_count");
+            k_scan<false, false><<<scan_grid, 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(),
+                                                            counters + 0, n, c->pat.as<uint2>(), np, bl, max_err, prefix_len,
+                                                            c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), nullptr, nullptr);
+        }
+        {
+            Timer t(c, "k_dp_count");
+            k_scan<true, false><<<scan_grid, 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_dp.as<int32_t>(),
+                                                           counters + 1, n, c->pat.as<uint2>(), np, bl, max_err, prefix_len,
+                                                           c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), nullptr, nullptr);
+        }
+        {
+            Timer t(c, "k_offsets");
+            k_sum_blocks<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>());
+            k_scan_sums<<<1, 256, 0, st>>>(c->sums.as<uint64_t>(), nb, c->total.as<uint64_t>());
+            k_offsets<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>(), c->total.as<uint64_t>(),
+                                                    c->hit_offs.as<int64_t>());
+        }
+    } else {
+        HIPCHK(hipMemsetAsync(c->hit_offs.p, 0, 8, st));
+        HIPCHK(hipMemsetAsync(c->total.p, 0, 8, st));
+    }
+    uint64_t total = 0;
+    uint32_t hc[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(&total, c->total.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hc, c->counters.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (c->hits.ensure(4 * (size_t)(total ? total : 1))) return SCT_E_HIP;
+    if (n > 0 && total > 0) {
+        const unsigned scan_grid = 256 * 8;
+        if (filter_ok) {
+            Timer t(c, "k_fill");
+            k_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->hit_offs.as<int64_t>(),
+                                                       c->route.as<uint32_t>(), n, c->hits.as<uint32_t>());
+        }
+        if (hc[0]) {
+            Timer t(c, "k_scan_fill");
+            k_scan<false, true><<<scan_grid, 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(),
+                                                           counters + 0, n, c->pat.as<uint2>(), np, bl, max_err, prefix_len,
+                                                           c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->hit_offs.as<int64_t>(),
+                                                           c->hits.as<uint32_t>());
+        }
+        if (hc[1]) {
+            Timer t(c, "k_dp_fill");
+            k_scan<true, true><<<scan_grid, 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_dp.as<int32_t>(),
+                                                          counters + 1, n, c->pat.as<uint2>(), np, bl, max_err, prefix_len,
+                                                          c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->hit_offs.as<int64_t>(),
+                                                          c->hits.as<uint32_t>());
+        }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    c->last_ms.clear();
+    for (const TimedKernel &t : c->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) c->last_ms.emplace_back(t.name, ms);
+    }
+    c->n_hits = (int64_t)total;
+    c->stats[0] = n - hc[0] - hc[1];
+    c->stats[1] = hc[0];
+    c->stats[2] = hc[1];
+    c->stats[3] = (int64_t)total;
+    c->have_result = true;
+    if (n_hits_out) *n_hits_out = (int64_t)total;
+    return SCT_OK;
+}
+
+extern "C" int sct_download(sct_ctx *c, uint8_t *min_e, int64_t *hit_offs, uint32_t *hits) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    if (!c->have_result) return fail(SCT_E_STATE, "sct_download without a completed sct_run");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t n = c->n_seg;
+    if (min_e && n) HIPCHK(hipMemcpyAsync(min_e, c->min_e.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (hit_offs) HIPCHK(hipMemcpyAsync(hit_offs, c->hit_offs.p, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, c->stream));
+    if (hits && c->n_hits) HIPCHK(hipMemcpyAsync(hits, c->hits.p, 4 * (size_t)c->n_hits, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SCT_OK;
+}
+
+extern "C" int sct_match(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n, int32_t max_err, int32_t threads,
+                         uint8_t *min_e, int64_t *hit_offs, uint32_t **hits, int64_t *n_hits) {
+    if (!hits || !n_hits || !min_e || !hit_offs) return fail(SCT_E_ARG, "sct_match: NULL output pointer");
+    *hits = nullptr;
+    *n_hits = 0;
+    int rc = sct_upload_segments(c, segs, offs, n);
+    if (rc) return rc;
+    int64_t total = 0;
+    rc = sct_run(c, max_err, threads, &total);
+    if (rc) return rc;
+    uint32_t *h = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(total ? total : 1));
+    if (!h) return fail(SCT_E_ARG, "out of host memory for %lld hits", (long long)total);
+    rc = sct_download(c, min_e, hit_offs, h);
+    if (rc) {
+        free(h);
+        return rc;
+    }
+    *hits = h;
+    *n_hits = total;
+    return SCT_OK;
+}
+
+extern "C" void sct_free_hits(sct_ctx *, uint32_t *hits) { free(hits); }
+
+extern "C" int sct_last_timing(sct_ctx *c, const char **names, float *ms, int cap) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    const int k = (int)c->last_ms.size();
+    for (int i = 0; i < k && i < cap; i++) {
+        if (names) names[i] = c->last_ms[i].first;
+        if (ms) ms[i] = c->last_ms[i].second;
+    }
+    return k;
+}
+
+extern "C" int sct_last_stats(sct_ctx *c, int64_t *out, int cap) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    for (int i = 0; i < 4 && i < cap; i++) out[i] = c->stats[i];
+    return 4;
+}

@@ -1,0 +1,208 @@
+"""Host-side mirror of the reference's match_trie stage (scTagger.py:602-640, 688-716, 758-790).
+
+Same module-level state, same function names and argument meaning as the reference, so that
+code written against `scTagger.py` reads the same here:
+
+    read_sr_barcodes(path)            -> fills `barcodes`, `barcodes_rc`      (reference :631-640)
+    read_long_reads(path)             -> fills `lr_names`, `lr_segs`, `lr_segs_idxs`   (:602-628)
+    run_get_matches_prefix(e, threads) -> dict[rid -> (e, set[(bid, strand)])]        (:688-716)
+    match_trie(args)                  -> reads, matches, writes the TSV                (:758-790)
+
+The matching itself is one call into libsctagger_hip.so (sctagger_amd/_native.py); nothing is
+computed on the CPU and there is no fallback.  `run_get_matches_prefix_arrays` is the same seam
+returning flat arrays (what the writer consumes; a Python dict of 10^7 rows is only built on request).
+Diagnostics go to stderr (the reference prints them to stdout).
+"""
+import gzip
+import sys
+import threading
+
+import numpy as np
+
+from . import _native
+
+barcodes = None       # list[str], column 0 of -sr
+barcodes_rc = None    # list[str], rev_compl of each
+lr_segs = None        # uint8[sum of lengths]: the reference's RawArray('c')
+lr_segs_idxs = None   # int64[n+1]: the reference's RawArray('i') (int32 there)
+lr_names = None       # list[str], column 0 of -lr
+
+_COMPLEMENT = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def _log(msg):
+    print(msg, file=sys.stderr)
+
+
+def rev_compl(s):
+    """Reverse complement; A<->T, C<->G, every other character unchanged (reference :148-156)."""
+    return "".join(_COMPLEMENT.get(c, c) for c in reversed(s))
+
+
+def _open_text(path):
+    # the reference decides by the '.gz' suffix only (:605, :634)
+    return gzip.open(path, "rt") if path.endswith(".gz") else open(path, "r")
+
+
+def read_sr_barcodes(path):
+    """Column 0 of every line of the (gz) TSV (reference :631-640)."""
+    global barcodes, barcodes_rc
+    _log("Reading short reads barcodes")
+    with _open_text(path) as f:
+        barcodes = [line.rstrip("\n").split("\t")[0] for line in f]
+    barcodes_rc = [rev_compl(b) for b in barcodes]
+    _log("There are {:,} SR barcodes".format(len(barcodes)))
+
+
+def read_long_reads(path):
+    """Column 0 -> lr_names, column 3 -> CSR bytes + offsets (reference :602-628).
+
+    A line with fewer than 4 tab-separated fields raises IndexError, as in the reference."""
+    global lr_names, lr_segs, lr_segs_idxs
+    _log("Reading long reads barcodes")
+    names, segs = [], []
+    with _open_text(path) as f:
+        for line in f:
+            parts = line.rstrip("\n").split("\t")
+            names.append(parts[0])
+            segs.append(parts[3])
+    lr_names = names
+    lens = np.fromiter((len(s) for s in segs), dtype=np.int64, count=len(segs))
+    lr_segs_idxs = np.zeros(len(segs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=lr_segs_idxs[1:])
+    # the reference stores ord(c) into a c_char array: a code point above 255 raises there too
+    lr_segs = np.frombuffer("".join(segs).encode("latin-1"), dtype=np.uint8)
+    _log("There are {:,} LRs".format(len(lr_names)))
+
+
+def set_inputs(bcs, names, segs, offs):
+    """Install the module state from memory instead of files (tests, benchmarks)."""
+    global barcodes, barcodes_rc, lr_names, lr_segs, lr_segs_idxs
+    barcodes = list(bcs)
+    barcodes_rc = [rev_compl(b) for b in barcodes]
+    lr_names = names
+    lr_segs = np.ascontiguousarray(segs, dtype=np.uint8)
+    lr_segs_idxs = np.ascontiguousarray(offs, dtype=np.int64)
+
+
+def shard_ranges(n, parts):
+    """Contiguous rid ranges, one per device: [(lo, hi), ...] covering [0, n)."""
+    parts = max(1, int(parts))
+    edges = [(n * i) // parts for i in range(parts + 1)]
+    return [(edges[i], edges[i + 1]) for i in range(parts)]
+
+
+def concat_shards(results):
+    """Concatenate per-shard (min_e, hit_offs, hits) in rid order, rebasing the CSR offsets.
+
+    This is the whole multi-GPU merge: segments are independent, so unlike the reference's per-rid
+    min/union over prefix tasks (:705-715) nothing has to be reconciled."""
+    min_e = np.concatenate([r[0] for r in results]) if results else np.empty(0, np.uint8)
+    hits = np.concatenate([r[2] for r in results]) if results else np.empty(0, np.uint32)
+    total = 1 + sum(r[1].size - 1 for r in results)
+    offs = np.zeros(total, dtype=np.int64)
+    at, base = 0, 0
+    for _, ho, _h in results:
+        k = ho.size - 1
+        offs[at:at + k + 1] = ho + base
+        at += k
+        base += int(ho[-1])
+    return min_e, offs, hits
+
+
+def _barcode_matrix(bl):
+    rows = [b.encode("latin-1") for b in barcodes]
+    if any(len(r) != bl for r in rows):
+        raise AssertionError({len(b) for b in barcodes})
+    return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), bl)
+
+
+def run_get_matches_prefix_arrays(max_error, threads, devices=(0,), barcode_length=None):
+    """The seam, as arrays: -> (min_e uint8[n], hit_offs int64[n+1], hits uint32[total]).
+
+    hits are (bid << 1 | strand), strand 1 = forward, ascending per segment == sorted(bids) of the
+    reference (:789).  `threads` only sets the reference's prefix length (non-ACGT window rule).
+    With several devices the rids are cut into contiguous ranges, one host thread + context each."""
+    bl = barcode_length if barcode_length is not None else (len(barcodes[0]) if barcodes else 16)
+    bc = _barcode_matrix(bl)
+    n = lr_segs_idxs.size - 1
+    devices = list(devices)
+    ranges = shard_ranges(n, len(devices))
+    results = [None] * len(devices)
+    errors = []
+
+    def work(i):
+        try:
+            lo, hi = ranges[i]
+            offs = lr_segs_idxs[lo:hi + 1] - lr_segs_idxs[lo]
+            segs = lr_segs[lr_segs_idxs[lo]:lr_segs_idxs[hi]]
+            with _native.Matcher(devices[i]) as m:
+                m.set_barcodes(bc, bl)
+                results[i] = m.match(segs, offs, max_error, threads)
+        except BaseException as e:  # re-raised on the caller's thread
+            errors.append(e)
+
+    if len(devices) == 1:
+        work(0)
+    else:
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(devices))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    if errors:
+        raise errors[0]
+    return concat_shards(results)
+
+
+def run_get_matches_prefix(max_error, threads, devices=(0,)):
+    """dict[rid -> (e, set[(bid, strand)])] exactly as the reference returns it (:688-716)."""
+    min_e, hit_offs, hits = run_get_matches_prefix_arrays(max_error, threads, devices)
+    result = {}
+    for rid in np.flatnonzero(min_e != _native.NO_HIT):
+        h = hits[hit_offs[rid]:hit_offs[rid + 1]]
+        result[int(rid)] = (int(min_e[rid]), {(int(x) >> 1, bool(x & 1)) for x in h})
+    return result
+
+
+def write_matches(outfile, min_e, hit_offs, hits, chunk=200_000):
+    """The output block of the reference (:770-790): matched rids only, in rid order, 5 columns."""
+    # pattern id p = bid*2 + strand -> the string the reference prints (:789)
+    table = [None] * (2 * len(barcodes))
+    table[0::2] = barcodes_rc
+    table[1::2] = barcodes
+    rids = np.flatnonzero(min_e != _native.NO_HIT)
+    buf = lr_segs.tobytes()
+    idx = lr_segs_idxs
+    for c0 in range(0, rids.size, chunk):
+        lines = []
+        for rid in rids[c0:c0 + chunk].tolist():
+            a, b = hit_offs[rid], hit_offs[rid + 1]
+            lines.append("%s\t%d\t%d\t%s\t%s\n" % (
+                lr_names[rid], min_e[rid], b - a, buf[idx[rid]:idx[rid + 1]].decode("latin-1"),
+                ",".join([table[p] for p in hits[a:b].tolist()])))
+        outfile.write("".join(lines))
+
+
+def match_trie(args):
+    """reference :758-790. args: long_read_segments, short_read_barcodes, max_error, barcode_length,
+    threads, outfile (and mem/plotfile, accepted and unused as in the reference)."""
+    read_sr_barcodes(args.short_read_barcodes)
+    barcode_lens = {len(b) for b in barcodes}
+    assert barcode_lens == {args.barcode_length}, barcode_lens
+    read_long_reads(args.long_read_segments)
+    devices = getattr(args, "devices", None) or (0,)
+    min_e, hit_offs, hits = run_get_matches_prefix_arrays(
+        max_error=args.max_error, threads=args.threads, devices=devices, barcode_length=args.barcode_length)
+    if args.outfile:
+        if args.outfile.endswith("gz"):
+            outfile = gzip.open(args.outfile, "wt", compresslevel=getattr(args, "gzip_level", 6))
+        else:
+            outfile = open(args.outfile, "w")
+    else:
+        outfile = sys.stdout
+    try:
+        write_matches(outfile, min_e, hit_offs, hits)
+    finally:
+        if outfile is not sys.stdout:
+            outfile.close()

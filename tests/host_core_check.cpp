@@ -1,0 +1,175 @@
+// Host-side check of the arithmetic in sctagger_amd/csrc/sct_core.h (the header the gfx950 kernels are
+// built from) against a plain dynamic-programming infix Levenshtein.  Test infrastructure only: built and
+// run by tests/test_core_host.py with g++; nothing here is shipped or used by the product path.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../sctagger_amd/csrc/sct_core.h"
+
+static int brute_infix(const std::vector<int> &p, const std::vector<int> &t) {
+    const int m = (int)p.size(), n = (int)t.size();
+    std::vector<int> prev(m + 1), cur(m + 1);
+    for (int i = 0; i <= m; i++) prev[i] = i;
+    int best = prev[m];
+    for (int j = 1; j <= n; j++) {
+        cur[0] = 0;
+        for (int i = 1; i <= m; i++) cur[i] = std::min({prev[i - 1] + (p[i - 1] != t[j - 1]), prev[i] + 1, cur[i - 1] + 1});
+        best = std::min(best, cur[m]);
+        std::swap(prev, cur);
+    }
+    return best;
+}
+
+static void planes(const std::vector<int> &s, uint64_t &lo, uint64_t &hi) {
+    lo = hi = 0;
+    for (size_t i = 0; i < s.size(); i++) {
+        lo |= (uint64_t)(s[i] & 1) << i;
+        hi |= (uint64_t)(s[i] >> 1) << i;
+    }
+}
+
+template <typename W>
+static int myers_infix(const std::vector<int> &p, const std::vector<int> &t) {
+    uint64_t lo, hi;
+    planes(p, lo, hi);
+    MyersState<W> s;
+    const int m = (int)p.size();
+    myers_init(s, m);
+    int best = m;
+    for (int c : t) {
+        myers_step<W>(s, (W)lo, (W)hi, (uint32_t)c, m);
+        best = std::min(best, s.score);
+    }
+    return best;
+}
+
+template <int E>
+static int wm(const std::vector<int> &p, const std::vector<int> &t) {
+    uint64_t plo, phi, tlo, thi;
+    planes(p, plo, phi);
+    planes(t, tlo, thi);
+    const int L = (int)t.size();
+    const uint32_t va = L >= 31 ? 0xFFFFFFFFu : ((1u << (L + 1)) - 1u);
+    const uint32_t ve = va & ~1u;
+    return wm_verify<E>((uint32_t)tlo << 1, (uint32_t)thi << 1, ve, va, (uint32_t)plo, (uint32_t)phi, (int)p.size());
+}
+
+struct SeedHit {
+    const uint32_t *keys;  // the pattern's six family keys
+    bool hit = false;
+    void operator()(int f, uint32_t k) {
+        if (keys[f] == k) hit = true;
+    }
+};
+
+template <int E>
+static bool seeds_cover(const std::vector<int> &p, const std::vector<int> &t) {
+    uint64_t plo, phi, tlo, thi;
+    planes(p, plo, phi);
+    planes(t, tlo, thi);
+    uint32_t keys[SCT_NFAM];
+    for (int f = 0; f < SCT_NFAM; f++) keys[f] = sct_pattern_key(f, (uint32_t)plo, (uint32_t)phi);
+    SeedHit sh;
+    sh.keys = keys;
+    sct_for_each_seed<E>((uint32_t)tlo, (uint32_t)thi, (int)t.size(), sh);
+    return sh.hit;
+}
+
+int main() {
+    std::mt19937_64 rng(12345);
+    auto rnd = [&](int n) { return (int)(rng() % (uint64_t)n); };
+    long checked = 0;
+    // 1. Myers, 32- and 64-bit words, every pattern length, texts 0..70, small alphabets to force matches
+    for (int it = 0; it < 60000; it++) {
+        const int m = 1 + rnd(it % 2 ? 32 : 64), n = rnd(71), alpha = 1 + rnd(4);
+        std::vector<int> p(m), t(n);
+        for (auto &x : p) x = rnd(alpha);
+        for (auto &x : t) x = rnd(alpha);
+        if (n >= m && rnd(2)) {  // plant an edited copy
+            int at = rnd(n - m + 1);
+            for (int i = 0; i < m; i++) t[at + i] = p[i];
+            for (int k = rnd(4); k > 0; k--) t[rnd(n)] = rnd(4);
+        }
+        const int want = brute_infix(p, t);
+        if (m <= 32 && myers_infix<uint32_t>(p, t) != want) { printf("FAIL myers32 m=%d n=%d\n", m, n); return 1; }
+        if (myers_infix<uint64_t>(p, t) != want) { printf("FAIL myers64 m=%d n=%d\n", m, n); return 1; }
+        checked++;
+    }
+    // 2. transposed Wu-Manber + seed completeness, bl = 16, texts 0..31, planted copies with 0..3 edits
+    for (int it = 0; it < 300000; it++) {
+        const int m = 16, alpha = (it % 7 == 0) ? 2 : 4;
+        int n = rnd(32);
+        std::vector<int> p(m), t;
+        for (auto &x : p) x = rnd(alpha);
+        if (rnd(4)) {
+            std::vector<int> c(p);
+            for (int k = rnd(4); k > 0; k--) {
+                int kind = rnd(3), pos = rnd((int)c.size() + (kind == 1));
+                if (kind == 0 && !c.empty()) c[std::min(pos, (int)c.size() - 1)] = rnd(4);
+                else if (kind == 1) c.insert(c.begin() + pos, rnd(4));
+                else if (!c.empty()) c.erase(c.begin() + std::min(pos, (int)c.size() - 1));
+            }
+            int left = rnd(8);
+            for (int i = 0; i < left; i++) t.push_back(rnd(alpha));
+            t.insert(t.end(), c.begin(), c.end());
+            while ((int)t.size() < n) t.push_back(rnd(alpha));
+            if ((int)t.size() > 31) t.resize(31);
+        } else {
+            t.resize(n);
+            for (auto &x : t) x = rnd(alpha);
+        }
+        const int want = brute_infix(p, t);
+        if (wm<0>(p, t) != std::min(want, 1)) { printf("FAIL wm0\n"); return 1; }
+        if (wm<1>(p, t) != std::min(want, 2)) { printf("FAIL wm1\n"); return 1; }
+        if (wm<2>(p, t) != std::min(want, 3)) { printf("FAIL wm2 want=%d got=%d n=%zu\n", want, wm<2>(p, t), t.size()); return 1; }
+        if (want <= 0 && !seeds_cover<0>(p, t)) { printf("FAIL seeds0\n"); return 1; }
+        if (want <= 1 && !seeds_cover<1>(p, t)) { printf("FAIL seeds1\n"); return 1; }
+        if (want <= 2 && !seeds_cover<2>(p, t)) { printf("FAIL seeds2 want=%d\n", want); return 1; }
+        checked++;
+    }
+    // 3. exhaustive seed completeness around one pattern: every text obtained by <= 2 edits of it
+    {
+        std::vector<int> p(16);
+        for (auto &x : p) x = rnd(4);
+        std::vector<std::vector<int>> level{p}, next;
+        long n_texts = 0;
+        for (int depth = 0; depth < 2; depth++) {
+            next.clear();
+            for (auto &s : level) {
+                for (size_t pos = 0; pos <= s.size(); pos++) {
+                    for (int b = 0; b < 4; b++) {
+                        std::vector<int> a(s);
+                        a.insert(a.begin() + pos, b);
+                        next.push_back(a);
+                        if (pos < s.size()) { a = s; a[pos] = b; next.push_back(a); }
+                    }
+                    if (pos < s.size()) { std::vector<int> a(s); a.erase(a.begin() + pos); next.push_back(a); }
+                }
+            }
+            std::sort(next.begin(), next.end());
+            next.erase(std::unique(next.begin(), next.end()), next.end());
+            for (auto &s : next) {
+                std::vector<int> t;
+                for (int i = 0; i < 3; i++) t.push_back(rnd(4));
+                t.insert(t.end(), s.begin(), s.end());
+                for (int i = 0; i < 3; i++) t.push_back(rnd(4));
+                const int want = brute_infix(p, t);
+                if (want <= 2 && !seeds_cover<2>(p, t)) { printf("FAIL seeds2 exhaustive\n"); return 1; }
+                if (want <= 1 && !seeds_cover<1>(p, t)) { printf("FAIL seeds1 exhaustive\n"); return 1; }
+                if (wm<2>(p, t) != std::min(want, 3)) { printf("FAIL wm2 exhaustive\n"); return 1; }
+                // and the bare edited string with nothing around it
+                const int w2 = brute_infix(p, s);
+                if (s.size() <= 31 && w2 <= 2 && !seeds_cover<2>(p, s)) { printf("FAIL seeds2 bare\n"); return 1; }
+                n_texts++;
+            }
+            level = next;
+        }
+        checked += n_texts;
+    }
+    printf("OK %ld cases\n", checked);
+    return 0;
+}

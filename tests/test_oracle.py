@@ -1,0 +1,73 @@
+"""CPU suite: the oracle (oracle/trie_oracle.c) against the reference's golden vectors and against the
+independent brute-force checker."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bruteforce, trie_oracle
+from sctagger_amd import synth
+from tests import util
+
+
+@pytest.mark.parametrize("case", util.golden_cases(), ids=lambda c: "%s-e%d-t%d" % (c[0], c[3], c[4]))
+def test_oracle_matches_reference_output(case):
+    name, lr, sr, e, t, bl, exp = case
+    bcs, names, segs, offs = util.read_inputs(lr, sr)
+    res = trie_oracle.match(util.bc_matrix(bcs, bl), segs, offs, e, threads=t, workers=4)
+    with open(exp) as f:
+        want = f.read()
+    assert util.render(bcs, names, segs, offs, *res) == want
+
+
+def test_trie_unit_vectors():
+    with open(os.path.join(util.GOLDEN, "g4.trie_unit.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        t = trie_oracle.Trie(c["max_error"], c["barcode_length"])
+        for w, rid in c["inserts"]:
+            t.insert(w, rid)
+        assert t.size == c["size"]
+        for q in c["queries"]:
+            assert t.query(q["barcode"]) == q["result"], (c["inserts"], q["barcode"])
+
+
+def test_seam_return_values():
+    with open(os.path.join(util.GOLDEN, "g8.seam.json")) as f:
+        want = json.load(f)
+    bcs, names, segs, offs = util.read_inputs(os.path.join(util.GOLDEN, "g3.lr.tsv"), os.path.join(util.GOLDEN, "g3.sr.tsv"))
+    bc = util.bc_matrix(bcs, 16)
+    for key, rows in want.items():
+        kind, e, arg = key.split(":")
+        if kind != "run":
+            continue  # single-prefix tasks are covered through the merged result below
+        min_e, ho, hits = trie_oracle.match(bc, segs, offs, int(e), threads=int(arg))
+        got = [[rid, int(min_e[rid]), sorted([int(p) >> 1, bool(p & 1)] for p in hits[ho[rid]:ho[rid + 1]])]
+               for rid in range(len(names)) if min_e[rid] != 0xFF]
+        assert got == rows, key
+
+
+@pytest.mark.parametrize("e,t", [(0, 1), (1, 1), (2, 1), (2, 4), (1, 16), (2, 16)])
+def test_bruteforce_agrees_on_quirk_set(e, t):
+    bcs, names, segs, offs = util.read_inputs(os.path.join(util.GOLDEN, "g3.lr.tsv"), os.path.join(util.GOLDEN, "g3.sr.tsv"))
+    bc = util.bc_matrix(bcs, 16)
+    a = trie_oracle.match(bc, segs, offs, e, threads=t)
+    b = bruteforce.match(bc, segs, offs, e, starts_k=trie_oracle.load().orc_prefix_len(t))
+    util.assert_same(a, b, "oracle vs bruteforce")
+
+
+@pytest.mark.parametrize("nseg,nbc,bl,e,seed", [(300, 80, 16, 2, 11), (300, 60, 16, 1, 12), (200, 40, 12, 3, 13), (150, 30, 20, 2, 14)])
+def test_bruteforce_agrees_on_synthetic(nseg, nbc, bl, e, seed):
+    bc = synth.make_barcodes(nbc, bl=bl, seed=seed)
+    segs, offs = synth.make_segments(nseg, bc, seg_len=bl + 6, seed=seed)
+    a = trie_oracle.match(bc, segs, offs, e, threads=4, workers=2)
+    b = bruteforce.match(bc, segs, offs, e)
+    util.assert_same(a, b, "oracle vs bruteforce")
+
+
+def test_oracle_rejects_high_bytes():
+    bc = synth.make_barcodes(4, seed=1)
+    segs = np.frombuffer(b"ACGT\xc3\xa9ACGTACGTACGTACGT", dtype=np.uint8)
+    with pytest.raises(ValueError):
+        trie_oracle.match(bc, segs, np.array([0, segs.size], dtype=np.int64), 1)
