@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — LR segments matched/sec on MI355X for the match_trie path (BASELINE.json metric).
+
+A step = one pass of the whole device path (every kernel of sct_run: pack, seed filter, scans, CSR
+assembly) over one batch of synthetic segments that is already resident in HBM.  At N = 1 the batch is
+BASELINE.json configs[2] ("10M LR segments x 25k barcodes, bl=16 e<=2, 1xMI355X"), the configuration the
+metric is quoted on; with N > 1 every rank runs its own batch of the same size (independent rid shards,
+no data-path collective: weak scaling), seeds 40+rank as SURVEY.md §8(d) prescribes for cfg4.
+
+Launch: `python bench.py` (N=1) or
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+torch is used only for the barrier / max-over-ranks of the timing (gloo); the product path is ctypes -> HIP.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from sctagger_amd import _native, synth  # noqa: E402
+
+WORKLOADS = {
+    # name: (segments per GPU, barcodes, bl, max_err)
+    "cfg2": (1_000_000, 5_000, 16, 2),
+    "cfg3": (10_000_000, 25_000, 16, 2),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def make_batch(n, bc, seed, chunk=1_000_000):
+    """Seeded synthetic segments, generated in chunks to bound host memory."""
+    segs, offs, base = [], [np.zeros(1, np.int64)], 0
+    for i, c0 in enumerate(range(0, n, chunk)):
+        s, o = synth.make_segments(min(chunk, n - c0), bc, seed=seed * 1000 + i)
+        segs.append(s)
+        offs.append(o[1:] + base)
+        base += int(o[-1])
+    return np.concatenate(segs), np.concatenate(offs)
+
+
+def cpu_baseline(bc, segs, offs, max_err, sample):
+    """The oracle (C restatement of the reference's trie + prefix tasks) timed on this host's cores on a
+    bounded sample of the same workload.  A reported baseline; never the product path."""
+    from oracle import trie_oracle
+    trie_oracle.load()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    n = min(sample, offs.size - 1)
+    t0 = time.perf_counter()
+    trie_oracle.match(bc, segs[:offs[n]], offs[:n + 1], max_err, threads=16, workers=min(cores, 16))
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "segments/s", "cores": min(cores, 16), "kind": "port",
+            "sample": "first %d segments of the batch x %d barcodes, e<=%d, reference -t 16 (16 prefix tasks)" % (
+                n, bc.shape[0], max_err), "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--segments", type=int, default=None, help="override segments per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exhaustive", action="store_true", help="time the all-barcodes scan instead of the seed filter")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+
+    n_seg, n_bc, bl, max_err = WORKLOADS[args.workload]
+    if args.segments:
+        n_seg = args.segments
+    bc = synth.make_barcodes(n_bc, bl=bl, seed=3)
+    seed = 3 if world == 1 else 40 + rank
+    segs, offs = make_batch(n_seg, bc, seed)
+
+    m = _native.Matcher(local_rank)
+    m.set_barcodes(bc)
+    if args.force_exhaustive:
+        m.set_option("force_exhaustive", 1)
+    m.upload_segments(segs, offs)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        m.run(max_err, threads=1)
+    m.sync()
+    barrier()
+    per_kernel = {}
+    t0 = time.perf_counter()
+    hits = 0
+    for _ in range(args.steps):
+        hits = m.run(max_err, threads=1)
+        for name, ms in m.last_timing():
+            per_kernel.setdefault(name, []).append(ms)
+    m.sync()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        tot = torch.tensor([float(n_seg)], dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_segments = float(tot[0])
+    else:
+        total_segments = float(n_seg)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+        value = total_segments / (ms_per_step / 1e3)
+        avg = {k: float(np.mean(v)) for k, v in per_kernel.items()}
+        dominant = max(avg, key=avg.get) if avg else None
+        h = hits / float(n_seg)
+        bytes_per_seg = (float(offs[-1]) / n_seg + 4) + (1 + 4 + 4 * h)   # in L+4, out 1+4+4h
+        alg_bytes = bytes_per_seg * n_seg + bc.size                   # + barcode set read once per launch
+        roof = None
+        if dominant:
+            achieved = alg_bytes / (avg[dominant] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "kernel_ms": round(avg[dominant], 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "bytes_per_segment": round(bytes_per_seg, 2),
+                    # the binding resource is integer VALU issue, not HBM: all-pairs DP cells credited
+                    "dp_cells_per_segment": int(synth_seg_len(offs) * bl * n_bc * 2),
+                    "gcups_equivalent": round(n_seg * synth_seg_len(offs) * bl * n_bc * 2 / (avg[dominant] * 1e-3) / 1e9, 1)}
+        out = {
+            "metric": "LR segments matched/sec (whole node), 25k barcodes e<=2" if args.workload == "cfg3"
+                      else "LR segments matched/sec (whole node)",
+            "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, 22-bp segments (SURVEY 8(d))" % (
+                args.workload, n_seg, n_bc, bl, max_err), "segments_per_gpu": n_seg, "barcodes": n_bc, "max_err": max_err,
+                "path": "exhaustive" if args.force_exhaustive else "seed-filter", "paths": m.last_stats()},
+            "hits_per_segment": round(h, 4),
+            "kernels_ms": {k: round(v, 4) for k, v in avg.items()},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(bc, segs, offs, max_err, args.cpu_sample)
+        print(json.dumps(out))
+    m.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def synth_seg_len(offs):
+    lens = np.diff(offs)
+    return float(lens[lens > 0].mean()) if (lens > 0).any() else 0.0
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,267 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against
+(a) the reference's golden output, (b) the oracle on seeded inputs, (c) size-independent properties at
+BASELINE.json's full sizes.  Everything is integer work: the bar is bit-exact."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import bruteforce, trie_oracle
+from sctagger_amd import _native, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(util.HERE)
+
+
+@pytest.fixture(scope="module")
+def m():
+    mm = _native.Matcher(0)
+    yield mm
+    mm.close()
+
+
+def run_both(m, bc, segs, offs, e, t=1):
+    """-> (filter-path result, exhaustive-path result)"""
+    m.set_barcodes(bc)
+    m.set_option("force_exhaustive", 0)
+    a = m.match(segs, offs, e, t)
+    m.set_option("force_exhaustive", 1)
+    b = m.match(segs, offs, e, t)
+    m.set_option("force_exhaustive", 0)
+    return a, b
+
+
+@pytest.mark.parametrize("case", util.golden_cases(), ids=lambda c: "%s-e%d-t%d" % (c[0], c[3], c[4]))
+def test_golden_reference_output(m, case):
+    name, lr, sr, e, t, bl, exp = case
+    bcs, names, segs, offs = util.read_inputs(lr, sr)
+    with open(exp) as f:
+        want = f.read()
+    a, b = run_both(m, util.bc_matrix(bcs, bl), segs, offs, e, t)
+    assert util.render(bcs, names, segs, offs, *a) == want
+    assert util.render(bcs, names, segs, offs, *b) == want
+
+
+@pytest.mark.parametrize("nseg,nbc,bl,e,t,seed", [
+    (20000, 2000, 16, 2, 1, 21), (20000, 3000, 16, 1, 1, 22), (20000, 3000, 16, 0, 16, 23),
+    (3000, 300, 12, 3, 4, 24), (3000, 200, 20, 2, 1, 25), (2000, 100, 32, 4, 1, 26), (2000, 50, 5, 1, 1, 27),
+    (1000, 4, 1, 0, 1, 28), (600, 64, 16, 4, 1, 29),
+])
+def test_seeded_vs_oracle(m, nseg, nbc, bl, e, t, seed):
+    bc = synth.make_barcodes(nbc, bl=bl, seed=seed)
+    segs, offs = synth.make_segments(nseg, bc, seg_len=bl + 6, seed=seed)
+    want = trie_oracle.match(bc, segs, offs, e, threads=t, workers=8)
+    a, b = run_both(m, bc, segs, offs, e, t)
+    util.assert_same(a, want, "filter path")
+    util.assert_same(b, want, "exhaustive path")
+
+
+@pytest.mark.parametrize("nseg,nbc,bl,e,seed", [(300, 65, 16, 15, 30), (300, 65, 16, 8, 31), (200, 40, 32, 31, 32), (300, 30, 7, 6, 33)])
+def test_large_error_budgets_vs_bruteforce(m, nseg, nbc, bl, e, seed):
+    """max_err up to bl-1: the trie DFS of the oracle is exponential in e, so the checker here is the plain DP."""
+    bc = synth.make_barcodes(nbc, bl=bl, seed=seed)
+    segs, offs = synth.make_segments(nseg, bc, seg_len=bl + 6, seed=seed)
+    want = bruteforce.match(bc, segs, offs, e)
+    a, b = run_both(m, bc, segs, offs, e)
+    util.assert_same(a, want, "filter path")
+    util.assert_same(b, want, "exhaustive path")
+
+
+def ragged(nseg, bc, seed, maxlen, junk=0.0):
+    """Segments of every length 0..maxlen cut from planted rows; `junk` = fraction of bytes replaced by non-ACGT."""
+    rng = np.random.default_rng(seed)
+    base, bo = synth.make_segments(nseg, bc, seg_len=maxlen, seed=seed, frac_empty=0.0)
+    rows = []
+    for i in range(nseg):
+        s = base[bo[i]:bo[i + 1]].copy()
+        st = int(rng.integers(0, 4))
+        s = s[st:st + int(rng.integers(0, maxlen + 1))]
+        if junk and s.size:
+            k = rng.random(s.size) < junk
+            s[k] = rng.choice(np.frombuffer(b"NnacgtRYX -*", dtype=np.uint8), size=int(k.sum()))
+        rows.append(s)
+    offs = np.zeros(nseg + 1, dtype=np.int64)
+    np.cumsum([r.size for r in rows], out=offs[1:])
+    return (np.concatenate(rows) if rows else np.empty(0, np.uint8)), offs
+
+
+@pytest.mark.parametrize("maxlen,e,t", [(45, 2, 1), (45, 1, 16), (130, 2, 4), (31, 2, 1), (32, 2, 1), (33, 0, 1)])
+def test_ragged_lengths(m, maxlen, e, t):
+    bc = synth.make_barcodes(400, seed=31)
+    segs, offs = ragged(3000, bc, 31 + maxlen, maxlen)
+    want = trie_oracle.match(bc, segs, offs, e, threads=t, workers=8)
+    a, b = run_both(m, bc, segs, offs, e, t)
+    util.assert_same(a, want, "filter path")
+    util.assert_same(b, want, "exhaustive path")
+
+
+@pytest.mark.parametrize("e,t", [(2, 1), (2, 2), (2, 16), (1, 64), (0, 5), (2, 300)])
+def test_non_acgt_bytes_follow_the_reference_rule(m, e, t):
+    """other bytes match as 'A'; with k > 0 windows starting on them are not searched."""
+    bc = synth.make_barcodes(300, seed=41)
+    bc[::7, 3] = ord("N")       # N inside some barcodes (rev_compl keeps it, map_char makes it A)
+    bc[5] = np.frombuffer(b"acgtacgtacgtacgt", dtype=np.uint8)
+    segs, offs = ragged(2500, bc, 41 + t, 40, junk=0.06)
+    want = trie_oracle.match(bc, segs, offs, e, threads=t, workers=8)
+    a, b = run_both(m, bc, segs, offs, e, t)
+    util.assert_same(a, want, "filter path")
+    util.assert_same(b, want, "exhaustive path")
+    k = _native.prefix_len(t)
+    sub = slice(0, 150)
+    bf = bruteforce.match(bc, segs[:offs[150]], offs[:151], e, starts_k=k)
+    assert np.array_equal(bf[0], a[0][sub]) and np.array_equal(bf[2], a[2][:a[1][150]])
+
+
+def test_many_ties_defer_to_the_scan_path(m):
+    """Low-complexity barcodes: far more than 8 barcodes tie at the minimum for poly-A segments."""
+    rng = np.random.default_rng(5)
+    bc = np.full((300, 16), ord("A"), dtype=np.uint8)
+    for i in range(1, 300):                       # 1 or 2 substitutions away from poly-A
+        bc[i, rng.integers(0, 16, size=rng.integers(1, 3))] = ord("C")
+    segs = np.frombuffer(b"A" * 22 + b"AAAAAAAACAAAAAAAAAAAAA" + b"T" * 22 + b"ACGT" * 5, dtype=np.uint8)
+    offs = np.array([0, 22, 44, 66, 86], dtype=np.int64)
+    want = trie_oracle.match(bc, segs, offs, 2, threads=1)
+    assert np.diff(want[1]).max() > 8
+    a, b = run_both(m, bc, segs, offs, 2)
+    util.assert_same(a, want, "filter path")
+    util.assert_same(b, want, "exhaustive path")
+    m.set_barcodes(bc)
+    m.match(segs, offs, 2, 1)
+    assert m.last_stats()["exhaustive"] >= 1
+
+
+def test_empty_and_degenerate_inputs(m):
+    bc = synth.make_barcodes(50, seed=7)
+    m.set_barcodes(bc)
+    z = np.zeros(1, dtype=np.int64)
+    r = m.match(np.empty(0, np.uint8), z, 2)
+    assert r[0].size == 0 and r[1].tolist() == [0] and r[2].size == 0
+    r = m.match(np.empty(0, np.uint8), np.zeros(6, dtype=np.int64), 2)       # five empty rows
+    assert r[0].tolist() == [255] * 5 and r[1].tolist() == [0] * 6
+    seg = bc[3][:14]                                                        # exactly bl - e characters
+    r = m.match(seg, np.array([0, 14], dtype=np.int64), 2)
+    assert r[0].tolist() == [2] and 7 in r[2].tolist()
+    r = m.match(seg[:13], np.array([0, 13], dtype=np.int64), 2)             # one shorter: nothing
+    assert r[0].tolist() == [255]
+    m.set_barcodes(np.empty((0, 16), dtype=np.uint8))                       # no barcodes at all
+    segs, offs = synth.make_segments(100, bc, seed=1)
+    r = m.match(segs, offs, 2)
+    assert (r[0] == 255).all() and r[2].size == 0
+    long_seg = np.concatenate([synth.make_segments(1, bc, seg_len=22, seed=2, frac_empty=0)[0]] * 50)  # 1100 chars
+    m.set_barcodes(bc)
+    want = trie_oracle.match(bc, long_seg, np.array([0, long_seg.size], dtype=np.int64), 2)
+    util.assert_same(m.match(long_seg, np.array([0, long_seg.size], dtype=np.int64), 2), want, "long segment")
+
+
+def test_error_behaviour(m):
+    bc = synth.make_barcodes(10, seed=7)
+    segs, offs = synth.make_segments(10, bc, seed=1)
+    m.set_barcodes(bc)
+    with pytest.raises(_native.SctError):
+        m.match(segs, offs, 16)                    # reference asserts bl > max_err (:143)
+    with pytest.raises(_native.SctError):
+        m.match(segs, offs, -1)
+    bad = segs.copy()
+    bad[3] = 200
+    with pytest.raises(_native.SctError):          # reference: IndexError on map_char[>=128]
+        m.match(bad, offs, 2)
+    with pytest.raises(_native.SctError):
+        m.set_barcodes(np.full((2, 33), ord("A"), dtype=np.uint8))
+    hi = bc.copy()
+    hi[0, 0] = 255
+    with pytest.raises(_native.SctError):
+        m.set_barcodes(hi)
+    with _native.Matcher(0) as fresh:
+        fresh.upload_segments(segs, offs)
+        with pytest.raises(_native.SctError):
+            fresh.run(2)                           # no barcodes yet
+    m.set_barcodes(bc)
+    util.assert_same(m.match(segs, offs, 2), trie_oracle.match(bc, segs, offs, 2), "after errors")
+
+
+def test_cfg2_full_size_properties(m):
+    """BASELINE configs[1]: 1M segments x 5k barcodes, e<=2.  The oracle cannot run this in seconds, so:
+    filter path == exhaustive path bit for bit; a 20k-row sample == oracle; shard/concat invariance;
+    permutation equivariance; planted exact copies are found at distance 0."""
+    bc = synth.make_barcodes(5000, seed=2)
+    segs, offs = synth.make_segments(1_000_000, bc, seed=2)
+    a, b = run_both(m, bc, segs, offs, 2)
+    util.assert_same(a, b, "filter vs exhaustive at 1M x 5k")
+    n = offs.size - 1
+    assert a[1][-1] == a[2].size and (np.diff(a[1]) >= 0).all()
+    matched = a[0] != 255
+    assert ((np.diff(a[1]) > 0) == matched).all()
+    # hit lists strictly ascending inside each row (sorted, deduplicated)
+    inner = np.ones(a[2].size, dtype=bool)
+    inner[a[1][:-1][np.diff(a[1]) > 0]] = False
+    assert (np.diff(a[2].astype(np.int64))[inner[1:]] > 0).all()
+    k = 20000
+    want = trie_oracle.match(bc, segs[:offs[k]], offs[:k + 1], 2, threads=16, workers=8)
+    assert np.array_equal(a[0][:k], want[0]) and np.array_equal(a[2][:a[1][k]], want[2])
+    # two shards, concatenated == one call
+    from sctagger_amd.match_trie import concat_shards
+    h = n // 2
+    m.set_barcodes(bc)
+    r1 = m.match(segs[:offs[h]], offs[:h + 1], 2)
+    r2 = m.match(segs[offs[h]:], offs[h:] - offs[h], 2)
+    util.assert_same(concat_shards([r1, r2]), a, "shard + concat")
+    # reversing the row order reverses the results
+    lens = np.diff(offs)
+    full = np.flatnonzero(lens == 22)
+    rows = segs.reshape(-1, 22)[::-1]
+    o2 = np.zeros(full.size + 1, dtype=np.int64)
+    o2[1:] = 22 * np.arange(1, full.size + 1)
+    r = m.match(np.ascontiguousarray(rows).reshape(-1), o2, 2)
+    assert np.array_equal(r[0], a[0][full][::-1])
+    assert np.array_equal(np.diff(r[1]), np.diff(a[1])[full][::-1])
+    # planted exact barcodes
+    ids = np.arange(0, 5000, 7)
+    g3, c3 = np.frombuffer(b"GGG", np.uint8), np.frombuffer(b"CCC", np.uint8)
+    planted = np.concatenate([np.concatenate([g3, bc[i], c3]) for i in ids])
+    po = 22 * np.arange(ids.size + 1, dtype=np.int64)
+    r = m.match(planted, po, 2)
+    assert (r[0] == 0).all()
+    for j, i in enumerate(ids):
+        assert 2 * i + 1 in r[2][r[1][j]:r[1][j + 1]].tolist()
+
+
+def test_cfg3_sample_vs_exhaustive_and_oracle(m):
+    """BASELINE configs[2] barcode set (25k), 2M-segment batch: filter path == exhaustive path; 10k rows == oracle."""
+    bc = synth.make_barcodes(25000, seed=3)
+    segs, offs = synth.make_segments(2_000_000, bc, seed=3)
+    a, b = run_both(m, bc, segs, offs, 2, t=16)
+    util.assert_same(a, b, "filter vs exhaustive at 2M x 25k")
+    k = 10000
+    want = trie_oracle.match(bc, segs[:offs[k]], offs[:k + 1], 2, threads=16, workers=8)
+    assert np.array_equal(a[0][:k], want[0]) and np.array_equal(a[2][:a[1][k]], want[2])
+
+
+def test_resident_three_step_api(m):
+    bc = synth.make_barcodes(1000, seed=9)
+    segs, offs = synth.make_segments(50000, bc, seed=9)
+    m.set_barcodes(bc)
+    one = m.match(segs, offs, 2)
+    m.upload_segments(segs, offs)
+    for _ in range(3):                              # idempotent on resident inputs
+        m.run(2)
+        util.assert_same(m.download(), one, "upload/run/download")
+    names = [k for k, _ in m.last_timing()]
+    assert "k_filter" in names and all(ms >= 0 for _, ms in m.last_timing())
+
+
+def test_cli_end_to_end(tmp_path):
+    """`scTagger.py match_trie ...` writes the reference's bytes (gz and plain), with the reference's flags."""
+    g = util.GOLDEN
+    for out, e, t, exp in (("o.tsv.gz", 1, 4, "g1.e1.t4.expected.tsv"), ("o.tsv", 2, 16, "g3.e2.t16.expected.tsv")):
+        name = exp.split(".")[0]
+        o = tmp_path / out
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", os.path.join(g, name + ".lr.tsv"),
+                               "-sr", os.path.join(g, name + ".sr.tsv"), "-mr", str(e), "-t", str(t), "-o", str(o)],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        data = gzip.open(o, "rb").read() if out.endswith("gz") else o.read_bytes()
+        with open(os.path.join(g, exp), "rb") as f:
+            assert data == f.read()
