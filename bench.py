@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from sctagger_amd import _native, synth  # noqa: E402
+from sctagger_amd import _native, shard, synth  # noqa: E402
 
 WORKLOADS = {
     # name: (segments per GPU, barcodes, bl, max_err)
@@ -71,18 +71,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--segments", type=int, default=None, help="override segments per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--cpu-sample", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exhaustive", action="store_true", help="time the all-barcodes scan instead of the seed filter")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="gloo")
+    rank, local_rank, world = shard.rank_info()
+    dist = shard.init_dist()
 
     n_seg, n_bc, bl, max_err = WORKLOADS[args.workload]
     if args.segments:
@@ -98,8 +93,7 @@ def main():
     m.upload_segments(segs, offs)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        shard.barrier(dist)
 
     for _ in range(args.warmup):
         m.run(max_err, threads=1)
@@ -115,16 +109,7 @@ def main():
     m.sync()
     elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        tot = torch.tensor([float(n_seg)], dtype=torch.float64)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_segments = float(tot[0])
-    else:
-        total_segments = float(n_seg)
+    elapsed, total_segments = shard.reduce_timing(dist, elapsed, n_seg)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into profiles/<tag>_*.{csv,json}.
+
+Copies the rocprofv3 --kernel-trace --stats summary (kernel_stats.csv) and writes per-kernel averages of
+every PMC counter pass, with the HBM traffic derived as MI355X_MICROARCH.md prescribes (FETCH_SIZE and
+WRITE_SIZE in KiB from separate passes; on gfx950 FETCH_SIZE counts 128-B requests at 64 B for wide
+coalesced reads, so the read side is reported both raw and doubled)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    os.makedirs("profiles", exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], "profiles/%s_kernel_stats.csv" % tag)
+    bench = os.path.join(src, "trace_bench.json")
+    if os.path.exists(bench):
+        shutil.copy(bench, "profiles/%s_bench_under_rocprof.json" % tag)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    out = {}
+    for k, v in agg.items():
+        c = {n: sum(x) / len(x) for n, x in v.items()}
+        d = {"counters_avg_per_launch": c}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            d["hbm_read_bytes_raw"] = c["FETCH_SIZE"] * 1024
+            d["hbm_read_bytes_x2_gfx950"] = c["FETCH_SIZE"] * 2048
+            d["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+        if "TCC_HIT_sum" in c:
+            d["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0), 1)
+        if "GRBM_GUI_ACTIVE" in c:
+            d["gui_active_cycles_per_xcd"] = c["GRBM_GUI_ACTIVE"] / 8
+        out[k] = d
+    with open("profiles/%s_pmc_summary.json" % tag, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in out.items() if "filter" in k}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
