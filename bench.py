@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exhaustive", action="store_true", help="time the all-barcodes scan instead of the seed filter")
+    ap.add_argument("--filter-mode", type=int, default=0, help="0 = wave-cooperative filter kernel (default), 1 = lane-per-segment variant")
     args = ap.parse_args()
 
     rank, local_rank, world = shard.rank_info()
@@ -90,6 +91,7 @@ def main():
     m.set_barcodes(bc)
     if args.force_exhaustive:
         m.set_option("force_exhaustive", 1)
+    m.set_option("filter_mode", args.filter_mode)
     m.upload_segments(segs, offs)
 
     def barrier():

@@ -11,8 +11,10 @@
 
 #if defined(__HIPCC__)
 #define SCT_HD __host__ __device__ __forceinline__
+#define SCT_HDM __host__ __device__ __forceinline__
 #else
 #define SCT_HD static inline
+#define SCT_HDM inline
 #endif
 
 SCT_HD uint32_t sct_code(uint8_t b) { return b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 0u; }
@@ -127,25 +129,52 @@ SCT_HD uint32_t sct_pattern_key(int f, uint32_t plo, uint32_t phi) {
     }
 }
 
-// Enumerate every (family, key) lookup the filter makes for a text of `len` characters (planes lo/hi).
-// The H1/H2/MID families share one 8-mer key per position, 02/13 share one pair key; the kernel and the
-// host-side completeness test both go through this function.
+// Enumerate the lookup steps the filter makes for a text of `len` characters.  A step is (kind, t, t2):
+//   SCT_STEP_8MER   the 8-mer at t               -> families H1 (and H2 if E >= 1, MID if E >= 2)
+//   SCT_STEP_PAIR8  4-mers at t and t2 = t+8+d   -> families 02 and 13, |d| <= 1            (E >= 2)
+//   SCT_STEP_PAIR12 4-mers at t and t2 = t+12+d  -> family 03, |d| <= 2                     (E >= 2)
+// A step is valid for a text of length L iff its last character exists: t+8 <= L resp. t2+4 <= L
+// (sct_step_valid).  Kernels that walk the steps wave-uniformly pass the longest length in the wave and
+// test validity per lane; the host-side completeness test goes through the same enumeration.
+enum { SCT_STEP_8MER = 0, SCT_STEP_PAIR8 = 1, SCT_STEP_PAIR12 = 2 };
+
+SCT_HD bool sct_step_valid(int kind, int t, int t2, int len) { return kind == SCT_STEP_8MER ? t + 8 <= len : t2 + 4 <= len; }
+SCT_HD uint32_t sct_step_key(int kind, uint32_t lo, uint32_t hi, int t, int t2) {
+    return kind == SCT_STEP_8MER ? sct_key8(lo, hi, t) : sct_key44(lo, hi, t, t2);
+}
+
 template <int E, typename F>
-SCT_HD void sct_for_each_seed(uint32_t lo, uint32_t hi, int len, F &&fn) {
-    for (int t = 0; t + 8 <= len; t++) {
-        const uint32_t k = sct_key8(lo, hi, t);
-        fn(SCT_F_H1, k);
-        if (E >= 1) fn(SCT_F_H2, k);
-        if (E >= 2) fn(SCT_F_MID, k);
-    }
+SCT_HD void sct_for_each_step(int len, F &&fn) {
+    for (int t = 0; t + 8 <= len; t++) fn(SCT_STEP_8MER, t, t);
     if (E >= 2) {
         for (int d = -1; d <= 1; d++)
-            for (int t = 0; t + 12 + d <= len; t++) {
-                const uint32_t k = sct_key44(lo, hi, t, t + 8 + d);
-                fn(SCT_F_02, k);
-                fn(SCT_F_13, k);
-            }
+            for (int t = 0; t + 12 + d <= len; t++) fn(SCT_STEP_PAIR8, t, t + 8 + d);
         for (int d = -2; d <= 2; d++)
-            for (int t = 0; t + 16 + d <= len; t++) fn(SCT_F_03, sct_key44(lo, hi, t, t + 12 + d));
+            for (int t = 0; t + 16 + d <= len; t++) fn(SCT_STEP_PAIR12, t, t + 12 + d);
     }
+}
+
+// Every (family, key) lookup for one text (planes lo/hi): the steps above expanded into their families.
+template <int E, typename F>
+struct SctSeedExpand {
+    uint32_t lo, hi;
+    F &fn;
+    SCT_HDM void operator()(int kind, int t, int t2) {
+        const uint32_t k = sct_step_key(kind, lo, hi, t, t2);
+        if (kind == SCT_STEP_8MER) {
+            fn(SCT_F_H1, k);
+            if (E >= 1) fn(SCT_F_H2, k);
+            if (E >= 2) fn(SCT_F_MID, k);
+        } else if (kind == SCT_STEP_PAIR8) {
+            fn(SCT_F_02, k);
+            fn(SCT_F_13, k);
+        } else {
+            fn(SCT_F_03, k);
+        }
+    }
+};
+template <int E, typename F>
+SCT_HD void sct_for_each_seed(uint32_t lo, uint32_t hi, int len, F &&fn) {
+    SctSeedExpand<E, F> x{lo, hi, fn};
+    sct_for_each_step<E>(len, x);
 }

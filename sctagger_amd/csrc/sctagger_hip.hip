@@ -108,23 +108,28 @@ __global__ void k_pack(const uint8_t *__restrict__ segs, const int64_t *__restri
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_filter<E>: one lane per segment (bl == 16, max_err == E <= 2, <= 31 characters, routed here by k_pack).
-// For every seed lookup of sct_for_each_seed the lane walks the bucket of pattern ids sharing that key and
-// verifies each candidate with the transposed Wu-Manber automaton; it keeps the running minimum and up to
-// K_SLOTS distinct pattern ids at that minimum.  More than K_SLOTS ties defer the segment to the scan path.
+// Per-lane result of the filter kernels: running minimum distance and up to K_SLOTS distinct pattern ids at
+// that minimum, in registers (static indexing only).  More than K_SLOTS ties defer the segment to the scan path.
 // ------------------------------------------------------------------------------------------------------------
 template <int E>
-struct FilterLane {
-    const uint32_t *__restrict__ tab_off;
-    const uint32_t *__restrict__ tab_ent;
-    const uint2 *__restrict__ pat;
-    int np;
-    uint32_t tls, ths, ve, va;
-    int best;
-    int nh;
+struct LaneResult {
+    int best = E + 1;
+    int nh = 0;
     uint32_t h[K_SLOTS];
 
-    __device__ __forceinline__ void add_hit(uint32_t pid) {
+    __device__ __forceinline__ void init() {
+        best = E + 1;
+        nh = 0;
+#pragma unroll
+        for (int i = 0; i < K_SLOTS; i++) h[i] = 0;
+    }
+    __device__ __forceinline__ void add(int d, uint32_t pid) {
+        if (d > E) return;
+        if (d < best) {
+            best = d;
+            nh = 0;
+        }
+        if (d != best) return;
         bool dup = false;
 #pragma unroll
         for (int i = 0; i < K_SLOTS; i++) dup |= (i < nh) && (h[i] == pid);
@@ -134,6 +139,55 @@ struct FilterLane {
             if (i == nh) h[i] = pid;
         nh++;  // may run past K_SLOTS: that is the defer signal
     }
+    // writes min_e / cnt / slots for row r, or defers it to the scan list
+    __device__ __forceinline__ void store(int64_t r, bool overflow, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
+                                          uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan,
+                                          uint32_t *__restrict__ counters) {
+        if (overflow || nh > K_SLOTS) {
+            const uint32_t k = atomicAdd(&counters[0], 1u);
+            list_scan[k] = (int32_t)r;
+            cnt[r] = CNT_DEFER;
+            return;
+        }
+        if (nh == 0) {
+            min_e[r] = SCT_NO_HIT;
+            cnt[r] = 0;
+            return;
+        }
+        if (nh > 1) {  // sort ascending: odd-even transposition network on registers
+#pragma unroll
+            for (int i = 0; i < K_SLOTS; i++)
+                if (i >= nh) h[i] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int round = 0; round < K_SLOTS; round++) {
+#pragma unroll
+                for (int i = round & 1; i + 1 < K_SLOTS; i += 2) {
+                    const uint32_t a = h[i], b = h[i + 1];
+                    h[i] = a < b ? a : b;
+                    h[i + 1] = a < b ? b : a;
+                }
+            }
+        }
+        min_e[r] = (uint8_t)best;
+        cnt[r] = (uint32_t)nh;
+#pragma unroll
+        for (int i = 0; i < K_SLOTS; i++)
+            if (i < nh) slots[(size_t)r * K_SLOTS + i] = h[i];
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// k_filter_lane<E> (first version, kept for A/B: option "filter_mode" = 1): one lane per segment, each lane walks
+// its own buckets and verifies its own candidates; lanes idle while the longest bucket of the wave is walked.
+// ------------------------------------------------------------------------------------------------------------
+template <int E>
+struct FilterLane {
+    const uint32_t *__restrict__ tab_off;
+    const uint32_t *__restrict__ tab_ent;
+    const uint2 *__restrict__ pat;
+    int np;
+    uint32_t tls, ths, ve, va;
+    LaneResult<E> res;
 
     __device__ __forceinline__ void operator()(int f, uint32_t key) {
         const uint32_t *off = tab_off + (size_t)f * (SCT_KEYS + 1) + key;
@@ -142,22 +196,17 @@ struct FilterLane {
         for (uint32_t k = s; k < e; k++) {
             const uint32_t pid = ent[k];
             const uint2 p = pat[pid];
-            const int d = wm_verify<E>(tls, ths, ve, va, p.x, p.y, 16);
-            if (d < best) {
-                best = d;
-                nh = 0;
-            }
-            if (d == best && d <= E) add_hit(pid);
+            res.add(wm_verify<E>(tls, ths, ve, va, p.x, p.y, 16), pid);
         }
     }
 };
 
 template <int E>
 __global__ void __launch_bounds__(256)
-k_filter(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
-         int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
-         const uint2 *__restrict__ pat, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
-         uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan, uint32_t *__restrict__ counters) {
+k_filter_lane(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
+              int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
+              const uint2 *__restrict__ pat, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
+              uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan, uint32_t *__restrict__ counters) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     if (cnt[r] == CNT_DEFER) return;  // routed to a scan path by k_pack
@@ -174,42 +223,199 @@ k_filter(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in,
     L.ths = hi << 1;
     L.va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
     L.ve = L.va & ~1u;
-    L.best = E + 1;
-    L.nh = 0;
-#pragma unroll
-    for (int i = 0; i < K_SLOTS; i++) L.h[i] = 0;
+    L.res.init();
     sct_for_each_seed<E>(lo, hi, len, L);
-    if (L.nh > K_SLOTS) {
-        const uint32_t k = atomicAdd(&counters[0], 1u);
-        list_scan[k] = (int32_t)r;
-        cnt[r] = CNT_DEFER;
-        return;
+    L.res.store(r, false, min_e, cnt, slots, list_scan, counters);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_filter<E> (default): one WAVE per 64 segments, cooperating through LDS so that verification always runs on
+// full waves.
+//   lookup   every lane computes the seed key of its own segment for the current step (the steps are walked
+//            wave-uniformly up to the longest segment of the wave) and reads its bucket range;
+//   push     round by round, every lane that still has a candidate appends (lane, pattern id) to the wave's
+//            queue in LDS (position = tail + mbcnt(ballot));
+//   drain    whenever 64 candidates are queued, lane i takes entry head+i: fetches that segment's planes from
+//            LDS and the pattern from L2, runs the transposed Wu-Manber automaton, and on a match (d <= E)
+//            appends (d, pid) to the owning segment's list in LDS (LDS atomic counter);
+//   finish   every lane folds its own list into (minimum, distinct pattern ids), sorts and stores.
+// A segment with more than HMAX verified matches (duplicates included) or more than K_SLOTS ties is deferred.
+// All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
+// needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
+// ------------------------------------------------------------------------------------------------------------
+static constexpr int QCAP = 128;  // >= 64 left over + 64 pushed per round
+static constexpr int HMAX = 24;
+static constexpr int PID_BITS = 26;
+static constexpr uint32_t PID_MASK = (1u << PID_BITS) - 1u;
+
+struct FilterWaveLds {
+    uint32_t tls[64], ths[64], va[64];
+    uint32_t hcnt[64];
+    uint32_t hlist[HMAX][64];
+    uint32_t q[QCAP];
+};
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t m) {  // number of set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+template <int E>
+struct FilterWave {
+    FilterWaveLds &L;
+    const uint32_t *__restrict__ tab_off;
+    const uint32_t *__restrict__ tab_ent;
+    const uint2 *__restrict__ pat;
+    int np;
+    int lane;
+    bool active;
+    int len;
+    uint32_t lo, hi;
+    uint32_t head = 0, tail = 0;  // wave-uniform
+
+    __device__ __forceinline__ void verify(bool take) {
+        if (take) {
+            const uint32_t item = L.q[(head + lane) & (QCAP - 1)];
+            const uint32_t src = item >> PID_BITS, pid = item & PID_MASK;
+            const uint32_t tl = L.tls[src], th = L.ths[src], v = L.va[src];
+            const uint2 p = pat[pid];
+            const int d = wm_verify<E>(tl, th, v & ~1u, v, p.x, p.y, 16);
+            if (d <= E) {
+                const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
+                if (k < HMAX) L.hlist[k][src] = ((uint32_t)d << 30) | pid;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    if (L.nh == 0) {
-        min_e[r] = SCT_NO_HIT;
-        cnt[r] = 0;
-        return;
-    }
-    // sort the (few) pattern ids ascending: odd-even transposition network on registers
-    if (L.nh > 1) {
+
+    // append the bucket [s, e) of family f for every lane, draining full batches as they form
+    __device__ __forceinline__ void push_bucket(int f, uint32_t s, uint32_t e) {
+        const uint32_t *ent = tab_ent + (size_t)f * np;
+        uint32_t c = e - s;
+        while (__ballot(c > 0)) {
+            // up to four entries per lane are fetched together so that their latencies overlap
+            uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            if (c > 0) p0 = ent[s];
+            if (c > 1) p1 = ent[s + 1];
+            if (c > 2) p2 = ent[s + 2];
+            if (c > 3) p3 = ent[s + 3];
 #pragma unroll
-        for (int i = 0; i < K_SLOTS; i++)
-            if (i >= L.nh) L.h[i] = 0xFFFFFFFFu;
-#pragma unroll
-        for (int round = 0; round < K_SLOTS; round++) {
-#pragma unroll
-            for (int i = round & 1; i + 1 < K_SLOTS; i += 2) {
-                const uint32_t a = L.h[i], b = L.h[i + 1];
-                L.h[i] = a < b ? a : b;
-                L.h[i + 1] = a < b ? b : a;
+            for (int i = 0; i < 4; i++) {
+                const bool has = c > 0;
+                const uint64_t m = __ballot(has);
+                if (m == 0) break;
+                if (has) {
+                    L.q[(tail + lane_rank(m)) & (QCAP - 1)] = ((uint32_t)lane << PID_BITS) | p0;
+                    s++;
+                    c--;
+                }
+                p0 = p1;
+                p1 = p2;
+                p2 = p3;
+                tail += (uint32_t)__popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (tail - head >= 64) {
+                    verify(true);
+                    head += 64;
+                }
             }
         }
     }
-    min_e[r] = (uint8_t)L.best;
-    cnt[r] = (uint32_t)L.nh;
+
+    __device__ __forceinline__ void operator()(int kind, int t, int t2) {
+        const bool v = active && sct_step_valid(kind, t, t2, len);
+        const uint32_t key = sct_step_key(kind, lo, hi, t, t2);
+        if (kind == SCT_STEP_8MER) {
+            uint32_t s0 = 0, e0 = 0, s1 = 0, e1 = 0, s2 = 0, e2 = 0;
+            if (v) {
+                const uint32_t *o = tab_off + key;
+                s0 = o[(size_t)SCT_F_H1 * (SCT_KEYS + 1)];
+                e0 = o[(size_t)SCT_F_H1 * (SCT_KEYS + 1) + 1];
+                if (E >= 1) {
+                    s1 = o[(size_t)SCT_F_H2 * (SCT_KEYS + 1)];
+                    e1 = o[(size_t)SCT_F_H2 * (SCT_KEYS + 1) + 1];
+                }
+                if (E >= 2) {
+                    s2 = o[(size_t)SCT_F_MID * (SCT_KEYS + 1)];
+                    e2 = o[(size_t)SCT_F_MID * (SCT_KEYS + 1) + 1];
+                }
+            }
+            push_bucket(SCT_F_H1, s0, e0);
+            if (E >= 1) push_bucket(SCT_F_H2, s1, e1);
+            if (E >= 2) push_bucket(SCT_F_MID, s2, e2);
+        } else if (kind == SCT_STEP_PAIR8) {
+            uint32_t s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+            if (v) {
+                const uint32_t *o = tab_off + key;
+                s0 = o[(size_t)SCT_F_02 * (SCT_KEYS + 1)];
+                e0 = o[(size_t)SCT_F_02 * (SCT_KEYS + 1) + 1];
+                s1 = o[(size_t)SCT_F_13 * (SCT_KEYS + 1)];
+                e1 = o[(size_t)SCT_F_13 * (SCT_KEYS + 1) + 1];
+            }
+            push_bucket(SCT_F_02, s0, e0);
+            push_bucket(SCT_F_13, s1, e1);
+        } else {
+            uint32_t s0 = 0, e0 = 0;
+            if (v) {
+                const uint32_t *o = tab_off + (size_t)SCT_F_03 * (SCT_KEYS + 1) + key;
+                s0 = o[0];
+                e0 = o[1];
+            }
+            push_bucket(SCT_F_03, s0, e0);
+        }
+    }
+};
+
+__device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
-    for (int i = 0; i < K_SLOTS; i++)
-        if (i < L.nh) slots[(size_t)r * K_SLOTS + i] = L.h[i];
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int E>
+__global__ void __launch_bounds__(256)
+k_filter(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
+         int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
+         const uint2 *__restrict__ pat, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
+         uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan, uint32_t *__restrict__ counters) {
+    __shared__ FilterWaveLds lds[4];
+    FilterWaveLds &L = lds[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = r < n;
+    int len = 0;
+    uint32_t lo = 0, hi = 0;
+    if (active) active = cnt[r] != CNT_DEFER;  // routed to a scan path by k_pack
+    if (active) {
+        len = (int)(meta_in[r] & 0xFF);
+        active = len >= 16 - E;  // shorter rows were finished by k_pack
+        lo = lo_in[r];
+        hi = hi_in[r];
+    }
+    if (!active) len = 0;
+    const int maxlen = wave_max_i(len);
+    if (maxlen == 0) return;  // the whole wave has nothing to do
+    const uint32_t va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
+    L.tls[lane] = lo << 1;
+    L.ths[lane] = hi << 1;
+    L.va[lane] = va;
+    L.hcnt[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    FilterWave<E> W{L, tab_off, tab_ent, pat, np, lane, active, len, lo, hi};
+    sct_for_each_step<E>(maxlen, W);
+    if (W.tail != W.head) {
+        W.verify((uint32_t)lane < W.tail - W.head);
+        W.head = W.tail;
+    }
+    if (!active) return;
+    const uint32_t nc = L.hcnt[lane];
+    LaneResult<E> res;
+    res.init();
+    const uint32_t lim = nc < HMAX ? nc : HMAX;
+    for (uint32_t k = 0; k < lim; k++) {
+        const uint32_t v = L.hlist[k][lane];
+        res.add((int)(v >> 30), v & PID_MASK);
+    }
+    res.store(r, nc > HMAX, min_e, cnt, slots, list_scan, counters);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -234,37 +440,38 @@ static constexpr int DP_BIG = 100;
 template <bool DP, bool FILL>
 __global__ void __launch_bounds__(256)
 k_scan(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const int32_t *__restrict__ list,
-       const uint32_t *__restrict__ list_count, int64_t n_all, const uint2 *__restrict__ pat, int np, int bl,
-       int max_err, int prefix_len, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
+       int64_t n_list, int n_slices, const uint2 *__restrict__ pat, int np, int bl, int max_err, int prefix_len,
+       const uint8_t *__restrict__ min_e, uint32_t *__restrict__ part_best, uint32_t *__restrict__ part_cnt,
        const int64_t *__restrict__ hit_offs, uint32_t *__restrict__ hits) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t n_list = list ? (int64_t)*list_count : n_all;
-    for (int64_t w = wave; w < n_list; w += n_waves) {
-        const int64_t r = list ? (int64_t)list[w] : w;
+    const int tiles = (np + 63) / 64;
+    const int tiles_per_slice = (tiles + n_slices - 1) / n_slices;
+    for (int64_t w = wave; w < n_list * n_slices; w += n_waves) {
+        const int64_t li = w / n_slices;
+        const int slice = (int)(w - li * n_slices);
+        const int64_t r = (int64_t)list[li];
         const int64_t b0 = offs[r];
         const int64_t len = offs[r + 1] - b0;
-        if (len < bl - max_err) {  // only reachable when list == nullptr (k_pack filters otherwise)
-            if (!FILL && lane == 0) {
-                min_e[r] = SCT_NO_HIT;
-                cnt[r] = 0;
-            }
-            continue;
-        }
+        const int p_begin = slice * tiles_per_slice * 64;
+        const int p_end = min(np, p_begin + tiles_per_slice * 64);
         int target = 0;
         int64_t out_base = 0;
         if (FILL) {
             target = min_e[r];
             if (target == SCT_NO_HIT) continue;
-            out_base = hit_offs[r];
+            // hits of the earlier slices at the same minimum come first (lane s holds slice s, n_slices <= 64)
+            uint32_t mine = 0;
+            if (lane < slice && part_best[li * n_slices + lane] == (uint32_t)target) mine = part_cnt[li * n_slices + lane];
+            out_base = hit_offs[r] + wave_sum(mine);
         }
         int lane_best = max_err + 1;
         uint32_t lane_cnt = 0;
         uint32_t written = 0;  // wave-uniform
-        for (int p0 = 0; p0 < np; p0 += 64) {
+        for (int p0 = p_begin; p0 < p_end; p0 += 64) {
             const int p = p0 + lane;
-            const bool pvalid = p < np;
+            const bool pvalid = p < p_end;
             const uint2 pp = pvalid ? pat[p] : make_uint2(0, 0);
             int d;
             if (!DP) {
@@ -348,15 +555,36 @@ k_scan(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const
             const int wb = wave_min(lane_best);
             const uint32_t total = wave_sum(lane_best == wb ? lane_cnt : 0u);
             if (lane == 0) {
-                if (wb <= max_err) {
-                    min_e[r] = (uint8_t)wb;
-                    cnt[r] = total;
-                } else {
-                    min_e[r] = SCT_NO_HIT;
-                    cnt[r] = 0;
-                }
+                part_best[w] = (uint32_t)wb;
+                part_cnt[w] = total;
             }
         }
+    }
+}
+
+// fold the per-slice partial results of k_scan's count pass: one lane per listed segment
+__global__ void __launch_bounds__(256)
+k_scan_reduce(const int32_t *__restrict__ list, int64_t n_list, int n_slices, int max_err,
+              const uint32_t *__restrict__ part_best, const uint32_t *__restrict__ part_cnt,
+              uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt) {
+    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_list) return;
+    uint32_t best = (uint32_t)max_err + 1u, total = 0;
+    for (int sl = 0; sl < n_slices; sl++) {
+        const uint32_t b = part_best[li * n_slices + sl], c = part_cnt[li * n_slices + sl];
+        if (b < best) {
+            best = b;
+            total = 0;
+        }
+        if (b == best) total += c;
+    }
+    const int64_t r = list[li];
+    if (best <= (uint32_t)max_err) {
+        min_e[r] = (uint8_t)best;
+        cnt[r] = total;
+    } else {
+        min_e[r] = SCT_NO_HIT;
+        cnt[r] = 0;
     }
 }
 
@@ -487,11 +715,12 @@ struct sct_ctx {
     int64_t n_seg = -1, seg_bytes = 0;
     DevBuf segs, offs;
     // work / results
-    DevBuf lo, hi, meta, min_e, cnt, route, slots, list_scan, list_dp, counters, hit_offs, sums, total, hits;
+    DevBuf lo, hi, meta, min_e, cnt, route, slots, list_scan, list_dp, counters, hit_offs, sums, total, hits, part_best, part_cnt;
     int64_t n_hits = 0;
     bool have_result = false;
     // options
     bool force_exhaustive = false, timing = true;
+    int filter_mode = 0;  // 0 = wave-cooperative k_filter, 1 = k_filter_lane
     // timing
     std::vector<TimedKernel> timed;
     std::vector<std::pair<const char *, float>> last_ms;
@@ -573,7 +802,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
                       &c->cnt, &c->route, &c->slots, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
-                      &c->total, &c->hits};
+                      &c->total, &c->hits, &c->part_best, &c->part_cnt};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -591,6 +820,7 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return fail(SCT_E_ARG, "sct_set_option: NULL argument");
     if (!strcmp(key, "force_exhaustive")) c->force_exhaustive = value != 0;
     else if (!strcmp(key, "timing")) c->timing = value != 0;
+    else if (!strcmp(key, "filter_mode")) c->filter_mode = (int)value;
     else return fail(SCT_E_ARG, "unknown option '%s'", key);
     return SCT_OK;
 }
@@ -702,7 +932,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     const int64_t n = c->n_seg;
     const int np = c->np, bl = c->bl;
     const int prefix_len = sct_prefix_len(threads);
-    const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0;
+    const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && np <= (int)PID_MASK;
     const size_t n1 = (size_t)(n ? n : 1);
     if (c->lo.ensure(4 * n1) || c->hi.ensure(4 * n1) || c->meta.ensure(4 * n1) || c->min_e.ensure(n1) ||
         c->cnt.ensure(4 * n1) || c->route.ensure(4 * n1) || c->list_scan.ensure(4 * n1) || c->list_dp.ensure(4 * n1) ||
@@ -728,30 +958,64 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         if (filter_ok) {
             Timer t(c, "k_filter");
             const unsigned g = blocks_for(n, 256);
+#define FILTER_ARGS                                                                                                   \
+    c->lo.as<uint32_t>(), c->hi.as<uint32_t>(), c->meta.as<uint32_t>(), n, c->tab_off.as<uint32_t>(),                  \
+        c->tab_ent.as<uint32_t>(), c->pat.as<uint2>(), np, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(),              \
+        c->slots.as<uint32_t>(), c->list_scan.as<int32_t>(), counters
 #define LAUNCH_FILTER(E)                                                                                              \
-    k_filter<E><<<g, 256, 0, st>>>(c->lo.as<uint32_t>(), c->hi.as<uint32_t>(), c->meta.as<uint32_t>(), n,              \
-                                   c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->pat.as<uint2>(), np,       \
-                                   c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(),             \
-                                   c->list_scan.as<int32_t>(), counters)
+    do {                                                                                                              \
+        if (c->filter_mode == 1) k_filter_lane<E><<<g, 256, 0, st>>>(FILTER_ARGS);                                     \
+        else k_filter<E><<<g, 256, 0, st>>>(FILTER_ARGS);                                                              \
+    } while (0)
             if (max_err == 0) LAUNCH_FILTER(0);
             else if (max_err == 1) LAUNCH_FILTER(1);
             else LAUNCH_FILTER(2);
 #undef LAUNCH_FILTER
+#undef FILTER_ARGS
         }
         // remember which rows were deferred (cnt is about to be overwritten by the scan path's count pass)
         HIPCHK(hipMemcpyAsync(c->route.p, c->cnt.p, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
-        const unsigned scan_grid = 256 * 8;  // grid-stride over the lists: 8 blocks of 4 waves per CU
-        {
+    }
+    // host sync #1: how many rows go through the scan paths (normally none or a handful)
+    uint32_t hc[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(hc, c->counters.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // a short list is cut into pattern slices so that the whole chip works on it; a long one needs no slicing
+    auto slices_for = [&](uint32_t rows) {
+        if (rows == 0) return 1;
+        const int tiles = (np + 63) / 64;
+        int64_t sl = (4096 + rows - 1) / rows;
+        if (sl > 64) sl = 64;
+        if (sl > tiles) sl = tiles;
+        return (int)(sl < 1 ? 1 : sl);
+    };
+    const int sl_scan = slices_for(hc[0]), sl_dp = slices_for(hc[1]);
+    auto grid_for = [&](uint32_t rows, int sl) {
+        const int64_t waves = (int64_t)rows * sl;
+        const int64_t blocks = (waves + 3) / 4;
+        return (unsigned)(blocks < 2048 ? (blocks < 1 ? 1 : blocks) : 2048);
+    };
+    if (c->part_best.ensure(4 * ((size_t)hc[0] * sl_scan + (size_t)hc[1] * sl_dp + 1)) ||
+        c->part_cnt.ensure(4 * ((size_t)hc[0] * sl_scan + (size_t)hc[1] * sl_dp + 1)))
+        return SCT_E_HIP;
+    uint32_t *pb_scan = c->part_best.as<uint32_t>(), *pc_scan = c->part_cnt.as<uint32_t>();
+    uint32_t *pb_dp = pb_scan + (size_t)hc[0] * sl_scan, *pc_dp = pc_scan + (size_t)hc[0] * sl_scan;
+    if (n > 0) {
+        if (hc[0]) {
             Timer t(c, "k_scan_count");
-            k_scan<false, false><<<scan_grid, 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(),
-                                                            counters + 0, n, c->pat.as<uint2>(), np, bl, max_err, prefix_len,
-                                                            c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), nullptr, nullptr);
+            k_scan<false, false><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
+                c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
+                np, bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_scan, pc_scan, nullptr, nullptr);
+            k_scan_reduce<<<blocks_for(hc[0], 256), 256, 0, st>>>(c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, max_err, pb_scan,
+                                                                  pc_scan, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>());
         }
-        {
+        if (hc[1]) {
             Timer t(c, "k_dp_count");
-            k_scan<true, false><<<scan_grid, 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_dp.as<int32_t>(),
-                                                           counters + 1, n, c->pat.as<uint2>(), np, bl, max_err, prefix_len,
-                                                           c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), nullptr, nullptr);
+            k_scan<true, false><<<grid_for(hc[1], sl_dp), 256, 0, st>>>(
+                c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_dp.as<int32_t>(), (int64_t)hc[1], sl_dp, c->pat.as<uint2>(), np,
+                bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_dp, pc_dp, nullptr, nullptr);
+            k_scan_reduce<<<blocks_for(hc[1], 256), 256, 0, st>>>(c->list_dp.as<int32_t>(), (int64_t)hc[1], sl_dp, max_err, pb_dp, pc_dp,
+                                                                  c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>());
         }
         {
             Timer t(c, "k_offsets");
@@ -764,14 +1028,12 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         HIPCHK(hipMemsetAsync(c->hit_offs.p, 0, 8, st));
         HIPCHK(hipMemsetAsync(c->total.p, 0, 8, st));
     }
+    // host sync #2: the total hit count sizes the CSR hit array
     uint64_t total = 0;
-    uint32_t hc[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(&total, c->total.p, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(hc, c->counters.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (c->hits.ensure(4 * (size_t)(total ? total : 1))) return SCT_E_HIP;
     if (n > 0 && total > 0) {
-        const unsigned scan_grid = 256 * 8;
         if (filter_ok) {
             Timer t(c, "k_fill");
             k_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->hit_offs.as<int64_t>(),
@@ -779,17 +1041,15 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         }
         if (hc[0]) {
             Timer t(c, "k_scan_fill");
-            k_scan<false, true><<<scan_grid, 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(),
-                                                           counters + 0, n, c->pat.as<uint2>(), np, bl, max_err, prefix_len,
-                                                           c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->hit_offs.as<int64_t>(),
-                                                           c->hits.as<uint32_t>());
+            k_scan<false, true><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
+                c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
+                np, bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_scan, pc_scan, c->hit_offs.as<int64_t>(), c->hits.as<uint32_t>());
         }
         if (hc[1]) {
             Timer t(c, "k_dp_fill");
-            k_scan<true, true><<<scan_grid, 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_dp.as<int32_t>(),
-                                                          counters + 1, n, c->pat.as<uint2>(), np, bl, max_err, prefix_len,
-                                                          c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->hit_offs.as<int64_t>(),
-                                                          c->hits.as<uint32_t>());
+            k_scan<true, true><<<grid_for(hc[1], sl_dp), 256, 0, st>>>(
+                c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_dp.as<int32_t>(), (int64_t)hc[1], sl_dp, c->pat.as<uint2>(), np,
+                bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_dp, pc_dp, c->hit_offs.as<int64_t>(), c->hits.as<uint32_t>());
         }
     }
     HIPCHK(hipStreamSynchronize(st));

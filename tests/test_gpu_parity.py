@@ -28,7 +28,11 @@ def run_both(m, bc, segs, offs, e, t=1):
     """-> (filter-path result, exhaustive-path result)"""
     m.set_barcodes(bc)
     m.set_option("force_exhaustive", 0)
+    m.set_option("filter_mode", 0)
     a = m.match(segs, offs, e, t)
+    m.set_option("filter_mode", 1)          # the one-lane-per-segment variant must agree bit for bit
+    util.assert_same(m.match(segs, offs, e, t), a, "filter_mode 1 vs 0")
+    m.set_option("filter_mode", 0)
     m.set_option("force_exhaustive", 1)
     b = m.match(segs, offs, e, t)
     m.set_option("force_exhaustive", 0)
