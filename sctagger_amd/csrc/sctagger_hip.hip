@@ -263,23 +263,28 @@ template <int E>
 struct FilterWave {
     FilterWaveLds &L;
     const uint32_t *__restrict__ tab_off;
-    const uint32_t *__restrict__ tab_ent;
-    const uint2 *__restrict__ pat;
+    const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
+    const uint32_t *__restrict__ tab_code;  // the same entries as packed planes lo16 | hi16 << 16
     int np;
     int lane;
     bool active;
     int len;
     uint32_t lo, hi;
     uint32_t head = 0, tail = 0;  // wave-uniform
+    // bucket ranges of the step whose offsets were loaded last (global entry indices f*np + k); they are pushed
+    // when the NEXT step arrives, so that the offset loads of a step overlap the queue work of the one before
+    int pend_kind = -1;
+    uint32_t ps0 = 0, pe0 = 0, ps1 = 0, pe1 = 0, ps2 = 0, pe2 = 0;
 
     __device__ __forceinline__ void verify(bool take) {
         if (take) {
             const uint32_t item = L.q[(head + lane) & (QCAP - 1)];
-            const uint32_t src = item >> PID_BITS, pid = item & PID_MASK;
+            const uint32_t src = item >> PID_BITS, gk = item & PID_MASK;
+            const uint32_t code = tab_code[gk];
             const uint32_t tl = L.tls[src], th = L.ths[src], v = L.va[src];
-            const uint2 p = pat[pid];
-            const int d = wm_verify<E>(tl, th, v & ~1u, v, p.x, p.y, 16);
+            const int d = wm_verify<E>(tl, th, v & ~1u, v, code & 0xFFFFu, code >> 16, 16);
             if (d <= E) {
+                const uint32_t pid = tab_ent[gk];
                 const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
                 if (k < HMAX) L.hlist[k][src] = ((uint32_t)d << 30) | pid;
             }
@@ -287,81 +292,64 @@ struct FilterWave {
         __builtin_amdgcn_wave_barrier();
     }
 
-    // append the bucket [s, e) of family f for every lane, draining full batches as they form
-    __device__ __forceinline__ void push_bucket(int f, uint32_t s, uint32_t e) {
-        const uint32_t *ent = tab_ent + (size_t)f * np;
+    // append the entry indices [s, e) for every lane, one per lane and round, draining full batches as they form
+    __device__ __forceinline__ void push_range(uint32_t s, uint32_t e) {
         uint32_t c = e - s;
-        while (__ballot(c > 0)) {
-            // up to four entries per lane are fetched together so that their latencies overlap
-            uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-            if (c > 0) p0 = ent[s];
-            if (c > 1) p1 = ent[s + 1];
-            if (c > 2) p2 = ent[s + 2];
-            if (c > 3) p3 = ent[s + 3];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const bool has = c > 0;
-                const uint64_t m = __ballot(has);
-                if (m == 0) break;
-                if (has) {
-                    L.q[(tail + lane_rank(m)) & (QCAP - 1)] = ((uint32_t)lane << PID_BITS) | p0;
-                    s++;
-                    c--;
-                }
-                p0 = p1;
-                p1 = p2;
-                p2 = p3;
-                tail += (uint32_t)__popcll(m);
-                __builtin_amdgcn_wave_barrier();
-                if (tail - head >= 64) {
-                    verify(true);
-                    head += 64;
-                }
+        for (;;) {
+            const bool has = c > 0;
+            const uint64_t m = __ballot(has);
+            if (m == 0) break;
+            if (has) {
+                L.q[(tail + lane_rank(m)) & (QCAP - 1)] = ((uint32_t)lane << PID_BITS) | s;
+                s++;
+                c--;
+            }
+            tail += (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (tail - head >= 64) {
+                verify(true);
+                head += 64;
             }
         }
     }
 
+    __device__ __forceinline__ void flush_pending() {
+        if (pend_kind < 0) return;
+        push_range(ps0, pe0);
+        if (pend_kind == SCT_STEP_8MER) {
+            if (E >= 1) push_range(ps1, pe1);
+            if (E >= 2) push_range(ps2, pe2);
+        } else if (pend_kind == SCT_STEP_PAIR8) {
+            push_range(ps1, pe1);
+        }
+        pend_kind = -1;
+    }
+
     __device__ __forceinline__ void operator()(int kind, int t, int t2) {
+        // 1. issue this step's offset loads
         const bool v = active && sct_step_valid(kind, t, t2, len);
         const uint32_t key = sct_step_key(kind, lo, hi, t, t2);
-        if (kind == SCT_STEP_8MER) {
-            uint32_t s0 = 0, e0 = 0, s1 = 0, e1 = 0, s2 = 0, e2 = 0;
-            if (v) {
-                const uint32_t *o = tab_off + key;
-                s0 = o[(size_t)SCT_F_H1 * (SCT_KEYS + 1)];
-                e0 = o[(size_t)SCT_F_H1 * (SCT_KEYS + 1) + 1];
-                if (E >= 1) {
-                    s1 = o[(size_t)SCT_F_H2 * (SCT_KEYS + 1)];
-                    e1 = o[(size_t)SCT_F_H2 * (SCT_KEYS + 1) + 1];
-                }
-                if (E >= 2) {
-                    s2 = o[(size_t)SCT_F_MID * (SCT_KEYS + 1)];
-                    e2 = o[(size_t)SCT_F_MID * (SCT_KEYS + 1) + 1];
-                }
+        uint32_t s0 = 0, e0 = 0, s1 = 0, e1 = 0, s2 = 0, e2 = 0;
+        const int f0 = kind == SCT_STEP_8MER ? SCT_F_H1 : kind == SCT_STEP_PAIR8 ? SCT_F_02 : SCT_F_03;
+        const int f1 = kind == SCT_STEP_8MER ? SCT_F_H2 : SCT_F_13;
+        if (v) {
+            const uint32_t *o = tab_off + key;
+            s0 = o[(size_t)f0 * (SCT_KEYS + 1)] + (uint32_t)f0 * (uint32_t)np;
+            e0 = o[(size_t)f0 * (SCT_KEYS + 1) + 1] + (uint32_t)f0 * (uint32_t)np;
+            if ((kind == SCT_STEP_8MER && E >= 1) || kind == SCT_STEP_PAIR8) {
+                s1 = o[(size_t)f1 * (SCT_KEYS + 1)] + (uint32_t)f1 * (uint32_t)np;
+                e1 = o[(size_t)f1 * (SCT_KEYS + 1) + 1] + (uint32_t)f1 * (uint32_t)np;
             }
-            push_bucket(SCT_F_H1, s0, e0);
-            if (E >= 1) push_bucket(SCT_F_H2, s1, e1);
-            if (E >= 2) push_bucket(SCT_F_MID, s2, e2);
-        } else if (kind == SCT_STEP_PAIR8) {
-            uint32_t s0 = 0, e0 = 0, s1 = 0, e1 = 0;
-            if (v) {
-                const uint32_t *o = tab_off + key;
-                s0 = o[(size_t)SCT_F_02 * (SCT_KEYS + 1)];
-                e0 = o[(size_t)SCT_F_02 * (SCT_KEYS + 1) + 1];
-                s1 = o[(size_t)SCT_F_13 * (SCT_KEYS + 1)];
-                e1 = o[(size_t)SCT_F_13 * (SCT_KEYS + 1) + 1];
+            if (kind == SCT_STEP_8MER && E >= 2) {
+                s2 = o[(size_t)SCT_F_MID * (SCT_KEYS + 1)] + (uint32_t)SCT_F_MID * (uint32_t)np;
+                e2 = o[(size_t)SCT_F_MID * (SCT_KEYS + 1) + 1] + (uint32_t)SCT_F_MID * (uint32_t)np;
             }
-            push_bucket(SCT_F_02, s0, e0);
-            push_bucket(SCT_F_13, s1, e1);
-        } else {
-            uint32_t s0 = 0, e0 = 0;
-            if (v) {
-                const uint32_t *o = tab_off + (size_t)SCT_F_03 * (SCT_KEYS + 1) + key;
-                s0 = o[0];
-                e0 = o[1];
-            }
-            push_bucket(SCT_F_03, s0, e0);
         }
+        // 2. queue the previous step's buckets while those loads are in flight
+        flush_pending();
+        // 3. this step becomes the pending one
+        pend_kind = kind;
+        ps0 = s0; pe0 = e0; ps1 = s1; pe1 = e1; ps2 = s2; pe2 = e2;
     }
 };
 
@@ -375,7 +363,7 @@ template <int E>
 __global__ void __launch_bounds__(256)
 k_filter(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
          int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
-         const uint2 *__restrict__ pat, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
+         const uint32_t *__restrict__ tab_code, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
          uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan, uint32_t *__restrict__ counters) {
     __shared__ FilterWaveLds lds[4];
     FilterWaveLds &L = lds[threadIdx.x >> 6];
@@ -400,8 +388,9 @@ k_filter(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in,
     L.va[lane] = va;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    FilterWave<E> W{L, tab_off, tab_ent, pat, np, lane, active, len, lo, hi};
+    FilterWave<E> W{L, tab_off, tab_ent, tab_code, np, lane, active, len, lo, hi};
     sct_for_each_step<E>(maxlen, W);
+    W.flush_pending();
     if (W.tail != W.head) {
         W.verify((uint32_t)lane < W.tail - W.head);
         W.head = W.tail;
@@ -710,7 +699,7 @@ struct sct_ctx {
     // barcodes
     int n_bc = 0, bl = 0, np = 0;
     bool have_bc = false, have_tables = false;
-    DevBuf pat, tab_off, tab_ent;
+    DevBuf pat, tab_off, tab_ent, tab_code;
     // segments
     int64_t n_seg = -1, seg_bytes = 0;
     DevBuf segs, offs;
@@ -800,7 +789,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
+    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
                       &c->cnt, &c->route, &c->slots, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
                       &c->total, &c->hits, &c->part_best, &c->part_cnt};
     for (DevBuf *b : bufs) b->release();
@@ -867,17 +856,25 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
     c->have_tables = false;
     if (bl == 16) {
         // seed tables: counting sort of the pattern ids by key, per family (ids ascending inside a bucket)
-        std::vector<uint32_t> off((size_t)SCT_NFAM * (SCT_KEYS + 1), 0u), ent((size_t)SCT_NFAM * (np ? np : 1));
+        std::vector<uint32_t> off((size_t)SCT_NFAM * (SCT_KEYS + 1), 0u), ent((size_t)SCT_NFAM * (np ? np : 1)),
+            code((size_t)SCT_NFAM * (np ? np : 1));
         for (int f = 0; f < SCT_NFAM; f++) {
             uint32_t *o = off.data() + (size_t)f * (SCT_KEYS + 1);
             for (int p = 0; p < np; p++) o[sct_pattern_key(f, pat[p].x, pat[p].y) + 1]++;
             for (int k = 0; k < SCT_KEYS; k++) o[k + 1] += o[k];
             std::vector<uint32_t> cur(o, o + SCT_KEYS);
             uint32_t *e = ent.data() + (size_t)f * np;
-            for (int p = 0; p < np; p++) e[cur[sct_pattern_key(f, pat[p].x, pat[p].y)]++] = (uint32_t)p;
+            uint32_t *cd = code.data() + (size_t)f * np;
+            for (int p = 0; p < np; p++) {
+                const uint32_t at = cur[sct_pattern_key(f, pat[p].x, pat[p].y)]++;
+                e[at] = (uint32_t)p;
+                cd[at] = (pat[p].x & 0xFFFFu) | (pat[p].y << 16);
+            }
         }
         if (c->tab_off.ensure(off.size() * sizeof(uint32_t))) return SCT_E_HIP;
         if (c->tab_ent.ensure(ent.size() * sizeof(uint32_t))) return SCT_E_HIP;
+        if (c->tab_code.ensure(code.size() * sizeof(uint32_t))) return SCT_E_HIP;
+        HIPCHK(hipMemcpyAsync(c->tab_code.p, code.data(), code.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->tab_off.p, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->tab_ent.p, ent.data(), ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -932,7 +929,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     const int64_t n = c->n_seg;
     const int np = c->np, bl = c->bl;
     const int prefix_len = sct_prefix_len(threads);
-    const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && np <= (int)PID_MASK;
+    const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && (int64_t)np * SCT_NFAM <= (int64_t)PID_MASK;
     const size_t n1 = (size_t)(n ? n : 1);
     if (c->lo.ensure(4 * n1) || c->hi.ensure(4 * n1) || c->meta.ensure(4 * n1) || c->min_e.ensure(n1) ||
         c->cnt.ensure(4 * n1) || c->route.ensure(4 * n1) || c->list_scan.ensure(4 * n1) || c->list_dp.ensure(4 * n1) ||
@@ -958,14 +955,14 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         if (filter_ok) {
             Timer t(c, "k_filter");
             const unsigned g = blocks_for(n, 256);
-#define FILTER_ARGS                                                                                                   \
+#define FILTER_ARGS(THIRD)                                                                                            \
     c->lo.as<uint32_t>(), c->hi.as<uint32_t>(), c->meta.as<uint32_t>(), n, c->tab_off.as<uint32_t>(),                  \
-        c->tab_ent.as<uint32_t>(), c->pat.as<uint2>(), np, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(),              \
-        c->slots.as<uint32_t>(), c->list_scan.as<int32_t>(), counters
+        c->tab_ent.as<uint32_t>(), THIRD, np, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(),  \
+        c->list_scan.as<int32_t>(), counters
 #define LAUNCH_FILTER(E)                                                                                              \
     do {                                                                                                              \
-        if (c->filter_mode == 1) k_filter_lane<E><<<g, 256, 0, st>>>(FILTER_ARGS);                                     \
-        else k_filter<E><<<g, 256, 0, st>>>(FILTER_ARGS);                                                              \
+        if (c->filter_mode == 1) k_filter_lane<E><<<g, 256, 0, st>>>(FILTER_ARGS(c->pat.as<uint2>()));                 \
+        else k_filter<E><<<g, 256, 0, st>>>(FILTER_ARGS(c->tab_code.as<uint32_t>()));                                  \
     } while (0)
             if (max_err == 0) LAUNCH_FILTER(0);
             else if (max_err == 1) LAUNCH_FILTER(1);
