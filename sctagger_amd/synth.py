@@ -26,6 +26,16 @@ def make_barcodes(n, bl=16, seed=1):
     rng = np.random.default_rng(seed)
     if 4 ** bl < n:
         raise ValueError("cannot draw %d distinct %d-mers" % (n, bl))
+    if bl <= 31:
+        # distinct 2-bit packed integers (fast path, used for the 3.6 M-barcode configuration)
+        codes = np.empty(0, dtype=np.uint64)
+        while codes.size < n:
+            cand = rng.integers(0, 4 ** bl, size=max(2 * (n - codes.size), 64), dtype=np.uint64)
+            codes = np.unique(np.concatenate([codes, cand]))
+        codes = codes[rng.permutation(codes.size)[:n]]
+        shifts = (2 * np.arange(bl, dtype=np.uint64))[None, :]
+        got = ((codes[:, None] >> shifts) & np.uint64(3)).astype(np.uint8)
+        return _ACGT[got]
     got = np.empty((0, bl), dtype=np.uint8)
     while got.shape[0] < n:
         cand = rng.integers(0, 4, size=(max(2 * (n - got.shape[0]), 64), bl), dtype=np.uint8)

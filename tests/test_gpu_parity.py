@@ -244,6 +244,17 @@ def test_cfg3_sample_vs_exhaustive_and_oracle(m):
     assert np.array_equal(a[0][:k], want[0]) and np.array_equal(a[2][:a[1][k]], want[2])
 
 
+def test_cfg5_scale_barcode_set(m):
+    """BASELINE configs[4]: 3.6 M barcodes, e<=1.  Filter path == exhaustive scan on 2000 rows; 200 rows == oracle."""
+    bc = synth.make_barcodes(3_600_000, seed=5)
+    segs, offs = synth.make_segments(2000, bc, seed=5)
+    a, b = run_both(m, bc, segs, offs, 1, t=16)
+    util.assert_same(a, b, "filter vs exhaustive at 3.6M barcodes")
+    k = 200
+    want = trie_oracle.match(bc, segs[:offs[k]], offs[:k + 1], 1, threads=16, workers=8)
+    assert np.array_equal(a[0][:k], want[0]) and np.array_equal(a[2][:a[1][k]], want[2])
+
+
 def test_resident_three_step_api(m):
     bc = synth.make_barcodes(1000, seed=9)
     segs, offs = synth.make_segments(50000, bc, seed=9)
