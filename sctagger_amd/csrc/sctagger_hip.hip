@@ -249,7 +249,8 @@ static constexpr int PID_BITS = 26;
 static constexpr uint32_t PID_MASK = (1u << PID_BITS) - 1u;
 
 struct FilterWaveLds {
-    uint32_t tls[64], ths[64], va[64];
+    uint32_t em[4][64];  // em[c][lane]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
+    uint32_t va[64];     // bits 0..len
     uint32_t hcnt[64];
     uint32_t hlist[HMAX][64];
     uint32_t q[QCAP];
@@ -264,7 +265,7 @@ struct FilterWave {
     FilterWaveLds &L;
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
-    const uint32_t *__restrict__ tab_code;  // the same entries as packed planes lo16 | hi16 << 16
+    const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
     int np;
     int lane;
     bool active;
@@ -276,13 +277,39 @@ struct FilterWave {
     int pend_kind = -1;
     uint32_t ps0 = 0, pe0 = 0, ps1 = 0, pe1 = 0, ps2 = 0, pe2 = 0;
 
+    // transposed Wu-Manber automaton (wm_verify of sct_core.h) with the per-character match masks read from LDS:
+    // code = the barcode as 2-bit codes, character j at bits 2j..2j+1
+    __device__ __forceinline__ int automaton(uint32_t src, uint32_t code) {
+        const uint32_t va = L.va[src];
+        const uint32_t *em = &L.em[0][src];
+        uint32_t R0 = va, R1 = va, R2 = va;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t Em = em[((code >> (2 * j)) & 3u) * 64];
+            const uint32_t s0 = R0 << 1;
+            const uint32_t n0 = s0 & Em;
+            if (E >= 1) {
+                const uint32_t s1 = R1 << 1;
+                const uint32_t n1 = (s1 & Em) | s0 | R0 | (n0 << 1);
+                if (E >= 2) {
+                    const uint32_t s2 = R2 << 1;
+                    R2 = (s2 & Em) | s1 | R1 | (n1 << 1);
+                }
+                R1 = n1;
+            }
+            R0 = n0;
+        }
+        if (R0 & va) return 0;
+        if (E >= 1 && (R1 & va)) return 1;
+        if (E >= 2 && (R2 & va)) return 2;
+        return E + 1;
+    }
+
     __device__ __forceinline__ void verify(bool take) {
         if (take) {
             const uint32_t item = L.q[(head + lane) & (QCAP - 1)];
             const uint32_t src = item >> PID_BITS, gk = item & PID_MASK;
-            const uint32_t code = tab_code[gk];
-            const uint32_t tl = L.tls[src], th = L.ths[src], v = L.va[src];
-            const int d = wm_verify<E>(tl, th, v & ~1u, v, code & 0xFFFFu, code >> 16, 16);
+            const int d = automaton(src, tab_code[gk]);
             if (d <= E) {
                 const uint32_t pid = tab_ent[gk];
                 const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
@@ -383,8 +410,11 @@ k_filter(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in,
     const int maxlen = wave_max_i(len);
     if (maxlen == 0) return;  // the whole wave has nothing to do
     const uint32_t va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
-    L.tls[lane] = lo << 1;
-    L.ths[lane] = hi << 1;
+    const uint32_t ve = va & ~1u, l1 = lo << 1, h1 = hi << 1;
+    L.em[0][lane] = ~l1 & ~h1 & ve;
+    L.em[1][lane] = l1 & ~h1 & ve;
+    L.em[2][lane] = ~l1 & h1 & ve;
+    L.em[3][lane] = l1 & h1 & ve;
     L.va[lane] = va;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -868,7 +898,9 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             for (int p = 0; p < np; p++) {
                 const uint32_t at = cur[sct_pattern_key(f, pat[p].x, pat[p].y)]++;
                 e[at] = (uint32_t)p;
-                cd[at] = (pat[p].x & 0xFFFFu) | (pat[p].y << 16);
+                uint32_t inter = 0;
+                for (int j = 0; j < 16; j++) inter |= (((pat[p].x >> j) & 1u) | (((pat[p].y >> j) & 1u) << 1)) << (2 * j);
+                cd[at] = inter;
             }
         }
         if (c->tab_off.ensure(off.size() * sizeof(uint32_t))) return SCT_E_HIP;
