@@ -1,0 +1,105 @@
+/*
+ * sct_hostio.c — host-side ingest / egress helpers of the match_trie CLI (plain C, no GPU code).
+ *
+ * The reference parses the -lr TSV with a per-character Python loop (scTagger.py:611-626) and writes the
+ * result with per-row f-strings (:777-789).  These two functions do the same byte shuffling at memory
+ * speed so that the command line is not dominated by Python at 10^7 rows:
+ *
+ *   sctio_parse_lr   TSV bytes -> read-id spans (column 0) + CSR segments (column 3)
+ *   sctio_render     result arrays -> exactly the bytes of the reference's output block
+ *
+ * Both are two-call APIs (size, then fill) over caller-owned buffers; bound from sctagger_amd/fastio.py.
+ */
+#include <stdint.h>
+#include <string.h>
+
+/* Number of lines (a last line without '\n' counts). */
+int64_t sctio_count_lines(const uint8_t *buf, int64_t len) {
+    int64_t n = 0;
+    const uint8_t *p = buf, *end = buf + len;
+    while (p < end) {
+        const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+        n++;
+        if (!q) break;
+        p = q + 1;
+    }
+    return n;
+}
+
+/*
+ * Column 0 span and column 3 bytes of every line (reference read_long_reads, scTagger.py:611-614: only
+ * l[0] and l[3] are used; a 5th column and beyond are ignored).
+ * Returns -1 on success, or the 0-based number of the first line with fewer than 4 tab-separated fields
+ * (the reference raises IndexError there).  segs must hold `len` bytes; offs n+1 entries.
+ */
+int64_t sctio_parse_lr(const uint8_t *buf, int64_t len, int64_t n, int64_t *name_start, int64_t *name_end,
+                       uint8_t *segs, int64_t *offs) {
+    int64_t out = 0, p = 0;
+    for (int64_t i = 0; i < n; i++) {
+        /* one pass over the line: positions of the first four tabs and of the line end */
+        int64_t tab[4] = {-1, -1, -1, -1};
+        int nt = 0;
+        int64_t q = p;
+        for (; q < len; q++) {
+            const uint8_t c = buf[q];
+            if (c == '\n') break;
+            if (c == '\t' && nt < 4) tab[nt++] = q;
+        }
+        if (nt < 3) return i;
+        const int64_t s = tab[2] + 1, e = nt >= 4 ? tab[3] : q;
+        name_start[i] = p;
+        name_end[i] = tab[0];
+        offs[i] = out;
+        for (int64_t k = s; k < e; k++) segs[out++] = buf[k];
+        p = q + 1;
+    }
+    offs[n] = out;
+    return -1;
+}
+
+static int ndigits(uint64_t v) {
+    int d = 1;
+    while (v >= 10) { v /= 10; d++; }
+    return d;
+}
+static uint8_t *put_num(uint8_t *o, uint64_t v) {
+    int d = ndigits(v);
+    for (int k = d - 1; k >= 0; k--) { o[k] = (uint8_t)('0' + v % 10); v /= 10; }
+    return o + d;
+}
+
+/*
+ * The reference's output block (scTagger.py:777-789) for rows [r0, r1): matched rows only, in rid order,
+ *   name \t min_e \t n_hits \t segment \t comma-joined barcode strings \n
+ * pattern_text: 2*n_bc rows of bl bytes, row p = string printed for hit p = bid*2+strand.
+ * With out == NULL only the size is returned.
+ */
+int64_t sctio_render(const uint8_t *namebuf, const int64_t *name_start, const int64_t *name_end, const uint8_t *segs,
+                     const int64_t *offs, const uint8_t *min_e, const int64_t *hit_offs, const uint32_t *hits,
+                     const uint8_t *pattern_text, int32_t bl, int64_t r0, int64_t r1, uint8_t *out) {
+    int64_t size = 0;
+    uint8_t *o = out;
+    for (int64_t r = r0; r < r1; r++) {
+        if (min_e[r] == 0xFF) continue;
+        const int64_t ln = name_end[r] - name_start[r], ls = offs[r + 1] - offs[r];
+        const int64_t c = hit_offs[r + 1] - hit_offs[r];
+        if (!out) {
+            size += ln + ndigits(min_e[r]) + ndigits((uint64_t)c) + ls + c * bl + (c > 0 ? c - 1 : 0) + 5;
+            continue;
+        }
+        memcpy(o, namebuf + name_start[r], (size_t)ln); o += ln;
+        *o++ = '\t';
+        o = put_num(o, min_e[r]);
+        *o++ = '\t';
+        o = put_num(o, (uint64_t)c);
+        *o++ = '\t';
+        memcpy(o, segs + offs[r], (size_t)ls); o += ls;
+        *o++ = '\t';
+        for (int64_t k = 0; k < c; k++) {
+            if (k) *o++ = ',';
+            memcpy(o, pattern_text + (int64_t)hits[hit_offs[r] + k] * bl, (size_t)bl); o += bl;
+        }
+        *o++ = '\n';
+    }
+    return out ? (int64_t)(o - out) : size;
+}

@@ -244,7 +244,7 @@ k_filter_lane(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ h
 // needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
 // ------------------------------------------------------------------------------------------------------------
 static constexpr int QCAP = 128;  // >= 64 left over + 64 pushed per round
-static constexpr int HMAX = 24;
+static constexpr int HMAX = 16;
 static constexpr int PID_BITS = 26;
 static constexpr uint32_t PID_MASK = (1u << PID_BITS) - 1u;
 

@@ -19,7 +19,7 @@ import threading
 
 import numpy as np
 
-from . import _native
+from . import _native, fastio
 
 barcodes = None       # list[str], column 0 of -sr
 barcodes_rc = None    # list[str], rev_compl of each
@@ -57,22 +57,32 @@ def read_sr_barcodes(path):
 def read_long_reads(path):
     """Column 0 -> lr_names, column 3 -> CSR bytes + offsets (reference :602-628).
 
-    A line with fewer than 4 tab-separated fields raises IndexError, as in the reference."""
+    A line with fewer than 4 tab-separated fields raises IndexError, as in the reference.  Plain-ASCII
+    files without '\r' go through the vectorised parser (fastio.parse_long_reads); anything else is read
+    line by line in text mode exactly as the reference does."""
     global lr_names, lr_segs, lr_segs_idxs
     _log("Reading long reads barcodes")
+    fast = fastio.parse_long_reads(fastio.read_file_bytes(path))
+    if fast is not None:
+        lr_names, lr_segs, lr_segs_idxs = fast
+    else:
+        lr_names, lr_segs, lr_segs_idxs = read_long_reads_plain(path)
+    _log("There are {:,} LRs".format(len(lr_names)))
+
+
+def read_long_reads_plain(path):
+    """Line-by-line reader in text mode (universal newlines, UTF-8), the reference's own procedure."""
     names, segs = [], []
     with _open_text(path) as f:
         for line in f:
             parts = line.rstrip("\n").split("\t")
             names.append(parts[0])
             segs.append(parts[3])
-    lr_names = names
     lens = np.fromiter((len(s) for s in segs), dtype=np.int64, count=len(segs))
-    lr_segs_idxs = np.zeros(len(segs) + 1, dtype=np.int64)
-    np.cumsum(lens, out=lr_segs_idxs[1:])
+    idxs = np.zeros(len(segs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=idxs[1:])
     # the reference stores ord(c) into a c_char array: a code point above 255 raises there too
-    lr_segs = np.frombuffer("".join(segs).encode("latin-1"), dtype=np.uint8)
-    _log("There are {:,} LRs".format(len(lr_names)))
+    return names, np.frombuffer("".join(segs).encode("latin-1"), dtype=np.uint8), idxs
 
 
 def set_inputs(bcs, names, segs, offs):
@@ -194,9 +204,15 @@ def match_trie(args):
     devices = getattr(args, "devices", None) or (0,)
     min_e, hit_offs, hits = run_get_matches_prefix_arrays(
         max_error=args.max_error, threads=args.threads, devices=devices, barcode_length=args.barcode_length)
+    level = getattr(args, "gzip_level", 4)
+    if isinstance(lr_names, fastio.LazyNames):
+        table = fastio.pattern_text_table(barcodes, barcodes_rc)
+        sink = args.outfile if args.outfile else sys.stdout.buffer
+        fastio.write_matches_fast(sink, lr_names, lr_segs, lr_segs_idxs, min_e, hit_offs, hits, table, gzip_level=level)
+        return
     if args.outfile:
         if args.outfile.endswith("gz"):
-            outfile = gzip.open(args.outfile, "wt", compresslevel=getattr(args, "gzip_level", 6))
+            outfile = gzip.open(args.outfile, "wt", compresslevel=level)
         else:
             outfile = open(args.outfile, "w")
     else:

@@ -1,0 +1,114 @@
+"""The vectorised reader / writer (sctagger_amd/fastio.py) against the plain line-by-line implementations
+and the reference's golden bytes.  CPU only; result arrays come from the oracle."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from oracle import trie_oracle
+from sctagger_amd import fastio, match_trie as mt, synth
+from tests import util
+
+
+@pytest.mark.parametrize("name", ["g1", "g3", "g7", "g6"])
+def test_fast_reader_equals_plain_reader(name):
+    lr = os.path.join(util.GOLDEN, name + ".lr.tsv")
+    names_p, segs_p, offs_p = mt.read_long_reads_plain(lr)
+    names_f, segs_f, offs_f = fastio.parse_long_reads(fastio.read_file_bytes(lr))
+    assert len(names_f) == len(names_p) and [names_f[i] for i in range(len(names_p))] == names_p
+    assert np.array_equal(segs_f, segs_p) and np.array_equal(offs_f, offs_p)
+    names_n, segs_n, offs_n = fastio.parse_long_reads_numpy(fastio.read_file_bytes(lr))
+    assert np.array_equal(segs_n, segs_p) and np.array_equal(offs_n, offs_p) and list(names_n) == names_p
+
+
+def test_reader_edge_cases(tmp_path):
+    assert fastio.parse_long_reads(b"r0\t1\t2\tACGT\r\n") is None                 # text mode would translate \\r\\n
+    assert fastio.parse_long_reads("ré\t1\t2\tACGT\n".encode()) is None       # non-ASCII -> plain reader
+    n, s, o = fastio.parse_long_reads(b"")
+    assert len(n) == 0 and s.size == 0 and o.tolist() == [0]
+    n, s, o = fastio.parse_long_reads(b"a\t1\t2\tAC\textra\tcols\nb\t-1\tNA\t\nc\t0\t3\tGGG")   # no final newline
+    assert [n[i] for i in range(3)] == ["a", "b", "c"] and s.tobytes() == b"ACGGG" and o.tolist() == [0, 2, 2, 5]
+    for bad in (b"a\t1\t2\n", b"a\t1\t2\tAC\n\nb\t1\t2\tAC\n", b"a\t1\t2\tAC\nb\t1\n"):
+        for fn in (fastio.parse_long_reads, fastio.parse_long_reads_numpy):
+            with pytest.raises(IndexError):
+                fn(bad)
+    # the public reader falls back transparently
+    p = tmp_path / "crlf.tsv"
+    p.write_bytes(b"r0\t1\t2\tACGT\r\nr1\t1\t2\tTT\r\n")
+    mt.read_long_reads(str(p))
+    assert list(mt.lr_names) == ["r0", "r1"] and mt.lr_segs.tobytes() == b"ACGTTT"
+    g = tmp_path / "x.tsv.gz"
+    with gzip.open(g, "wb") as f:
+        f.write(b"r0\t1\t2\tACGT\n")
+    mt.read_long_reads(str(g))
+    assert isinstance(mt.lr_names, fastio.LazyNames) and mt.lr_names[0] == "r0" and mt.lr_names[-1] == "r0"
+
+
+@pytest.mark.parametrize("case", [c for c in util.golden_cases() if c[0] in ("g1", "g3", "g6", "g7")],
+                         ids=lambda c: "%s-e%d-t%d" % (c[0], c[3], c[4]))
+def test_fast_writer_reproduces_reference_bytes(case, tmp_path):
+    name, lr, sr, e, t, bl, exp = case
+    mt.read_sr_barcodes(sr)
+    mt.read_long_reads(lr)
+    assert isinstance(mt.lr_names, fastio.LazyNames)
+    res = trie_oracle.match(util.bc_matrix(mt.barcodes, bl), mt.lr_segs, mt.lr_segs_idxs, e, threads=t)
+    table = fastio.pattern_text_table(mt.barcodes, mt.barcodes_rc)
+    with open(exp, "rb") as f:
+        want = f.read()
+    assert fastio.render_matches(mt.lr_names, mt.lr_segs, mt.lr_segs_idxs, *res, table) == want
+    assert fastio.render_matches_numpy(mt.lr_names, mt.lr_segs, mt.lr_segs_idxs, *res, table) == want
+    for out in ("o.tsv", "o.tsv.gz"):
+        path = str(tmp_path / out)
+        fastio.write_matches_fast(path, mt.lr_names, mt.lr_segs, mt.lr_segs_idxs, *res, table, rows_per_chunk=97, threads=3)
+        data = gzip.open(path, "rb").read() if out.endswith("gz") else open(path, "rb").read()
+        assert data == want
+
+
+def test_fast_writer_many_hits_and_two_digit_distances(tmp_path):
+    """Counts >= 10 and distances >= 10 (more than one digit), compared with the plain writer."""
+    bc = np.full((40, 24), ord("A"), dtype=np.uint8)
+    rng = np.random.default_rng(3)
+    for i in range(1, 40):
+        bc[i, rng.integers(0, 24, size=2)] = ord("C")
+    bcs = [b.tobytes().decode() for b in bc]
+    segs_l = ["A" * 30, "ACGT" * 7, "", "C" * 30, "AAAAAAAAAAAAAAAAAAAAAAAACCCC"]
+    lr = tmp_path / "s.tsv"
+    lr.write_text("".join("name_%d\t0\t1\t%s\n" % (i, s) for i, s in enumerate(segs_l)))
+    sr = tmp_path / "b.tsv"
+    sr.write_text("".join(b + "\t1\n" for b in bcs))
+    mt.read_sr_barcodes(str(sr))
+    mt.read_long_reads(str(lr))
+    from oracle import bruteforce
+    res = bruteforce.match(bc, mt.lr_segs, mt.lr_segs_idxs, 23)
+    assert (res[0][res[0] != 0xFF] >= 10).any() and np.diff(res[1]).max() >= 10
+    table = fastio.pattern_text_table(mt.barcodes, mt.barcodes_rc)
+    fast = fastio.render_matches(mt.lr_names, mt.lr_segs, mt.lr_segs_idxs, *res, table)
+    assert fastio.render_matches_numpy(mt.lr_names, mt.lr_segs, mt.lr_segs_idxs, *res, table) == fast
+    plain = tmp_path / "p.tsv"
+    with open(plain, "w") as f:
+        mt.write_matches(f, *res)
+    assert fast == plain.read_bytes()
+
+
+def test_ragged_copy_chunking():
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 255, size=5000, dtype=np.uint8)
+    lens = rng.integers(0, 40, size=300).astype(np.int64)
+    ss = rng.integers(0, 5000 - 40, size=300).astype(np.int64)
+    ds = np.zeros(300, dtype=np.int64)
+    ds[1:] = np.cumsum(lens)[:-1]
+    want = np.concatenate([src[a:a + l] for a, l in zip(ss, lens)])
+    for chunk in (1, 7, 64, 10**9):
+        dst = np.zeros(int(lens.sum()), dtype=np.uint8)
+        fastio.ragged_copy(dst, ds, src, ss, lens, chunk_bytes=chunk)
+        assert np.array_equal(dst, want)
+
+
+def test_empty_result_gzip_is_valid(tmp_path):
+    mt.set_inputs(["ACGTACGTACGTACGT"], [], np.empty(0, np.uint8), np.zeros(1, np.int64))
+    names = fastio.parse_long_reads(b"")[0]
+    p = str(tmp_path / "e.tsv.gz")
+    fastio.write_matches_fast(p, names, mt.lr_segs, mt.lr_segs_idxs, np.empty(0, np.uint8), np.zeros(1, np.int64),
+                              np.empty(0, np.uint32), fastio.pattern_text_table(mt.barcodes, mt.barcodes_rc))
+    assert gzip.open(p, "rb").read() == b""

@@ -54,7 +54,7 @@ def test_readers(tmp_path):
     lr = tmp_path / "s.tsv"
     lr.write_text("r0\t1\t30\tACGTAC\nr1\t-1\tNA\t\nr2\t0\t5\tTT\textra\n")
     mt.read_long_reads(str(lr))
-    assert mt.lr_names == ["r0", "r1", "r2"]
+    assert list(mt.lr_names) == ["r0", "r1", "r2"]
     assert mt.lr_segs.tobytes() == b"ACGTACTT" and mt.lr_segs_idxs.tolist() == [0, 6, 6, 8]
     bad = tmp_path / "bad.tsv"
     bad.write_text("r0\t1\t30\n")
