@@ -129,52 +129,114 @@ SCT_HD uint32_t sct_pattern_key(int f, uint32_t plo, uint32_t phi) {
     }
 }
 
-// Enumerate the lookup steps the filter makes for a text of `len` characters.  A step is (kind, t, t2):
-//   SCT_STEP_8MER   the 8-mer at t               -> families H1 (and H2 if E >= 1, MID if E >= 2)
-//   SCT_STEP_PAIR8  4-mers at t and t2 = t+8+d   -> families 02 and 13, |d| <= 1            (E >= 2)
-//   SCT_STEP_PAIR12 4-mers at t and t2 = t+12+d  -> family 03, |d| <= 2                     (E >= 2)
-// A step is valid for a text of length L iff its last character exists: t+8 <= L resp. t2+4 <= L
-// (sct_step_valid).  Kernels that walk the steps wave-uniformly pass the longest length in the wave and
-// test validity per lane; the host-side completeness test goes through the same enumeration.
-enum { SCT_STEP_8MER = 0, SCT_STEP_PAIR8 = 1, SCT_STEP_PAIR12 = 2 };
+// Seed placements.  A family F fixes which two quarters (A < B) are assumed untouched; a placement is the pair
+// of text positions (t, t2) at which those quarters are looked for:
+//   adjacent quarters (H1, MID, H2): one exact 8-mer at t (t2 = t + 4)
+//   (0,2), (1,3): t2 = t + 8 + d, |d| <= 1;   (0,3): t2 = t + 12 + d, |d| <= 2
+// A placement is valid for a text of length L iff the second quarter ends inside it: t2 + 4 <= L.
+// Kernels walk the placements wave-uniformly up to the longest length in the wave and test validity per lane;
+// the host-side completeness test (tests/host_core_check.cpp) goes through the same enumeration.
+template <int F>
+struct SctFamily {
+    static constexpr int A = F == SCT_F_H1 ? 0 : F == SCT_F_H2 ? 2 : F == SCT_F_MID ? 1 : F == SCT_F_02 ? 0 : F == SCT_F_13 ? 1 : 0;
+    static constexpr int B = F == SCT_F_H1 ? 1 : F == SCT_F_H2 ? 3 : F == SCT_F_MID ? 2 : F == SCT_F_02 ? 2 : F == SCT_F_13 ? 3 : 3;
+    static constexpr int GAP = 4 * (B - A);               // nominal distance of the two quarters in the text
+    static constexpr int SLACK = B - A - 1;               // |d| <= number of quarters in between (each holds one edit)
+    static constexpr int MIN_ERR = B - A == 1 ? (F == SCT_F_H1 ? 0 : F == SCT_F_H2 ? 1 : 2) : 2;  // smallest E that needs F
+};
 
-SCT_HD bool sct_step_valid(int kind, int t, int t2, int len) { return kind == SCT_STEP_8MER ? t + 8 <= len : t2 + 4 <= len; }
-SCT_HD uint32_t sct_step_key(int kind, uint32_t lo, uint32_t hi, int t, int t2) {
-    return kind == SCT_STEP_8MER ? sct_key8(lo, hi, t) : sct_key44(lo, hi, t, t2);
+SCT_HD bool sct_placement_valid(int t2, int len) { return t2 + 4 <= len; }
+template <int F>
+SCT_HD uint32_t sct_placement_key(uint32_t lo, uint32_t hi, int t, int t2) {
+    return SctFamily<F>::GAP == 4 ? sct_key8(lo, hi, t) : sct_key44(lo, hi, t, t2);
 }
 
-template <int E, typename F>
-SCT_HD void sct_for_each_step(int len, F &&fn) {
-    for (int t = 0; t + 8 <= len; t++) fn(SCT_STEP_8MER, t, t);
-    if (E >= 2) {
-        for (int d = -1; d <= 1; d++)
-            for (int t = 0; t + 12 + d <= len; t++) fn(SCT_STEP_PAIR8, t, t + 8 + d);
-        for (int d = -2; d <= 2; d++)
-            for (int t = 0; t + 16 + d <= len; t++) fn(SCT_STEP_PAIR12, t, t + 12 + d);
-    }
+template <int F, typename Fn>
+SCT_HD void sct_for_each_placement(int len, Fn &&fn) {
+    for (int d = -SctFamily<F>::SLACK; d <= SctFamily<F>::SLACK; d++)
+        for (int t = 0; t + SctFamily<F>::GAP + d + 4 <= len; t++) fn(t, t + SctFamily<F>::GAP + d);
 }
 
-// Every (family, key) lookup for one text (planes lo/hi): the steps above expanded into their families.
-template <int E, typename F>
+// Every (family, key) lookup for one text (planes lo/hi), family by family.
+template <int F, typename Fn>
 struct SctSeedExpand {
     uint32_t lo, hi;
-    F &fn;
-    SCT_HDM void operator()(int kind, int t, int t2) {
-        const uint32_t k = sct_step_key(kind, lo, hi, t, t2);
-        if (kind == SCT_STEP_8MER) {
-            fn(SCT_F_H1, k);
-            if (E >= 1) fn(SCT_F_H2, k);
-            if (E >= 2) fn(SCT_F_MID, k);
-        } else if (kind == SCT_STEP_PAIR8) {
-            fn(SCT_F_02, k);
-            fn(SCT_F_13, k);
-        } else {
-            fn(SCT_F_03, k);
+    Fn &fn;
+    SCT_HDM void operator()(int t, int t2) { fn(F, sct_placement_key<F>(lo, hi, t, t2)); }
+};
+template <int E, typename Fn>
+SCT_HD void sct_for_each_seed(uint32_t lo, uint32_t hi, int len, Fn &&fn) {
+    { SctSeedExpand<SCT_F_H1, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H1>(len, x); }
+    if (E >= 1) { SctSeedExpand<SCT_F_H2, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H2>(len, x); }
+    if (E >= 2) {
+        { SctSeedExpand<SCT_F_MID, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_MID>(len, x); }
+        { SctSeedExpand<SCT_F_02, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_02>(len, x); }
+        { SctSeedExpand<SCT_F_13, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_13>(len, x); }
+        { SctSeedExpand<SCT_F_03, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_03>(len, x); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Anchored verification.  A candidate found through family F at placement (t, t2) only has to be checked
+// under the hypothesis that produced it: quarter A of the barcode sits exactly at text position t and
+// quarter B exactly at t2.  (If the barcode matches the text within E edits, some optimal alignment leaves
+// two quarters untouched, that placement is enumerated, and the hypothesis holds for it; under any
+// hypothesis the value computed below is the cost of a real alignment, hence >= the true distance.  So the
+// minimum over all enumerated placements whose key matches is the true distance whenever that is <= E.)
+// Only the 8 characters outside the two quarters are run through the Wu-Manber automaton:
+//   left   characters before quarter A: free start, must arrive exactly at t
+//   middle characters between the quarters: from t+4 exactly to t2
+//   right  characters after quarter B: from t2+4, free end
+// em(c) returns the match mask of character code c (bit i+1 set iff text[i] == c, bits 1..len);
+// code holds the barcode as 2-bit codes, character j at bits 2j..2j+1; va = bits 0..len.
+// ---------------------------------------------------------------------------------------------------
+template <int E>
+struct WmState {
+    uint32_t R0, R1, R2;
+    SCT_HDM void set(uint32_t v) { R0 = R1 = R2 = v; }
+    SCT_HDM void step(uint32_t Em) {
+        const uint32_t s0 = R0 << 1;
+        const uint32_t n0 = s0 & Em;
+        if (E >= 1) {
+            const uint32_t s1 = R1 << 1;
+            const uint32_t n1 = (s1 & Em) | s0 | R0 | (n0 << 1);
+            if (E >= 2) {
+                const uint32_t s2 = R2 << 1;
+                R2 = (s2 & Em) | s1 | R1 | (n1 << 1);
+            }
+            R1 = n1;
         }
+        R0 = n0;
+    }
+    // keep only the states that sit exactly at position `at`, then skip `skip` exactly matched characters;
+    // text characters inserted right after them are accounted for by re-closing under insertion
+    SCT_HDM void anchor(int at, int skip) {
+        const uint32_t m = 1u << at;
+        R0 = (R0 & m) << skip;
+        if (E >= 1) R1 = ((R1 & m) << skip) | (R0 << 1);
+        if (E >= 2) R2 = ((R2 & m) << skip) | (R1 << 1);
+    }
+    SCT_HDM int result(uint32_t va) const {
+        if (R0 & va) return 0;
+        if (E >= 1 && (R1 & va)) return 1;
+        if (E >= 2 && (R2 & va)) return 2;
+        return E + 1;
     }
 };
-template <int E, typename F>
-SCT_HD void sct_for_each_seed(uint32_t lo, uint32_t hi, int len, F &&fn) {
-    SctSeedExpand<E, F> x{lo, hi, fn};
-    sct_for_each_step<E>(len, x);
+
+template <int E, int F, typename EmFetch>
+SCT_HD int wm_anchored(EmFetch &&em, uint32_t va, uint32_t code, int t, int t2) {
+    constexpr int A = SctFamily<F>::A, B = SctFamily<F>::B;
+    WmState<E> s;
+    s.set(A == 0 ? (1u << t) : va);
+    for (int j = 0; j < 4 * A; j++) s.step(em((code >> (2 * j)) & 3u));
+    if (B == A + 1) {
+        s.anchor(t, 8);
+    } else {
+        s.anchor(t, 4);
+        for (int j = 4 * (A + 1); j < 4 * B; j++) s.step(em((code >> (2 * j)) & 3u));
+        s.anchor(t2, 4);
+    }
+    for (int j = 4 * (B + 1); j < 16; j++) s.step(em((code >> (2 * j)) & 3u));
+    return s.result(va);
 }

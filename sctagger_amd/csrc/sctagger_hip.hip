@@ -230,15 +230,18 @@ k_filter_lane(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ h
 
 // ------------------------------------------------------------------------------------------------------------
 // k_filter<E> (default): one WAVE per 64 segments, cooperating through LDS so that verification always runs on
-// full waves.
-//   lookup   every lane computes the seed key of its own segment for the current step (the steps are walked
-//            wave-uniformly up to the longest segment of the wave) and reads its bucket range;
-//   push     round by round, every lane that still has a candidate appends (lane, pattern id) to the wave's
-//            queue in LDS (position = tail + mbcnt(ballot));
-//   drain    whenever 64 candidates are queued, lane i takes entry head+i: fetches that segment's planes from
-//            LDS and the pattern from L2, runs the transposed Wu-Manber automaton, and on a match (d <= E)
-//            appends (d, pid) to the owning segment's list in LDS (LDS atomic counter);
-//   finish   every lane folds its own list into (minimum, distinct pattern ids), sorts and stores.
+// full waves.  The seed families are processed one after the other; within a family
+//   lookup   every lane computes the seed key of its own segment for the current placement (t, t2) — the
+//            placements are walked wave-uniformly up to the longest segment of the wave — and reads its bucket
+//            range; the loads are issued one placement ahead of the queue work that consumes them;
+//   push     round by round, every lane that still has a candidate appends (table entry, lane, t, t2) to the
+//            wave's queue in LDS (position = tail + mbcnt(ballot));
+//   drain    whenever 64 candidates are queued, lane i takes entry head+i: reads the barcode's 2-bit codes from
+//            the table (L2), runs the ANCHORED Wu-Manber automaton of this family (8 of the 16 barcode
+//            characters, sct_core.h) against the owning segment's match masks in LDS, and on d <= E appends
+//            (d, pattern id) to that segment's list in LDS (LDS atomic counter);
+//   finish   (after the last family) every lane folds its own list into (minimum, distinct pattern ids), sorts
+//            and stores.
 // A segment with more than HMAX verified matches (duplicates included) or more than K_SLOTS ties is deferred.
 // All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
 // needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
@@ -253,12 +256,18 @@ struct FilterWaveLds {
     uint32_t va[64];     // bits 0..len
     uint32_t hcnt[64];
     uint32_t hlist[HMAX][64];
-    uint32_t q[QCAP];
+    uint32_t qk[QCAP];   // queue: global table entry index f*np + k
+    uint32_t qm[QCAP];   //        lane | t << 8 | t2 << 16
 };
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t m) {  // number of set bits of m below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+
+struct EmLds {
+    const uint32_t *base;  // &em[0][segment lane]
+    __device__ __forceinline__ uint32_t operator()(uint32_t c) const { return base[c * 64]; }
+};
 
 template <int E>
 struct FilterWave {
@@ -272,44 +281,19 @@ struct FilterWave {
     int len;
     uint32_t lo, hi;
     uint32_t head = 0, tail = 0;  // wave-uniform
-    // bucket ranges of the step whose offsets were loaded last (global entry indices f*np + k); they are pushed
-    // when the NEXT step arrives, so that the offset loads of a step overlap the queue work of the one before
-    int pend_kind = -1;
-    uint32_t ps0 = 0, pe0 = 0, ps1 = 0, pe1 = 0, ps2 = 0, pe2 = 0;
+    // bucket range of the placement whose offsets were loaded last; pushed when the NEXT placement arrives, so
+    // that the offset loads of a placement overlap the queue work of the one before
+    bool pend = false;  // wave-uniform
+    uint32_t ps = 0, pe = 0, pmeta = 0;
 
-    // transposed Wu-Manber automaton (wm_verify of sct_core.h) with the per-character match masks read from LDS:
-    // code = the barcode as 2-bit codes, character j at bits 2j..2j+1
-    __device__ __forceinline__ int automaton(uint32_t src, uint32_t code) {
-        const uint32_t va = L.va[src];
-        const uint32_t *em = &L.em[0][src];
-        uint32_t R0 = va, R1 = va, R2 = va;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t Em = em[((code >> (2 * j)) & 3u) * 64];
-            const uint32_t s0 = R0 << 1;
-            const uint32_t n0 = s0 & Em;
-            if (E >= 1) {
-                const uint32_t s1 = R1 << 1;
-                const uint32_t n1 = (s1 & Em) | s0 | R0 | (n0 << 1);
-                if (E >= 2) {
-                    const uint32_t s2 = R2 << 1;
-                    R2 = (s2 & Em) | s1 | R1 | (n1 << 1);
-                }
-                R1 = n1;
-            }
-            R0 = n0;
-        }
-        if (R0 & va) return 0;
-        if (E >= 1 && (R1 & va)) return 1;
-        if (E >= 2 && (R2 & va)) return 2;
-        return E + 1;
-    }
-
+    template <int F>
     __device__ __forceinline__ void verify(bool take) {
         if (take) {
-            const uint32_t item = L.q[(head + lane) & (QCAP - 1)];
-            const uint32_t src = item >> PID_BITS, gk = item & PID_MASK;
-            const int d = automaton(src, tab_code[gk]);
+            const uint32_t idx = (head + lane) & (QCAP - 1);
+            const uint32_t gk = L.qk[idx], meta = L.qm[idx];
+            const uint32_t src = meta & 63u;
+            const int t = (int)((meta >> 8) & 31u), t2 = (int)((meta >> 16) & 31u);
+            const int d = wm_anchored<E, F>(EmLds{&L.em[0][src]}, L.va[src], tab_code[gk], t, t2);
             if (d <= E) {
                 const uint32_t pid = tab_ent[gk];
                 const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
@@ -320,63 +304,64 @@ struct FilterWave {
     }
 
     // append the entry indices [s, e) for every lane, one per lane and round, draining full batches as they form
-    __device__ __forceinline__ void push_range(uint32_t s, uint32_t e) {
+    template <int F>
+    __device__ __forceinline__ void push_range(uint32_t s, uint32_t e, uint32_t meta) {
         uint32_t c = e - s;
         for (;;) {
             const bool has = c > 0;
             const uint64_t m = __ballot(has);
             if (m == 0) break;
             if (has) {
-                L.q[(tail + lane_rank(m)) & (QCAP - 1)] = ((uint32_t)lane << PID_BITS) | s;
+                const uint32_t idx = (tail + lane_rank(m)) & (QCAP - 1);
+                L.qk[idx] = s;
+                L.qm[idx] = meta;
                 s++;
                 c--;
             }
             tail += (uint32_t)__popcll(m);
             __builtin_amdgcn_wave_barrier();
             if (tail - head >= 64) {
-                verify(true);
+                verify<F>(true);
                 head += 64;
             }
         }
     }
 
+    template <int F>
     __device__ __forceinline__ void flush_pending() {
-        if (pend_kind < 0) return;
-        push_range(ps0, pe0);
-        if (pend_kind == SCT_STEP_8MER) {
-            if (E >= 1) push_range(ps1, pe1);
-            if (E >= 2) push_range(ps2, pe2);
-        } else if (pend_kind == SCT_STEP_PAIR8) {
-            push_range(ps1, pe1);
-        }
-        pend_kind = -1;
+        if (!pend) return;
+        push_range<F>(ps, pe, pmeta);
+        pend = false;
     }
 
-    __device__ __forceinline__ void operator()(int kind, int t, int t2) {
-        // 1. issue this step's offset loads
-        const bool v = active && sct_step_valid(kind, t, t2, len);
-        const uint32_t key = sct_step_key(kind, lo, hi, t, t2);
-        uint32_t s0 = 0, e0 = 0, s1 = 0, e1 = 0, s2 = 0, e2 = 0;
-        const int f0 = kind == SCT_STEP_8MER ? SCT_F_H1 : kind == SCT_STEP_PAIR8 ? SCT_F_02 : SCT_F_03;
-        const int f1 = kind == SCT_STEP_8MER ? SCT_F_H2 : SCT_F_13;
-        if (v) {
-            const uint32_t *o = tab_off + key;
-            s0 = o[(size_t)f0 * (SCT_KEYS + 1)] + (uint32_t)f0 * (uint32_t)np;
-            e0 = o[(size_t)f0 * (SCT_KEYS + 1) + 1] + (uint32_t)f0 * (uint32_t)np;
-            if ((kind == SCT_STEP_8MER && E >= 1) || kind == SCT_STEP_PAIR8) {
-                s1 = o[(size_t)f1 * (SCT_KEYS + 1)] + (uint32_t)f1 * (uint32_t)np;
-                e1 = o[(size_t)f1 * (SCT_KEYS + 1) + 1] + (uint32_t)f1 * (uint32_t)np;
+    template <int F>
+    struct Place {
+        FilterWave &w;
+        __device__ __forceinline__ void operator()(int t, int t2) {
+            const bool v = w.active && sct_placement_valid(t2, w.len);
+            uint32_t s = 0, e = 0;
+            if (v) {
+                const uint32_t *o = w.tab_off + (size_t)F * (SCT_KEYS + 1) + sct_placement_key<F>(w.lo, w.hi, t, t2);
+                s = o[0] + (uint32_t)F * (uint32_t)w.np;
+                e = o[1] + (uint32_t)F * (uint32_t)w.np;
             }
-            if (kind == SCT_STEP_8MER && E >= 2) {
-                s2 = o[(size_t)SCT_F_MID * (SCT_KEYS + 1)] + (uint32_t)SCT_F_MID * (uint32_t)np;
-                e2 = o[(size_t)SCT_F_MID * (SCT_KEYS + 1) + 1] + (uint32_t)SCT_F_MID * (uint32_t)np;
-            }
+            w.template flush_pending<F>();  // queue the previous placement's bucket while those loads are in flight
+            w.pend = true;
+            w.ps = s;
+            w.pe = e;
+            w.pmeta = (uint32_t)w.lane | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
         }
-        // 2. queue the previous step's buckets while those loads are in flight
-        flush_pending();
-        // 3. this step becomes the pending one
-        pend_kind = kind;
-        ps0 = s0; pe0 = e0; ps1 = s1; pe1 = e1; ps2 = s2; pe2 = e2;
+    };
+
+    template <int F>
+    __device__ __forceinline__ void run_family(int maxlen) {
+        Place<F> pl{*this};
+        sct_for_each_placement<F>(maxlen, pl);
+        flush_pending<F>();
+        if (tail != head) {  // the family's last, partial batch
+            verify<F>((uint32_t)lane < tail - head);
+            head = tail;
+        }
     }
 };
 
@@ -419,11 +404,13 @@ k_filter(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in,
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     FilterWave<E> W{L, tab_off, tab_ent, tab_code, np, lane, active, len, lo, hi};
-    sct_for_each_step<E>(maxlen, W);
-    W.flush_pending();
-    if (W.tail != W.head) {
-        W.verify((uint32_t)lane < W.tail - W.head);
-        W.head = W.tail;
+    W.template run_family<SCT_F_H1>(maxlen);
+    if (E >= 1) W.template run_family<SCT_F_H2>(maxlen);
+    if (E >= 2) {
+        W.template run_family<SCT_F_MID>(maxlen);
+        W.template run_family<SCT_F_02>(maxlen);
+        W.template run_family<SCT_F_13>(maxlen);
+        W.template run_family<SCT_F_03>(maxlen);
     }
     if (!active) return;
     const uint32_t nc = L.hcnt[lane];

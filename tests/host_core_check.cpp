@@ -58,6 +58,53 @@ static int wm(const std::vector<int> &p, const std::vector<int> &t) {
     return wm_verify<E>((uint32_t)tlo << 1, (uint32_t)thi << 1, ve, va, (uint32_t)plo, (uint32_t)phi, (int)p.size());
 }
 
+// minimum anchored distance over every enumerated placement whose key equals the pattern's key of that family
+struct EmArray {
+    uint32_t m[4];
+    uint32_t operator()(uint32_t c) const { return m[c]; }
+};
+template <int E, int F>
+struct AnchoredMin {
+    uint32_t tlo, thi, pkey, va, code;
+    EmArray em;
+    int best;
+    void operator()(int t, int t2) {
+        if (sct_placement_key<F>(tlo, thi, t, t2) != pkey) return;
+        const int d = wm_anchored<E, F>(em, va, code, t, t2);
+        if (d < best) best = d;
+    }
+};
+template <int E, int F>
+static int anchored_family(const std::vector<int> &p, const std::vector<int> &t) {
+    uint64_t plo, phi, tlo, thi;
+    planes(p, plo, phi);
+    planes(t, tlo, thi);
+    const int L = (int)t.size();
+    AnchoredMin<E, F> am;
+    am.tlo = (uint32_t)tlo; am.thi = (uint32_t)thi;
+    am.pkey = sct_pattern_key(F, (uint32_t)plo, (uint32_t)phi);
+    am.va = L >= 31 ? 0xFFFFFFFFu : ((1u << (L + 1)) - 1u);
+    const uint32_t ve = am.va & ~1u, l1 = (uint32_t)tlo << 1, h1 = (uint32_t)thi << 1;
+    am.em.m[0] = ~l1 & ~h1 & ve; am.em.m[1] = l1 & ~h1 & ve; am.em.m[2] = ~l1 & h1 & ve; am.em.m[3] = l1 & h1 & ve;
+    am.code = 0;
+    for (int j = 0; j < 16; j++) am.code |= (uint32_t)p[j] << (2 * j);
+    am.best = E + 1;
+    sct_for_each_placement<F>(L, am);
+    return am.best;
+}
+template <int E>
+static int anchored(const std::vector<int> &p, const std::vector<int> &t) {
+    int b = anchored_family<E, SCT_F_H1>(p, t);
+    if (E >= 1) b = std::min(b, anchored_family<E, SCT_F_H2>(p, t));
+    if (E >= 2) {
+        b = std::min(b, anchored_family<E, SCT_F_MID>(p, t));
+        b = std::min(b, anchored_family<E, SCT_F_02>(p, t));
+        b = std::min(b, anchored_family<E, SCT_F_13>(p, t));
+        b = std::min(b, anchored_family<E, SCT_F_03>(p, t));
+    }
+    return b;
+}
+
 struct SeedHit {
     const uint32_t *keys;  // the pattern's six family keys
     bool hit = false;
@@ -126,6 +173,9 @@ int main() {
         if (wm<0>(p, t) != std::min(want, 1)) { printf("FAIL wm0\n"); return 1; }
         if (wm<1>(p, t) != std::min(want, 2)) { printf("FAIL wm1\n"); return 1; }
         if (wm<2>(p, t) != std::min(want, 3)) { printf("FAIL wm2 want=%d got=%d n=%zu\n", want, wm<2>(p, t), t.size()); return 1; }
+        if (anchored<0>(p, t) != std::min(want, 1)) { printf("FAIL anchored0 want=%d got=%d\n", want, anchored<0>(p, t)); return 1; }
+        if (anchored<1>(p, t) != std::min(want, 2)) { printf("FAIL anchored1 want=%d got=%d\n", want, anchored<1>(p, t)); return 1; }
+        if (anchored<2>(p, t) != std::min(want, 3)) { printf("FAIL anchored2 want=%d got=%d n=%zu\n", want, anchored<2>(p, t), t.size()); return 1; }
         if (want <= 0 && !seeds_cover<0>(p, t)) { printf("FAIL seeds0\n"); return 1; }
         if (want <= 1 && !seeds_cover<1>(p, t)) { printf("FAIL seeds1\n"); return 1; }
         if (want <= 2 && !seeds_cover<2>(p, t)) { printf("FAIL seeds2 want=%d\n", want); return 1; }
@@ -158,11 +208,13 @@ int main() {
                 t.insert(t.end(), s.begin(), s.end());
                 for (int i = 0; i < 3; i++) t.push_back(rnd(4));
                 const int want = brute_infix(p, t);
+                const int w2 = brute_infix(p, s);  // the bare edited string with nothing around it
                 if (want <= 2 && !seeds_cover<2>(p, t)) { printf("FAIL seeds2 exhaustive\n"); return 1; }
                 if (want <= 1 && !seeds_cover<1>(p, t)) { printf("FAIL seeds1 exhaustive\n"); return 1; }
                 if (wm<2>(p, t) != std::min(want, 3)) { printf("FAIL wm2 exhaustive\n"); return 1; }
-                // and the bare edited string with nothing around it
-                const int w2 = brute_infix(p, s);
+                if (anchored<2>(p, t) != std::min(want, 3)) { printf("FAIL anchored2 exhaustive\n"); return 1; }
+                if (anchored<1>(p, t) != std::min(want, 2)) { printf("FAIL anchored1 exhaustive\n"); return 1; }
+                if (s.size() <= 31 && anchored<2>(p, s) != std::min(w2 <= 2 ? w2 : 3, 3)) { printf("FAIL anchored2 bare\n"); return 1; }
                 if (s.size() <= 31 && w2 <= 2 && !seeds_cover<2>(p, s)) { printf("FAIL seeds2 bare\n"); return 1; }
                 n_texts++;
             }
