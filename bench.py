@@ -32,6 +32,19 @@ WORKLOADS = {
     "cfg3": (10_000_000, 25_000, 16, 2),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# Non-packed 32-bit integer VALU ops issue one wave64 instruction per 4 cycles per SIMD (SQ_ACTIVE_INST_VALU counts
+# one quad-cycle per instruction; SURVEY.md §7: 256 CU x 64 lanes x 2.4 GHz = 3.9e13 lane-ops/s):
+VALU_PEAK_WINST_S = 256 * 4 * 2.4e9 / 4
+
+
+def pmc_quote(workload_desc):
+    """Per-launch counters of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if they
+    were taken on this workload.  bench.py cannot collect PMC counters itself; it only quotes them."""
+    path = os.path.join(ROOT, "profiles", "k_filter_counters.json")
+    if not os.path.exists(path):
+        return None
+    q = json.load(open(path))
+    return q if q.get("workload") == workload_desc else None
 
 
 def make_batch(n, bc, seed, chunk=1_000_000):
@@ -131,14 +144,26 @@ def main():
                     # the binding resource is integer VALU issue, not HBM: all-pairs DP cells credited
                     "dp_cells_per_segment": int(synth_seg_len(offs) * bl * n_bc * 2),
                     "gcups_equivalent": round(n_seg * synth_seg_len(offs) * bl * n_bc * 2 / (avg[dominant] * 1e-3) / 1e9, 1)}
+        workload_desc = "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, 22-bp segments (SURVEY 8(d))" % (
+            args.workload, n_seg, n_bc, bl, max_err)
+        q = pmc_quote(workload_desc) if (roof and not args.force_exhaustive and args.filter_mode == 0) else None
+        if q:
+            rd = q.get("hbm_read_bytes_x2_gfx950") or 0
+            roof["traffic"] = int(rd + (q.get("hbm_write_bytes") or 0))
+            roof["traffic_source"] = q["source"] + "; FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as read"
+            if q.get("valu_insts_per_launch"):
+                w = q["valu_insts_per_launch"] / (avg[dominant] * 1e-3)
+                roof["valu"] = {"insts_per_segment": round(q["valu_insts_per_launch"] / q["segments_per_launch"], 1),
+                                "achieved_wave_insts_per_s": w, "peak_wave_insts_per_s": VALU_PEAK_WINST_S,
+                                "frac": round(w / VALU_PEAK_WINST_S, 3),
+                                "note": "instruction count from the PMC pass, duration measured live; this is the binding resource"}
         out = {
             "metric": "LR segments matched/sec (whole node), 25k barcodes e<=2" if args.workload == "cfg3"
                       else "LR segments matched/sec (whole node)",
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, 22-bp segments (SURVEY 8(d))" % (
-                args.workload, n_seg, n_bc, bl, max_err), "segments_per_gpu": n_seg, "barcodes": n_bc, "max_err": max_err,
+            "config": {"workload": workload_desc, "segments_per_gpu": n_seg, "barcodes": n_bc, "max_err": max_err,
                 "path": "exhaustive" if args.force_exhaustive else "seed-filter", "paths": m.last_stats()},
             "hits_per_segment": round(h, 4),
             "kernels_ms": {k: round(v, 4) for k, v in avg.items()},

@@ -43,6 +43,19 @@ def main():
         out[k] = d
     with open("profiles/%s_pmc_summary.json" % tag, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
+    # the dominant kernel's per-launch counters in the form bench.py quotes (roofline.traffic / roofline.valu)
+    dom = [k for k in out if k.startswith("k_filter<")]
+    if dom and os.path.exists(bench):
+        b = json.load(open(bench))
+        d, c = out[dom[0]], out[dom[0]]["counters_avg_per_launch"]
+        quote = {"source": "rocprofv3 --pmc passes of tools/profile.sh, tag %s (profiles/%s_pmc_summary.json)" % (tag, tag),
+                 "kernel": dom[0], "workload": b["config"]["workload"], "segments_per_launch": b["config"]["segments_per_gpu"],
+                 "hbm_read_bytes_raw": d.get("hbm_read_bytes_raw"), "hbm_read_bytes_x2_gfx950": d.get("hbm_read_bytes_x2_gfx950"),
+                 "hbm_write_bytes": d.get("hbm_write_bytes"), "l2_hit_rate": d.get("l2_hit_rate"),
+                 "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
+                 "lds_insts_per_launch": c.get("SQ_INSTS_LDS"), "vmem_rd_insts_per_launch": c.get("SQ_INSTS_VMEM_RD")}
+        with open("profiles/k_filter_counters.json", "w") as f:
+            json.dump(quote, f, indent=1)
     print(json.dumps({k: v for k, v in out.items() if "filter" in k}, indent=1))
 
 
