@@ -109,12 +109,15 @@ SCT_HD int wm_verify(uint32_t tls, uint32_t ths, uint32_t ve, uint32_t va, uint3
 enum { SCT_F_H1 = 0, SCT_F_H2 = 1, SCT_F_MID = 2, SCT_F_02 = 3, SCT_F_13 = 4, SCT_F_03 = 5, SCT_NFAM = 6 };
 #define SCT_KEYS 65536
 
-SCT_HD uint32_t sct_key8(uint32_t lo, uint32_t hi, int t) {  // 8 consecutive characters starting at t
-    return ((lo >> t) & 0xFFu) | (((hi >> t) & 0xFFu) << 8);
+// W = uint32_t (texts up to 31 characters) or uint64_t (up to 63)
+template <typename W>
+SCT_HD uint32_t sct_key8(W lo, W hi, int t) {  // 8 consecutive characters starting at t
+    return ((uint32_t)(lo >> t) & 0xFFu) | (((uint32_t)(hi >> t) & 0xFFu) << 8);
 }
-SCT_HD uint32_t sct_key44(uint32_t lo, uint32_t hi, int t, int t2) {  // 4 characters at t and 4 at t2
-    const uint32_t l = ((lo >> t) & 0xFu) | (((lo >> t2) & 0xFu) << 4);
-    const uint32_t h = ((hi >> t) & 0xFu) | (((hi >> t2) & 0xFu) << 4);
+template <typename W>
+SCT_HD uint32_t sct_key44(W lo, W hi, int t, int t2) {  // 4 characters at t and 4 at t2
+    const uint32_t l = ((uint32_t)(lo >> t) & 0xFu) | (((uint32_t)(lo >> t2) & 0xFu) << 4);
+    const uint32_t h = ((uint32_t)(hi >> t) & 0xFu) | (((uint32_t)(hi >> t2) & 0xFu) << 4);
     return l | (h << 8);
 }
 // key of a 16-character barcode for family f
@@ -146,8 +149,8 @@ struct SctFamily {
 };
 
 SCT_HD bool sct_placement_valid(int t2, int len) { return t2 + 4 <= len; }
-template <int F>
-SCT_HD uint32_t sct_placement_key(uint32_t lo, uint32_t hi, int t, int t2) {
+template <int F, typename W>
+SCT_HD uint32_t sct_placement_key(W lo, W hi, int t, int t2) {
     return SctFamily<F>::GAP == 4 ? sct_key8(lo, hi, t) : sct_key44(lo, hi, t, t2);
 }
 
@@ -158,21 +161,21 @@ SCT_HD void sct_for_each_placement(int len, Fn &&fn) {
 }
 
 // Every (family, key) lookup for one text (planes lo/hi), family by family.
-template <int F, typename Fn>
+template <int F, typename W, typename Fn>
 struct SctSeedExpand {
-    uint32_t lo, hi;
+    W lo, hi;
     Fn &fn;
-    SCT_HDM void operator()(int t, int t2) { fn(F, sct_placement_key<F>(lo, hi, t, t2)); }
+    SCT_HDM void operator()(int t, int t2) { fn(F, sct_placement_key<F, W>(lo, hi, t, t2)); }
 };
-template <int E, typename Fn>
-SCT_HD void sct_for_each_seed(uint32_t lo, uint32_t hi, int len, Fn &&fn) {
-    { SctSeedExpand<SCT_F_H1, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H1>(len, x); }
-    if (E >= 1) { SctSeedExpand<SCT_F_H2, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H2>(len, x); }
+template <int E, typename W, typename Fn>
+SCT_HD void sct_for_each_seed(W lo, W hi, int len, Fn &&fn) {
+    { SctSeedExpand<SCT_F_H1, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H1>(len, x); }
+    if (E >= 1) { SctSeedExpand<SCT_F_H2, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H2>(len, x); }
     if (E >= 2) {
-        { SctSeedExpand<SCT_F_MID, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_MID>(len, x); }
-        { SctSeedExpand<SCT_F_02, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_02>(len, x); }
-        { SctSeedExpand<SCT_F_13, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_13>(len, x); }
-        { SctSeedExpand<SCT_F_03, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_03>(len, x); }
+        { SctSeedExpand<SCT_F_MID, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_MID>(len, x); }
+        { SctSeedExpand<SCT_F_02, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_02>(len, x); }
+        { SctSeedExpand<SCT_F_13, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_13>(len, x); }
+        { SctSeedExpand<SCT_F_03, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_03>(len, x); }
     }
 }
 
@@ -190,18 +193,18 @@ SCT_HD void sct_for_each_seed(uint32_t lo, uint32_t hi, int len, Fn &&fn) {
 // em(c) returns the match mask of character code c (bit i+1 set iff text[i] == c, bits 1..len);
 // code holds the barcode as 2-bit codes, character j at bits 2j..2j+1; va = bits 0..len.
 // ---------------------------------------------------------------------------------------------------
-template <int E>
+template <int E, typename W>
 struct WmState {
-    uint32_t R0, R1, R2;
-    SCT_HDM void set(uint32_t v) { R0 = R1 = R2 = v; }
-    SCT_HDM void step(uint32_t Em) {
-        const uint32_t s0 = R0 << 1;
-        const uint32_t n0 = s0 & Em;
+    W R0, R1, R2;
+    SCT_HDM void set(W v) { R0 = R1 = R2 = v; }
+    SCT_HDM void step(W Em) {
+        const W s0 = R0 << 1;
+        const W n0 = s0 & Em;
         if (E >= 1) {
-            const uint32_t s1 = R1 << 1;
-            const uint32_t n1 = (s1 & Em) | s0 | R0 | (n0 << 1);
+            const W s1 = R1 << 1;
+            const W n1 = (s1 & Em) | s0 | R0 | (n0 << 1);
             if (E >= 2) {
-                const uint32_t s2 = R2 << 1;
+                const W s2 = R2 << 1;
                 R2 = (s2 & Em) | s1 | R1 | (n1 << 1);
             }
             R1 = n1;
@@ -211,12 +214,12 @@ struct WmState {
     // keep only the states that sit exactly at position `at`, then skip `skip` exactly matched characters;
     // text characters inserted right after them are accounted for by re-closing under insertion
     SCT_HDM void anchor(int at, int skip) {
-        const uint32_t m = 1u << at;
+        const W m = (W)1 << at;
         R0 = (R0 & m) << skip;
         if (E >= 1) R1 = ((R1 & m) << skip) | (R0 << 1);
         if (E >= 2) R2 = ((R2 & m) << skip) | (R1 << 1);
     }
-    SCT_HDM int result(uint32_t va) const {
+    SCT_HDM int result(W va) const {
         if (R0 & va) return 0;
         if (E >= 1 && (R1 & va)) return 1;
         if (E >= 2 && (R2 & va)) return 2;
@@ -224,11 +227,17 @@ struct WmState {
     }
 };
 
-template <int E, int F, typename EmFetch>
-SCT_HD int wm_anchored(EmFetch &&em, uint32_t va, uint32_t code, int t, int t2) {
+// bits 0..len of a W (positions that exist in a text of `len` characters)
+template <typename W>
+SCT_HD W sct_valid_mask(int len) {
+    return len >= (int)(8 * sizeof(W)) - 1 ? ~(W)0 : (((W)1 << (len + 1)) - 1);
+}
+
+template <int E, int F, typename W, typename EmFetch>
+SCT_HD int wm_anchored(EmFetch &&em, W va, uint32_t code, int t, int t2) {
     constexpr int A = SctFamily<F>::A, B = SctFamily<F>::B;
-    WmState<E> s;
-    s.set(A == 0 ? (1u << t) : va);
+    WmState<E, W> s;
+    s.set(A == 0 ? ((W)1 << t) : va);
     for (int j = 0; j < 4 * A; j++) s.step(em((code >> (2 * j)) & 3u));
     if (B == A + 1) {
         s.anchor(t, 8);

@@ -55,37 +55,58 @@ static int fail(int code, const char *fmt, ...) {
 static constexpr int K_SLOTS = 8;          // hits kept per segment by the filter kernel before it defers
 static constexpr uint32_t CNT_DEFER = 0xFFFFFFFFu;
 static constexpr int META_NONACGT = 1 << 8;
-static constexpr int META_LONG = 1 << 9;   // more than 31 characters: not representable in the filter's planes
+static constexpr int META_LONG = 1 << 9;   // more than 63 characters: not representable in the filter's planes
+static constexpr int PLANE_MAX = 63;       // characters kept in the packed bit-planes
 
 // ------------------------------------------------------------------------------------------------------------
-// k_pack: one lane per segment. ASCII -> bit-planes of the first 31 characters, flags, and routing.
+// k_pack: one lane per segment. ASCII -> bit-planes of the first 63 characters, flags, and routing.
 //   route 0: filter path; route 1: exhaustive Myers scan; route 2: restricted-start DP scan
 // Segments shorter than bl - max_err cannot match anything (every window the reference inserts is at least
 // that long, scTagger.py:681) and are finished here.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void k_pack(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, int64_t n, int bl,
-                       int max_err, int prefix_len, int filter_ok, uint32_t *__restrict__ lo_out,
-                       uint32_t *__restrict__ hi_out, uint32_t *__restrict__ meta_out, uint8_t *__restrict__ min_e,
+                       int max_err, int prefix_len, int filter_maxlen, uint64_t *__restrict__ lo_out,
+                       uint64_t *__restrict__ hi_out, uint32_t *__restrict__ meta_out, uint8_t *__restrict__ min_e,
                        uint32_t *__restrict__ cnt, int32_t *__restrict__ list_scan, int32_t *__restrict__ list_dp,
                        uint32_t *__restrict__ counters) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const int64_t b0 = offs[r];
     const int64_t len = offs[r + 1] - b0;
-    uint32_t lo = 0, hi = 0;
+    // The segment's bytes are fetched as the aligned 32-bit words that cover them (neighbouring lanes read
+    // neighbouring words, so the loads coalesce; the buffer is padded past its end).  Per byte: valid = one of
+    // A C G T (bit test on b & 31 for b in 0x40..0x5F), code = ((b >> 1) ^ (b >> 2)) & 3 for those, else 0.
+    uint32_t lo0 = 0, lo1 = 0, hi0 = 0, hi1 = 0;  // planes of characters 0..31 and 32..62
     bool nonacgt = false;
-    const int head = len < 31 ? (int)len : 31;
-    for (int i = 0; i < head; i++) {
-        const uint8_t b = segs[b0 + i];
-        const uint32_t c = sct_code(b);
-        lo |= (c & 1u) << i;
-        hi |= (c >> 1) << i;
-        nonacgt |= !sct_is_acgt(b);
+    const uint32_t *wp = reinterpret_cast<const uint32_t *>(segs) + (b0 >> 2);
+    const int skip = (int)(b0 & 3);
+    const int nbytes = (int)(len < (1 << 20) ? len : (1 << 20)) + skip;  // bytes from the first word's start
+    constexpr uint32_t ACGT_SET = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20);
+    for (int k = 0; k * 4 < nbytes; k++) {
+        const uint32_t w = wp[k];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = k * 4 + j - skip;  // character index
+            if (i >= 0 && i < (int)len) {
+                const uint32_t b = (w >> (8 * j)) & 0xFFu;
+                const bool ok = (b >> 5) == 2u && ((ACGT_SET >> (b & 31u)) & 1u);
+                const uint32_t c = ok ? ((b >> 1) ^ (b >> 2)) & 3u : 0u;
+                nonacgt |= !ok;
+                if (i < 32) {
+                    lo0 |= (c & 1u) << i;
+                    hi0 |= (c >> 1) << i;
+                } else if (i < PLANE_MAX) {
+                    lo1 |= (c & 1u) << (i - 32);
+                    hi1 |= (c >> 1) << (i - 32);
+                }
+            }
+        }
     }
-    for (int64_t i = head; i < len; i++) nonacgt |= !sct_is_acgt(segs[b0 + i]);
+    for (int64_t i = (1 << 20); i < len; i++) nonacgt |= !sct_is_acgt(segs[b0 + i]);  // absurdly long rows
+    const uint64_t lo = lo0 | ((uint64_t)lo1 << 32), hi = hi0 | ((uint64_t)hi1 << 32);
     uint32_t meta = (uint32_t)(len < 255 ? len : 255);
     if (nonacgt) meta |= META_NONACGT;
-    if (len > 31) meta |= META_LONG;
+    if (len > PLANE_MAX) meta |= META_LONG;
     lo_out[r] = lo;
     hi_out[r] = hi;
     meta_out[r] = meta;
@@ -98,7 +119,7 @@ __global__ void k_pack(const uint8_t *__restrict__ segs, const int64_t *__restri
         const uint32_t k = atomicAdd(&counters[1], 1u);
         list_dp[k] = (int32_t)r;
         cnt[r] = CNT_DEFER;
-    } else if (!filter_ok || len > 31) {
+    } else if (len > filter_maxlen) {  // filter_maxlen: 0 = no filter path, 31 = lane variant, 63 = wave kernels
         const uint32_t k = atomicAdd(&counters[0], 1u);
         list_scan[k] = (int32_t)r;
         cnt[r] = CNT_DEFER;
@@ -203,7 +224,7 @@ struct FilterLane {
 
 template <int E>
 __global__ void __launch_bounds__(256)
-k_filter_lane(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
+k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
               int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
               const uint2 *__restrict__ pat, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
               uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan, uint32_t *__restrict__ counters) {
@@ -213,7 +234,7 @@ k_filter_lane(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ h
     const uint32_t meta = meta_in[r];
     const int len = (int)(meta & 0xFF);
     if (len < 16 - E) return;  // finished by k_pack
-    const uint32_t lo = lo_in[r], hi = hi_in[r];
+    const uint32_t lo = (uint32_t)lo_in[r], hi = (uint32_t)hi_in[r];
     FilterLane<E> L;
     L.tab_off = tab_off;
     L.tab_ent = tab_ent;
@@ -224,7 +245,7 @@ k_filter_lane(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ h
     L.va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
     L.ve = L.va & ~1u;
     L.res.init();
-    sct_for_each_seed<E>(lo, hi, len, L);
+    sct_for_each_seed<E, uint32_t>(lo, hi, len, L);
     L.res.store(r, false, min_e, cnt, slots, list_scan, counters);
 }
 
@@ -251,9 +272,10 @@ static constexpr int HMAX = 16;
 static constexpr int PID_BITS = 26;
 static constexpr uint32_t PID_MASK = (1u << PID_BITS) - 1u;
 
+template <typename W>
 struct FilterWaveLds {
-    uint32_t em[4][64];  // em[c][lane]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
-    uint32_t va[64];     // bits 0..len
+    W em[4][64];         // em[c][lane]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
+    W va[64];            // bits 0..len
     uint32_t hcnt[64];
     uint32_t hlist[HMAX][64];
     uint32_t qk[QCAP];   // queue: global table entry index f*np + k
@@ -264,14 +286,15 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t m) {  // number of set bi
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+template <typename W>
 struct EmLds {
-    const uint32_t *base;  // &em[0][segment lane]
-    __device__ __forceinline__ uint32_t operator()(uint32_t c) const { return base[c * 64]; }
+    const W *base;  // &em[0][segment lane]
+    __device__ __forceinline__ W operator()(uint32_t c) const { return base[c * 64]; }
 };
 
-template <int E>
+template <int E, typename W>
 struct FilterWave {
-    FilterWaveLds &L;
+    FilterWaveLds<W> &L;
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
     const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
@@ -279,7 +302,7 @@ struct FilterWave {
     int lane;
     bool active;
     int len;
-    uint32_t lo, hi;
+    W lo, hi;
     uint32_t head = 0, tail = 0;  // wave-uniform
     // bucket range of the placement whose offsets were loaded last; pushed when the NEXT placement arrives, so
     // that the offset loads of a placement overlap the queue work of the one before
@@ -292,8 +315,8 @@ struct FilterWave {
             const uint32_t idx = (head + lane) & (QCAP - 1);
             const uint32_t gk = L.qk[idx], meta = L.qm[idx];
             const uint32_t src = meta & 63u;
-            const int t = (int)((meta >> 8) & 31u), t2 = (int)((meta >> 16) & 31u);
-            const int d = wm_anchored<E, F>(EmLds{&L.em[0][src]}, L.va[src], tab_code[gk], t, t2);
+            const int t = (int)((meta >> 8) & 63u), t2 = (int)((meta >> 16) & 63u);
+            const int d = wm_anchored<E, F, W>(EmLds<W>{&L.em[0][src]}, L.va[src], tab_code[gk], t, t2);
             if (d <= E) {
                 const uint32_t pid = tab_ent[gk];
                 const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
@@ -341,7 +364,7 @@ struct FilterWave {
             const bool v = w.active && sct_placement_valid(t2, w.len);
             uint32_t s = 0, e = 0;
             if (v) {
-                const uint32_t *o = w.tab_off + (size_t)F * (SCT_KEYS + 1) + sct_placement_key<F>(w.lo, w.hi, t, t2);
+                const uint32_t *o = w.tab_off + (size_t)F * (SCT_KEYS + 1) + sct_placement_key<F, W>(w.lo, w.hi, t, t2);
                 s = o[0] + (uint32_t)F * (uint32_t)w.np;
                 e = o[1] + (uint32_t)F * (uint32_t)w.np;
             }
@@ -371,31 +394,36 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
-template <int E>
+// W = uint32_t handles the waves whose longest segment has at most 31 characters, W = uint64_t the others
+// (up to 63); both instantiations are launched over all rows and a wave leaves at once if it is not its kind.
+template <int E, typename W>
 __global__ void __launch_bounds__(256)
-k_filter(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
+k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
          int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
          const uint32_t *__restrict__ tab_code, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
          uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan, uint32_t *__restrict__ counters) {
-    __shared__ FilterWaveLds lds[4];
-    FilterWaveLds &L = lds[threadIdx.x >> 6];
+    __shared__ FilterWaveLds<W> lds[4];
+    FilterWaveLds<W> &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool active = r < n;
     int len = 0;
-    uint32_t lo = 0, hi = 0;
     if (active) active = cnt[r] != CNT_DEFER;  // routed to a scan path by k_pack
     if (active) {
         len = (int)(meta_in[r] & 0xFF);
         active = len >= 16 - E;  // shorter rows were finished by k_pack
-        lo = lo_in[r];
-        hi = hi_in[r];
     }
     if (!active) len = 0;
     const int maxlen = wave_max_i(len);
     if (maxlen == 0) return;  // the whole wave has nothing to do
-    const uint32_t va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
-    const uint32_t ve = va & ~1u, l1 = lo << 1, h1 = hi << 1;
+    if ((maxlen <= 31) != (sizeof(W) == 4)) return;  // the other instantiation's wave
+    W lo = 0, hi = 0;
+    if (active) {
+        lo = (W)lo_in[r];
+        hi = (W)hi_in[r];
+    }
+    const W va = sct_valid_mask<W>(len);
+    const W ve = va & ~(W)1, l1 = lo << 1, h1 = hi << 1;
     L.em[0][lane] = ~l1 & ~h1 & ve;
     L.em[1][lane] = l1 & ~h1 & ve;
     L.em[2][lane] = ~l1 & h1 & ve;
@@ -403,14 +431,14 @@ k_filter(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in,
     L.va[lane] = va;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    FilterWave<E> W{L, tab_off, tab_ent, tab_code, np, lane, active, len, lo, hi};
-    W.template run_family<SCT_F_H1>(maxlen);
-    if (E >= 1) W.template run_family<SCT_F_H2>(maxlen);
+    FilterWave<E, W> W_{L, tab_off, tab_ent, tab_code, np, lane, active, len, lo, hi};
+    W_.template run_family<SCT_F_H1>(maxlen);
+    if (E >= 1) W_.template run_family<SCT_F_H2>(maxlen);
     if (E >= 2) {
-        W.template run_family<SCT_F_MID>(maxlen);
-        W.template run_family<SCT_F_02>(maxlen);
-        W.template run_family<SCT_F_13>(maxlen);
-        W.template run_family<SCT_F_03>(maxlen);
+        W_.template run_family<SCT_F_MID>(maxlen);
+        W_.template run_family<SCT_F_02>(maxlen);
+        W_.template run_family<SCT_F_13>(maxlen);
+        W_.template run_family<SCT_F_03>(maxlen);
     }
     if (!active) return;
     const uint32_t nc = L.hcnt[lane];
@@ -950,7 +978,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     const int prefix_len = sct_prefix_len(threads);
     const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && (int64_t)np * SCT_NFAM <= (int64_t)PID_MASK;
     const size_t n1 = (size_t)(n ? n : 1);
-    if (c->lo.ensure(4 * n1) || c->hi.ensure(4 * n1) || c->meta.ensure(4 * n1) || c->min_e.ensure(n1) ||
+    if (c->lo.ensure(8 * n1) || c->hi.ensure(8 * n1) || c->meta.ensure(4 * n1) || c->min_e.ensure(n1) ||
         c->cnt.ensure(4 * n1) || c->route.ensure(4 * n1) || c->list_scan.ensure(4 * n1) || c->list_dp.ensure(4 * n1) ||
         c->counters.ensure(64) || c->hit_offs.ensure(8 * (n1 + 1)) || c->total.ensure(8))
         return SCT_E_HIP;
@@ -967,7 +995,8 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         {
             Timer t(c, "k_pack");
             k_pack<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), n, bl, max_err, prefix_len,
-                                                       filter_ok ? 1 : 0, c->lo.as<uint32_t>(), c->hi.as<uint32_t>(),
+                                                       !filter_ok ? 0 : (c->filter_mode == 1 ? 31 : PLANE_MAX), c->lo.as<uint64_t>(),
+                                                       c->hi.as<uint64_t>(),
                                                        c->meta.as<uint32_t>(), c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(),
                                                        c->list_scan.as<int32_t>(), c->list_dp.as<int32_t>(), counters);
         }
@@ -975,13 +1004,17 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
             Timer t(c, "k_filter");
             const unsigned g = blocks_for(n, 256);
 #define FILTER_ARGS(THIRD)                                                                                            \
-    c->lo.as<uint32_t>(), c->hi.as<uint32_t>(), c->meta.as<uint32_t>(), n, c->tab_off.as<uint32_t>(),                  \
+    c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), n, c->tab_off.as<uint32_t>(),                  \
         c->tab_ent.as<uint32_t>(), THIRD, np, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(),  \
         c->list_scan.as<int32_t>(), counters
 #define LAUNCH_FILTER(E)                                                                                              \
     do {                                                                                                              \
-        if (c->filter_mode == 1) k_filter_lane<E><<<g, 256, 0, st>>>(FILTER_ARGS(c->pat.as<uint2>()));                 \
-        else k_filter<E><<<g, 256, 0, st>>>(FILTER_ARGS(c->tab_code.as<uint32_t>()));                                  \
+        if (c->filter_mode == 1) {                                                                                    \
+            k_filter_lane<E><<<g, 256, 0, st>>>(FILTER_ARGS(c->pat.as<uint2>()));                                      \
+        } else {                                                                                                      \
+            k_filter<E, uint32_t><<<g, 256, 0, st>>>(FILTER_ARGS(c->tab_code.as<uint32_t>()));                         \
+            k_filter<E, uint64_t><<<g, 256, 0, st>>>(FILTER_ARGS(c->tab_code.as<uint32_t>()));                         \
+        }                                                                                                             \
     } while (0)
             if (max_err == 0) LAUNCH_FILTER(0);
             else if (max_err == 1) LAUNCH_FILTER(1);

@@ -59,32 +59,34 @@ static int wm(const std::vector<int> &p, const std::vector<int> &t) {
 }
 
 // minimum anchored distance over every enumerated placement whose key equals the pattern's key of that family
+template <typename W>
 struct EmArray {
-    uint32_t m[4];
-    uint32_t operator()(uint32_t c) const { return m[c]; }
+    W m[4];
+    W operator()(uint32_t c) const { return m[c]; }
 };
-template <int E, int F>
+template <int E, int F, typename W>
 struct AnchoredMin {
-    uint32_t tlo, thi, pkey, va, code;
-    EmArray em;
+    W tlo, thi, va;
+    uint32_t pkey, code;
+    EmArray<W> em;
     int best;
     void operator()(int t, int t2) {
-        if (sct_placement_key<F>(tlo, thi, t, t2) != pkey) return;
-        const int d = wm_anchored<E, F>(em, va, code, t, t2);
+        if (sct_placement_key<F, W>(tlo, thi, t, t2) != pkey) return;
+        const int d = wm_anchored<E, F, W>(em, va, code, t, t2);
         if (d < best) best = d;
     }
 };
-template <int E, int F>
+template <int E, int F, typename W>
 static int anchored_family(const std::vector<int> &p, const std::vector<int> &t) {
     uint64_t plo, phi, tlo, thi;
     planes(p, plo, phi);
     planes(t, tlo, thi);
     const int L = (int)t.size();
-    AnchoredMin<E, F> am;
-    am.tlo = (uint32_t)tlo; am.thi = (uint32_t)thi;
+    AnchoredMin<E, F, W> am;
+    am.tlo = (W)tlo; am.thi = (W)thi;
     am.pkey = sct_pattern_key(F, (uint32_t)plo, (uint32_t)phi);
-    am.va = L >= 31 ? 0xFFFFFFFFu : ((1u << (L + 1)) - 1u);
-    const uint32_t ve = am.va & ~1u, l1 = (uint32_t)tlo << 1, h1 = (uint32_t)thi << 1;
+    am.va = sct_valid_mask<W>(L);
+    const W ve = am.va & ~(W)1, l1 = (W)tlo << 1, h1 = (W)thi << 1;
     am.em.m[0] = ~l1 & ~h1 & ve; am.em.m[1] = l1 & ~h1 & ve; am.em.m[2] = ~l1 & h1 & ve; am.em.m[3] = l1 & h1 & ve;
     am.code = 0;
     for (int j = 0; j < 16; j++) am.code |= (uint32_t)p[j] << (2 * j);
@@ -92,15 +94,15 @@ static int anchored_family(const std::vector<int> &p, const std::vector<int> &t)
     sct_for_each_placement<F>(L, am);
     return am.best;
 }
-template <int E>
+template <int E, typename W = uint32_t>
 static int anchored(const std::vector<int> &p, const std::vector<int> &t) {
-    int b = anchored_family<E, SCT_F_H1>(p, t);
-    if (E >= 1) b = std::min(b, anchored_family<E, SCT_F_H2>(p, t));
+    int b = anchored_family<E, SCT_F_H1, W>(p, t);
+    if (E >= 1) b = std::min(b, anchored_family<E, SCT_F_H2, W>(p, t));
     if (E >= 2) {
-        b = std::min(b, anchored_family<E, SCT_F_MID>(p, t));
-        b = std::min(b, anchored_family<E, SCT_F_02>(p, t));
-        b = std::min(b, anchored_family<E, SCT_F_13>(p, t));
-        b = std::min(b, anchored_family<E, SCT_F_03>(p, t));
+        b = std::min(b, anchored_family<E, SCT_F_MID, W>(p, t));
+        b = std::min(b, anchored_family<E, SCT_F_02, W>(p, t));
+        b = std::min(b, anchored_family<E, SCT_F_13, W>(p, t));
+        b = std::min(b, anchored_family<E, SCT_F_03, W>(p, t));
     }
     return b;
 }
@@ -122,7 +124,7 @@ static bool seeds_cover(const std::vector<int> &p, const std::vector<int> &t) {
     for (int f = 0; f < SCT_NFAM; f++) keys[f] = sct_pattern_key(f, (uint32_t)plo, (uint32_t)phi);
     SeedHit sh;
     sh.keys = keys;
-    sct_for_each_seed<E>((uint32_t)tlo, (uint32_t)thi, (int)t.size(), sh);
+    sct_for_each_seed<E, uint32_t>((uint32_t)tlo, (uint32_t)thi, (int)t.size(), sh);
     return sh.hit;
 }
 
@@ -179,6 +181,31 @@ int main() {
         if (want <= 0 && !seeds_cover<0>(p, t)) { printf("FAIL seeds0\n"); return 1; }
         if (want <= 1 && !seeds_cover<1>(p, t)) { printf("FAIL seeds1\n"); return 1; }
         if (want <= 2 && !seeds_cover<2>(p, t)) { printf("FAIL seeds2 want=%d\n", want); return 1; }
+        checked++;
+    }
+    // 2b. the 64-bit variant of the anchored automaton: texts of 0..63 characters
+    for (int it = 0; it < 120000; it++) {
+        const int m = 16, alpha = (it % 7 == 0) ? 2 : 4;
+        int n = rnd(64);
+        std::vector<int> p(m), t;
+        for (auto &x : p) x = rnd(alpha);
+        std::vector<int> c(p);
+        for (int k = rnd(4); k > 0; k--) {
+            int kind = rnd(3), pos = rnd((int)c.size() + (kind == 1));
+            if (kind == 0 && !c.empty()) c[std::min(pos, (int)c.size() - 1)] = rnd(4);
+            else if (kind == 1) c.insert(c.begin() + pos, rnd(4));
+            else if (!c.empty()) c.erase(c.begin() + std::min(pos, (int)c.size() - 1));
+        }
+        int left = rnd(45);
+        for (int i = 0; i < left; i++) t.push_back(rnd(alpha));
+        if (rnd(5)) t.insert(t.end(), c.begin(), c.end());
+        while ((int)t.size() < n) t.push_back(rnd(alpha));
+        if ((int)t.size() > 63) t.resize(63);
+        const int want = brute_infix(p, t);
+        if (anchored<0, uint64_t>(p, t) != std::min(want, 1)) { printf("FAIL anchored64/0\n"); return 1; }
+        if (anchored<1, uint64_t>(p, t) != std::min(want, 2)) { printf("FAIL anchored64/1\n"); return 1; }
+        if (anchored<2, uint64_t>(p, t) != std::min(want, 3)) { printf("FAIL anchored64/2 want=%d got=%d n=%zu\n", want, anchored<2, uint64_t>(p, t), t.size()); return 1; }
+        if (t.size() <= 31 && anchored<2, uint32_t>(p, t) != std::min(want, 3)) { printf("FAIL anchored32 vs 64\n"); return 1; }
         checked++;
     }
     // 3. exhaustive seed completeness around one pattern: every text obtained by <= 2 edits of it
