@@ -47,11 +47,11 @@ def pmc_quote(workload_desc):
     return q if q.get("workload") == workload_desc else None
 
 
-def make_batch(n, bc, seed, chunk=1_000_000):
+def make_batch(n, bc, seed, chunk=1_000_000, seg_len=22):
     """Seeded synthetic segments, generated in chunks to bound host memory."""
     segs, offs, base = [], [np.zeros(1, np.int64)], 0
     for i, c0 in enumerate(range(0, n, chunk)):
-        s, o = synth.make_segments(min(chunk, n - c0), bc, seed=seed * 1000 + i)
+        s, o = synth.make_segments(min(chunk, n - c0), bc, seed=seed * 1000 + i, seg_len=seg_len)
         segs.append(s)
         offs.append(o[1:] + base)
         base += int(o[-1])
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--segments", type=int, default=None, help="override segments per GPU")
+    ap.add_argument("--seg-len", type=int, default=22, help="segment length of the synthetic rows (22 = the reference's nominal length)")
     ap.add_argument("--cpu-sample", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exhaustive", action="store_true", help="time the all-barcodes scan instead of the seed filter")
@@ -98,7 +99,7 @@ def main():
         n_seg = args.segments
     bc = synth.make_barcodes(n_bc, bl=bl, seed=3)
     seed = 3 if world == 1 else 40 + rank
-    segs, offs = make_batch(n_seg, bc, seed)
+    segs, offs = make_batch(n_seg, bc, seed, seg_len=args.seg_len)
 
     m = _native.Matcher(local_rank)
     m.set_barcodes(bc)
@@ -144,8 +145,8 @@ def main():
                     # the binding resource is integer VALU issue, not HBM: all-pairs DP cells credited
                     "dp_cells_per_segment": int(synth_seg_len(offs) * bl * n_bc * 2),
                     "gcups_equivalent": round(n_seg * synth_seg_len(offs) * bl * n_bc * 2 / (avg[dominant] * 1e-3) / 1e9, 1)}
-        workload_desc = "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, 22-bp segments (SURVEY 8(d))" % (
-            args.workload, n_seg, n_bc, bl, max_err)
+        workload_desc = "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, %d-bp segments (SURVEY 8(d))" % (
+            args.workload, n_seg, n_bc, bl, max_err, args.seg_len)
         q = pmc_quote(workload_desc) if (roof and not args.force_exhaustive and args.filter_mode == 0) else None
         if q:
             rd = q.get("hbm_read_bytes_x2_gfx950") or 0

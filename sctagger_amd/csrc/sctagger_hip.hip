@@ -10,7 +10,7 @@
 //              ascending p is the reference's sorted(bids) order), stored as bit-planes uint2{lo, hi}
 //   seed tables (bl == 16): six families x (65536+1 offsets, np pattern ids), see sct_core.h
 //   segments   the caller's CSR bytes + int64 offsets, plus per segment the packed bit-planes {lo, hi, meta}
-//   results    min_e u8[n], cnt u32[n], slots u32[n][8] (filter path), hit_offs i64[n+1], hits u32[total]
+//   results    min_e u8[n], cnt u32[n], slot_off u64[n] + dense slots u32[] (filter path), hit_offs i64[n+1], hits u32[total]
 //
 // Kernels:
 //   k_pack        ASCII -> bit-planes, routes each segment to the filter / exhaustive / restricted-start path
@@ -160,19 +160,37 @@ struct LaneResult {
             if (i == nh) h[i] = pid;
         nh++;  // may run past K_SLOTS: that is the defer signal
     }
-    // writes min_e / cnt / slots for row r, or defers it to the scan list
-    __device__ __forceinline__ void store(int64_t r, bool overflow, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
-                                          uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan,
+    // Wave-cooperative store (every lane of the wave must call it; `row` says whether the lane owns a row).
+    // The hit lists of the wave are written back to back into the dense `slots` array: one wave-wide prefix sum
+    // of the list lengths and one 64-bit atomic per wave reserve the space, slot_off[r] remembers where row r's
+    // list starts.  Rows with too many ties are pushed to the scan list instead.
+    __device__ __forceinline__ void store(bool row, int64_t r, bool overflow, uint8_t *__restrict__ min_e,
+                                          uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
+                                          uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_scan,
                                           uint32_t *__restrict__ counters) {
-        if (overflow || nh > K_SLOTS) {
+        const int lane = threadIdx.x & 63;
+        const bool defer = row && (overflow || nh > K_SLOTS);
+        const uint32_t mine = (row && !defer) ? (uint32_t)nh : 0u;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        const uint32_t total = __shfl(inc, 63, 64);
+        unsigned long long base = 0;
+        if (lane == 0 && total) base = atomicAdd(reinterpret_cast<unsigned long long *>(counters + 4), (unsigned long long)total);
+        base = __shfl(base, 0, 64);
+        if (!row) return;
+        if (defer) {
             const uint32_t k = atomicAdd(&counters[0], 1u);
             list_scan[k] = (int32_t)r;
             cnt[r] = CNT_DEFER;
             return;
         }
-        if (nh == 0) {
+        cnt[r] = mine;
+        if (mine == 0) {
             min_e[r] = SCT_NO_HIT;
-            cnt[r] = 0;
             return;
         }
         if (nh > 1) {  // sort ascending: odd-even transposition network on registers
@@ -190,10 +208,11 @@ struct LaneResult {
             }
         }
         min_e[r] = (uint8_t)best;
-        cnt[r] = (uint32_t)nh;
+        const uint64_t start = base + inc - mine;
+        slot_off[r] = start;
 #pragma unroll
         for (int i = 0; i < K_SLOTS; i++)
-            if (i < nh) slots[(size_t)r * K_SLOTS + i] = h[i];
+            if (i < nh) slots[start + i] = h[i];
     }
 };
 
@@ -227,26 +246,31 @@ __global__ void __launch_bounds__(256)
 k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
               int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
               const uint2 *__restrict__ pat, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
-              uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan, uint32_t *__restrict__ counters) {
+              uint32_t *__restrict__ slots, uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_scan,
+              uint32_t *__restrict__ counters) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    if (cnt[r] == CNT_DEFER) return;  // routed to a scan path by k_pack
-    const uint32_t meta = meta_in[r];
-    const int len = (int)(meta & 0xFF);
-    if (len < 16 - E) return;  // finished by k_pack
-    const uint32_t lo = (uint32_t)lo_in[r], hi = (uint32_t)hi_in[r];
+    bool active = r < n;
+    if (active) active = cnt[r] != CNT_DEFER;  // routed to a scan path by k_pack
+    int len = 0;
+    if (active) {
+        len = (int)(meta_in[r] & 0xFF);
+        active = len >= 16 - E;  // shorter rows were finished by k_pack
+    }
     FilterLane<E> L;
-    L.tab_off = tab_off;
-    L.tab_ent = tab_ent;
-    L.pat = pat;
-    L.np = np;
-    L.tls = lo << 1;
-    L.ths = hi << 1;
-    L.va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
-    L.ve = L.va & ~1u;
     L.res.init();
-    sct_for_each_seed<E, uint32_t>(lo, hi, len, L);
-    L.res.store(r, false, min_e, cnt, slots, list_scan, counters);
+    if (active) {
+        const uint32_t lo = (uint32_t)lo_in[r], hi = (uint32_t)hi_in[r];
+        L.tab_off = tab_off;
+        L.tab_ent = tab_ent;
+        L.pat = pat;
+        L.np = np;
+        L.tls = lo << 1;
+        L.ths = hi << 1;
+        L.va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
+        L.ve = L.va & ~1u;
+        sct_for_each_seed<E, uint32_t>(lo, hi, len, L);
+    }
+    L.res.store(active, r, false, min_e, cnt, slots, slot_off, list_scan, counters);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -401,7 +425,8 @@ __global__ void __launch_bounds__(256)
 k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
          int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
          const uint32_t *__restrict__ tab_code, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
-         uint32_t *__restrict__ slots, int32_t *__restrict__ list_scan, uint32_t *__restrict__ counters) {
+         uint32_t *__restrict__ slots, uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_scan,
+         uint32_t *__restrict__ counters) {
     __shared__ FilterWaveLds<W> lds[4];
     FilterWaveLds<W> &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
@@ -440,8 +465,7 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
         W_.template run_family<SCT_F_13>(maxlen);
         W_.template run_family<SCT_F_03>(maxlen);
     }
-    if (!active) return;
-    const uint32_t nc = L.hcnt[lane];
+    const uint32_t nc = active ? L.hcnt[lane] : 0u;
     LaneResult<E> res;
     res.init();
     const uint32_t lim = nc < HMAX ? nc : HMAX;
@@ -449,7 +473,7 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
         const uint32_t v = L.hlist[k][lane];
         res.add((int)(v >> 30), v & PID_MASK);
     }
-    res.store(r, nc > HMAX, min_e, cnt, slots, list_scan, counters);
+    res.store(active, r, nc > HMAX, min_e, cnt, slots, slot_off, list_scan, counters);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -697,14 +721,16 @@ __global__ void __launch_bounds__(256) k_offsets(const uint32_t *__restrict__ cn
 
 // filter path: slots -> CSR
 __global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ slots,
-                                               const int64_t *__restrict__ hit_offs, const uint32_t *__restrict__ route_cnt,
-                                               int64_t n, uint32_t *__restrict__ hits) {
+                                               const uint64_t *__restrict__ slot_off, const int64_t *__restrict__ hit_offs,
+                                               const uint32_t *__restrict__ route_cnt, int64_t n, uint32_t *__restrict__ hits) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     if (route_cnt[r] == CNT_DEFER) return;  // written by the scan path's fill pass
     const uint32_t c = cnt[r];
     const int64_t o = hit_offs[r];
-    for (uint32_t i = 0; i < c; i++) hits[o + i] = slots[(size_t)r * K_SLOTS + i];
+    if (c == 0) return;
+    const uint64_t so = slot_off[r];
+    for (uint32_t i = 0; i < c; i++) hits[o + i] = slots[so + i];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -749,7 +775,7 @@ struct sct_ctx {
     int64_t n_seg = -1, seg_bytes = 0;
     DevBuf segs, offs;
     // work / results
-    DevBuf lo, hi, meta, min_e, cnt, route, slots, list_scan, list_dp, counters, hit_offs, sums, total, hits, part_best, part_cnt;
+    DevBuf lo, hi, meta, min_e, cnt, route, slots, slot_off, list_scan, list_dp, counters, hit_offs, sums, total, hits, part_best, part_cnt;
     int64_t n_hits = 0;
     bool have_result = false;
     // options
@@ -835,7 +861,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
-                      &c->cnt, &c->route, &c->slots, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
+                      &c->cnt, &c->route, &c->slots, &c->slot_off, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
                       &c->total, &c->hits, &c->part_best, &c->part_cnt};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
@@ -982,7 +1008,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         c->cnt.ensure(4 * n1) || c->route.ensure(4 * n1) || c->list_scan.ensure(4 * n1) || c->list_dp.ensure(4 * n1) ||
         c->counters.ensure(64) || c->hit_offs.ensure(8 * (n1 + 1)) || c->total.ensure(8))
         return SCT_E_HIP;
-    if (filter_ok && c->slots.ensure(4 * n1 * K_SLOTS)) return SCT_E_HIP;
+    if (filter_ok && (c->slots.ensure(4 * n1 * K_SLOTS) || c->slot_off.ensure(8 * n1))) return SCT_E_HIP;
     const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (c->sums.ensure(8 * (size_t)(nb ? nb : 1))) return SCT_E_HIP;
     c->timed.clear();
@@ -1006,7 +1032,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
 #define FILTER_ARGS(THIRD)                                                                                            \
     c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), n, c->tab_off.as<uint32_t>(),                  \
         c->tab_ent.as<uint32_t>(), THIRD, np, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(),  \
-        c->list_scan.as<int32_t>(), counters
+        c->slot_off.as<uint64_t>(), c->list_scan.as<int32_t>(), counters
 #define LAUNCH_FILTER(E)                                                                                              \
     do {                                                                                                              \
         if (c->filter_mode == 1) {                                                                                    \
@@ -1085,7 +1111,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     if (n > 0 && total > 0) {
         if (filter_ok) {
             Timer t(c, "k_fill");
-            k_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->hit_offs.as<int64_t>(),
+            k_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->hit_offs.as<int64_t>(),
                                                        c->route.as<uint32_t>(), n, c->hits.as<uint32_t>());
         }
         if (hc[0]) {
