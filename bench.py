@@ -101,7 +101,9 @@ def main():
     seed = 3 if world == 1 else 40 + rank
     segs, offs = make_batch(n_seg, bc, seed, seg_len=args.seg_len)
 
-    m = _native.Matcher(local_rank)
+    # one rank per GPU; with fewer visible devices than ranks (rehearsing N > 1 on a one-GPU box) ranks share devices
+    ndev = max(1, _native.device_count())
+    m = _native.Matcher(local_rank % ndev)
     m.set_barcodes(bc)
     if args.force_exhaustive:
         m.set_option("force_exhaustive", 1)
@@ -111,9 +113,19 @@ def main():
     def barrier():
         shard.barrier(dist)
 
+    def device_sync():
+        m.sync()                      # the library's own stream (torch.cuda.synchronize would not see it)
+        if dist is not None:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+            except Exception:
+                pass
+
     for _ in range(args.warmup):
         m.run(max_err, threads=1)
-    m.sync()
+    device_sync()
     barrier()
     per_kernel = {}
     t0 = time.perf_counter()
@@ -122,7 +134,7 @@ def main():
         hits = m.run(max_err, threads=1)
         for name, ms in m.last_timing():
             per_kernel.setdefault(name, []).append(ms)
-    m.sync()
+    device_sync()
     elapsed = time.perf_counter() - t0
     barrier()
     elapsed, total_segments = shard.reduce_timing(dist, elapsed, n_seg)
