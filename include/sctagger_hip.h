@@ -115,6 +115,25 @@ int sct_last_timing(sct_ctx *ctx, const char **names, float *ms, int cap);
  * path, [2] segments on the restricted-start (non-ACGT, k>0) path, [3] total hits. Returns count or <0. */
 int sct_last_stats(sct_ctx *ctx, int64_t *out, int cap);
 
+/*
+ * --- extract_sr_bc_from_lr (reference scTagger.py:792-844) ------------------
+ * The reference builds an Aho-Corasick automaton (third-party pyahocorasick) over the whitelist and its reverse
+ * complements and counts, per barcode, the segments that contain exactly one occurrence of any word.
+ *
+ * sct_wl_set      the dictionary of :801-809.  keys = the n whitelist entries back to back (entry i has
+ *                 key_lens[i] raw bytes, 0..16; exactly what `l[:-1]` yields, :798).  Words are added in the
+ *                 reference's order — all forward words with value i, then all reverse complements (rev_compl,
+ *                 :148-156) with value -i — and adding an existing word replaces its value (add_word).
+ * sct_wl_count    the loop of :818-826 over CSR segments: rows with skip[r] != 0 (the reference's p == 'NA') are
+ *                 ignored; every occurrence of every word counts as a hit; rows with exactly one hit increment
+ *                 counts[|value|].  first_seen[b] = first row that incremented b, -1 if none (the reference's
+ *                 Counter keeps insertion order, which breaks ties in its sort, :828).  counts / first_seen hold
+ *                 n (whitelist size) entries.
+ */
+int sct_wl_set(sct_ctx *ctx, const char *keys, const int32_t *key_lens, int32_t n);
+int sct_wl_count(sct_ctx *ctx, const char *segs, const int64_t *offs, const uint8_t *skip, int64_t n, int64_t *counts,
+                 int64_t *first_seen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ MAX_BL = 32
 EXPORTS = (
     "sct_device_count", "sct_create", "sct_destroy", "sct_last_error", "sct_prefix_len", "sct_set_barcodes",
     "sct_match", "sct_free_hits", "sct_upload_segments", "sct_run", "sct_download", "sct_sync", "sct_set_option",
-    "sct_last_timing", "sct_last_stats",
+    "sct_last_timing", "sct_last_stats", "sct_wl_set", "sct_wl_count",
 )
 
 _lib = None
@@ -59,6 +59,8 @@ def load():
     lib.sct_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     lib.sct_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     lib.sct_last_stats.argtypes = [vp, ctypes.POINTER(i64), ctypes.c_int]
+    lib.sct_wl_set.argtypes = [vp, vp, vp, i32]
+    lib.sct_wl_count.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     _lib = lib
     return lib
 
@@ -192,6 +194,26 @@ class Matcher:
         if k < 0:
             self._check(k)
         return [(names[i].decode(), float(ms[i])) for i in range(min(k, cap))]
+
+    def wl_set(self, words):
+        """The whitelist dictionary of extract_sr_bc_from_lr (scTagger.py:801-809). words: list of str/bytes."""
+        rows = [w.encode("latin-1") if isinstance(w, str) else bytes(w) for w in words]
+        lens = np.fromiter((len(r) for r in rows), dtype=np.int32, count=len(rows))
+        flat = np.frombuffer(b"".join(rows), dtype=np.uint8) if rows else np.empty(0, np.uint8)
+        flat = np.ascontiguousarray(flat)
+        self._check(self._lib.sct_wl_set(self._ctx, _ptr(flat), _ptr(lens), len(rows)))
+        self.n_wl = len(rows)
+
+    def wl_count(self, segs, offs, skip):
+        """The counting loop (:818-826). -> (counts int64[n_wl], first_seen int64[n_wl])."""
+        segs, offs = self._csr(segs, offs)
+        skip = np.ascontiguousarray(skip, dtype=np.uint8)
+        if skip.size != offs.size - 1:
+            raise ValueError("skip must hold one flag per row")
+        counts = np.zeros(max(self.n_wl, 1), dtype=np.int64)
+        first = np.zeros(max(self.n_wl, 1), dtype=np.int64)
+        self._check(self._lib.sct_wl_count(self._ctx, _ptr(segs), _ptr(offs), _ptr(skip), offs.size - 1, _ptr(counts), _ptr(first)))
+        return counts[:self.n_wl], first[:self.n_wl]
 
     def last_stats(self):
         out = (ctypes.c_int64 * 4)()

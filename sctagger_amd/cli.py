@@ -1,4 +1,4 @@
-"""`scTagger.py match_trie` command line (reference scTagger.py:81-97, :140-143, :847-861).
+"""`scTagger.py match_trie` (and `extract_sr_bc_from_lr`) command line (reference scTagger.py:67-97, :135-143, :847-861).
 
 Flags, defaults and asserts are the reference's for this sub-command; `-m/--mem` and `-p/--plotfile`
 are accepted and unused, exactly as there.  Optional extras: `--devices` (GPU ids, one shard each) and
@@ -9,7 +9,7 @@ import sys
 
 from . import match_trie as _mt
 
-OTHER_SUBCOMMANDS = ("extract_lr_bc", "extract_sr_bc", "extract_sr_bc_from_lr")
+OTHER_SUBCOMMANDS = ("extract_lr_bc", "extract_sr_bc")
 
 
 def parse_args(argv=None):
@@ -31,24 +31,39 @@ def parse_args(argv=None):
                    help="Path to output file; gzipped if it ends with 'gz'. Default: stdout")
     p.add_argument("--devices", type=int, nargs="+", default=None, help="GPU ids to shard the segments over. Default: 0")
     p.add_argument("--gzip-level", type=int, default=4, help="gzip level of the output (the reference writes level 9; the bytes after decompression are identical). Default: 4")
+    q = subparsers.add_parser("extract_sr_bc_from_lr")     # reference scTagger.py:67-79
+    q.add_argument("-i", "--input", type=str, required=True, help="Input TSV file generated from extract_lr_bc step")
+    q.add_argument("-o", "--outfile", type=str, default=None, help="Path to output file (gzipped). Default: STDOUT")
+    q.add_argument("-wl", "--barcode-whitelist", type=str, required=True, help="Path to TXT barcode whitelist")
+    q.add_argument("--thresh", type=float, default=0.005)
+    q.add_argument("--step-size", type=int, default=1000)
+    q.add_argument("--max-barcode-cnt", type=int, default=25_000)
     for name in OTHER_SUBCOMMANDS:
         subparsers.add_parser(name, add_help=False)
     args, rest = parser.parse_known_args(argv)
-    if args.subcommand != "match_trie":
-        parser.error("sub-command %r is not part of this build (match_trie only)" % args.subcommand)
+    if args.subcommand in OTHER_SUBCOMMANDS:
+        parser.error("sub-command %r is not part of this build" % args.subcommand)
     if rest:
         parser.error("unrecognized arguments: %s" % " ".join(rest))
-    # reference :140-143
-    assert args.mem > 0
-    assert args.barcode_length > 0
-    assert args.barcode_length > args.max_error >= 0
+    if args.subcommand == "extract_sr_bc_from_lr":   # reference :135-138
+        assert 0 <= args.thresh <= 1
+        assert 0 < args.step_size
+        assert 0 < args.max_barcode_cnt
+    if args.subcommand == "match_trie":              # reference :140-143
+        assert args.mem > 0
+        assert args.barcode_length > 0
+        assert args.barcode_length > args.max_error >= 0
     return args
 
 
 def main(argv=None):
     args = parse_args(argv)
     print(args, file=sys.stderr)
-    _mt.match_trie(args)
+    if args.subcommand == "extract_sr_bc_from_lr":
+        from . import extract_sr_bc_from_lr as _x
+        _x.extract_sr_bc_from_lr(args)
+    else:
+        _mt.match_trie(args)
 
 
 if __name__ == "__main__":

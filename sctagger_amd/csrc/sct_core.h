@@ -249,3 +249,29 @@ SCT_HD int wm_anchored(EmFetch &&em, W va, uint32_t code, int t, int t2) {
     for (int j = 4 * (B + 1); j < 16; j++) s.step(em((code >> (2 * j)) & 3u));
     return s.result(va);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Whitelist dictionary of the extract_sr_bc_from_lr stage (reference scTagger.py:801-809): keys are whole
+// barcodes of 1..16 raw bytes, zero-padded into four little-endian words.  One open-addressing table holds
+// all keys (the length is part of the key); host build and device lookup share hash and slot layout.
+// ---------------------------------------------------------------------------------------------------
+struct SctWlSlot {
+    uint32_t k[4];
+    int32_t value;
+    uint32_t len;  // 0 = empty slot
+};
+
+SCT_HD uint32_t sct_wl_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
+    uint32_t h = len * 0x9E3779B1u;
+    h = (h ^ k0) * 0x85EBCA6Bu;
+    h = ((h << 13) | (h >> 19)) ^ k1;
+    h *= 0xC2B2AE35u;
+    h = ((h << 17) | (h >> 15)) ^ k2;
+    h *= 0x27D4EB2Fu;
+    h = ((h << 11) | (h >> 21)) ^ k3;
+    h *= 0x165667B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    return h;
+}

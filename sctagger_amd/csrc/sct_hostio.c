@@ -57,6 +57,35 @@ int64_t sctio_parse_lr(const uint8_t *buf, int64_t len, int64_t n, int64_t *name
     return -1;
 }
 
+/*
+ * The row parser of extract_sr_bc_from_lr (scTagger.py:819): `_,_,p,seg = l.rstrip('\n').split('\t')` needs
+ * exactly four fields.  na[i] = 1 iff the third field is "NA".  Returns -1, or the first offending line number
+ * (the reference raises ValueError there).
+ */
+int64_t sctio_parse_lr4(const uint8_t *buf, int64_t len, int64_t n, uint8_t *na, uint8_t *segs, int64_t *offs) {
+    int64_t out = 0, p = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t tab[3] = {-1, -1, -1};
+        int nt = 0;
+        int64_t q = p;
+        for (; q < len; q++) {
+            const uint8_t c = buf[q];
+            if (c == '\n') break;
+            if (c == '\t') {
+                if (nt < 3) tab[nt] = q;
+                nt++;
+            }
+        }
+        if (nt != 3) return i;
+        na[i] = (tab[2] - tab[1] == 3 && buf[tab[1] + 1] == 'N' && buf[tab[1] + 2] == 'A') ? 1 : 0;
+        offs[i] = out;
+        for (int64_t k = tab[2] + 1; k < q; k++) segs[out++] = buf[k];
+        p = q + 1;
+    }
+    offs[n] = out;
+    return -1;
+}
+
 static int ndigits(uint64_t v) {
     int d = 1;
     while (v >= 10) { v /= 10; d++; }

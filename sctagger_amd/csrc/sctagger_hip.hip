@@ -734,6 +734,70 @@ __global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_wl_count: the matching loop of extract_sr_bc_from_lr (reference scTagger.py:818-826).  One lane per row.
+// Every occurrence of every dictionary key in the segment counts as a hit (Automaton.iter); rows with exactly one
+// hit add 1 to that barcode's counter (index |value|) and lower its first-seen row (the Counter's insertion order
+// breaks ties in the reference's sort).  Genuinely memory-bound: ~7 random 24-byte table probes per row.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_wl_count(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const uint8_t *__restrict__ skip, int64_t n,
+           const SctWlSlot *__restrict__ table, uint32_t mask, uint32_t len_set, uint32_t *__restrict__ counts,
+           uint32_t *__restrict__ first_seen) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (skip[r]) return;
+    const int64_t b0 = offs[r];
+    const int64_t len = offs[r + 1] - b0;
+    const uint32_t *wp = reinterpret_cast<const uint32_t *>(segs) + (b0 >> 2);
+    const int sk = (int)(b0 & 3);
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // the last 16 bytes read, newest in the top byte of w3
+    uint32_t hits = 0;
+    int32_t value = 0;
+    uint32_t word = 0;
+    for (int64_t i = 0; i < len; i++) {
+        const int64_t g = i + sk;
+        if ((g & 3) == 0 || i == 0) word = wp[g >> 2];
+        const uint32_t b = (word >> (8 * (g & 3))) & 0xFFu;
+        w0 = (w0 >> 8) | (w1 << 24);
+        w1 = (w1 >> 8) | (w2 << 24);
+        w2 = (w2 >> 8) | (w3 << 24);
+        w3 = (w3 >> 8) | (b << 24);
+        for (uint32_t ls = len_set; ls; ls &= ls - 1) {
+            const int L = __ffs(ls) - 1;  // key length, 1..16
+            if (i + 1 < L) continue;
+            // the last L bytes, zero padded: shift the 128-bit window right by 16-L bytes
+            const int sb = 16 - L, dw = sb >> 2, bs = (sb & 3) * 8;
+            uint32_t a0 = dw == 0 ? w0 : dw == 1 ? w1 : dw == 2 ? w2 : w3;
+            uint32_t a1 = dw == 0 ? w1 : dw == 1 ? w2 : dw == 2 ? w3 : 0u;
+            uint32_t a2 = dw == 0 ? w2 : dw == 1 ? w3 : 0u;
+            uint32_t a3 = dw == 0 ? w3 : 0u;
+            if (bs) {
+                a0 = (a0 >> bs) | (a1 << (32 - bs));
+                a1 = (a1 >> bs) | (a2 << (32 - bs));
+                a2 = (a2 >> bs) | (a3 << (32 - bs));
+                a3 = a3 >> bs;
+            }
+            uint32_t idx = sct_wl_hash(a0, a1, a2, a3, (uint32_t)L) & mask;
+            for (;;) {
+                const SctWlSlot s = table[idx];
+                if (s.len == 0) break;
+                if (s.len == (uint32_t)L && s.k[0] == a0 && s.k[1] == a1 && s.k[2] == a2 && s.k[3] == a3) {
+                    hits++;
+                    value = s.value;
+                    break;
+                }
+                idx = (idx + 1) & mask;
+            }
+        }
+    }
+    if (hits == 1) {
+        const uint32_t b = (uint32_t)(value < 0 ? -value : value);
+        atomicAdd(&counts[b], 1u);
+        atomicMin(&first_seen[b], (uint32_t)r);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -778,6 +842,10 @@ struct sct_ctx {
     DevBuf lo, hi, meta, min_e, cnt, route, slots, slot_off, list_scan, list_dp, counters, hit_offs, sums, total, hits, part_best, part_cnt;
     int64_t n_hits = 0;
     bool have_result = false;
+    // whitelist dictionary (extract_sr_bc_from_lr)
+    DevBuf wl_table, wl_counts, wl_first, wl_skip;
+    uint32_t wl_mask = 0, wl_len_set = 0;
+    int32_t wl_n = -1;
     // options
     bool force_exhaustive = false, timing = true;
     int filter_mode = 0;  // 0 = wave-cooperative k_filter, 1 = k_filter_lane
@@ -862,7 +930,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
                       &c->cnt, &c->route, &c->slots, &c->slot_off, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
-                      &c->total, &c->hits, &c->part_best, &c->part_cnt};
+                      &c->total, &c->hits, &c->part_best, &c->part_cnt, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1194,4 +1262,108 @@ extern "C" int sct_last_stats(sct_ctx *c, int64_t *out, int cap) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
     for (int i = 0; i < 4 && i < cap; i++) out[i] = c->stats[i];
     return 4;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// extract_sr_bc_from_lr (reference scTagger.py:792-844): whitelist dictionary + counting
+// ------------------------------------------------------------------------------------------------------------
+static void wl_pack(const uint8_t *key, int len, bool rc, uint32_t k[4]) {
+    uint8_t b[16] = {0};
+    for (int j = 0; j < len; j++) b[j] = rc ? comp_byte(key[len - 1 - j]) : key[j];
+    for (int w = 0; w < 4; w++) k[w] = (uint32_t)b[4 * w] | ((uint32_t)b[4 * w + 1] << 8) | ((uint32_t)b[4 * w + 2] << 16) | ((uint32_t)b[4 * w + 3] << 24);
+}
+
+extern "C" int sct_wl_set(sct_ctx *c, const char *keys, const int32_t *key_lens, int32_t n) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!keys || !key_lens))) return fail(SCT_E_ARG, "sct_wl_set: bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    int64_t total = 0;
+    for (int32_t i = 0; i < n; i++) {
+        if (key_lens[i] < 0) return fail(SCT_E_ARG, "negative key length");
+        if (key_lens[i] > 16) return fail(SCT_E_UNSUPPORTED, "whitelist entry %d has %d characters; at most 16 are supported", i, key_lens[i]);
+        total += key_lens[i];
+    }
+    const uint8_t *kb = (const uint8_t *)keys;
+    for (int64_t i = 0; i < total; i++)
+        if (kb[i] >= 128) return fail(SCT_E_ARG, "whitelist contains byte 0x%02x >= 128", kb[i]);
+    uint64_t cap = 16;
+    while (cap < 4ull * (uint64_t)(n > 0 ? n : 1)) cap <<= 1;  // two words per barcode, load factor <= 0.5
+    if (cap > (1ull << 31)) return fail(SCT_E_UNSUPPORTED, "whitelist too large");
+    std::vector<SctWlSlot> tab((size_t)cap);
+    memset(tab.data(), 0, tab.size() * sizeof(SctWlSlot));
+    const uint32_t mask = (uint32_t)(cap - 1);
+    uint32_t len_set = 0;
+    // forward words in order, then reverse complements; adding an existing key replaces its value (add_word)
+    for (int pass = 0; pass < 2; pass++) {
+        int64_t at = 0;
+        for (int32_t i = 0; i < n; i++) {
+            const int L = key_lens[i];
+            const uint8_t *key = kb + at;
+            at += L;
+            if (L == 0) continue;  // the empty word cannot be added to the automaton
+            uint32_t k[4];
+            wl_pack(key, L, pass == 1, k);
+            uint32_t idx = sct_wl_hash(k[0], k[1], k[2], k[3], (uint32_t)L) & mask;
+            for (;;) {
+                SctWlSlot &s = tab[idx];
+                if (s.len == 0) {
+                    s.len = (uint32_t)L;
+                    memcpy(s.k, k, sizeof(k));
+                    s.value = pass == 0 ? i : -i;
+                    break;
+                }
+                if (s.len == (uint32_t)L && !memcmp(s.k, k, sizeof(k))) {
+                    s.value = pass == 0 ? i : -i;
+                    break;
+                }
+                idx = (idx + 1) & mask;
+            }
+            len_set |= 1u << L;
+        }
+    }
+    if (c->wl_table.ensure(tab.size() * sizeof(SctWlSlot))) return SCT_E_HIP;
+    HIPCHK(hipMemcpyAsync(c->wl_table.p, tab.data(), tab.size() * sizeof(SctWlSlot), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->wl_mask = mask;
+    c->wl_len_set = len_set;
+    c->wl_n = n;
+    return SCT_OK;
+}
+
+extern "C" int sct_wl_count(sct_ctx *c, const char *segs, const int64_t *offs, const uint8_t *skip, int64_t n, int64_t *counts,
+                            int64_t *first_seen) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    if (c->wl_n < 0) return fail(SCT_E_STATE, "sct_wl_count before sct_wl_set");
+    if (!counts || !first_seen || (n > 0 && !skip)) return fail(SCT_E_ARG, "sct_wl_count: NULL argument");
+    int rc = sct_upload_segments(c, segs, offs, n);
+    if (rc) return rc;
+    const size_t nk = (size_t)(c->wl_n > 0 ? c->wl_n : 1);
+    if (c->wl_counts.ensure(4 * nk) || c->wl_first.ensure(4 * nk) || c->wl_skip.ensure((size_t)(n ? n : 1))) return SCT_E_HIP;
+    hipStream_t st = c->stream;
+    c->timed.clear();
+    c->pool_used = 0;
+    HIPCHK(hipMemsetAsync(c->wl_counts.p, 0, 4 * nk, st));
+    HIPCHK(hipMemsetAsync(c->wl_first.p, 0xFF, 4 * nk, st));
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(c->wl_skip.p, skip, (size_t)n, hipMemcpyHostToDevice, st));
+        Timer t(c, "k_wl_count");
+        k_wl_count<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->wl_skip.as<uint8_t>(), n,
+                                                      c->wl_table.as<SctWlSlot>(), c->wl_mask, c->wl_len_set,
+                                                      c->wl_counts.as<uint32_t>(), c->wl_first.as<uint32_t>());
+    }
+    std::vector<uint32_t> hc(nk), hf(nk);
+    HIPCHK(hipMemcpyAsync(hc.data(), c->wl_counts.p, 4 * nk, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hf.data(), c->wl_first.p, 4 * nk, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    c->last_ms.clear();
+    for (const TimedKernel &t : c->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) c->last_ms.emplace_back(t.name, ms);
+    }
+    for (int32_t i = 0; i < c->wl_n; i++) {
+        counts[i] = hc[(size_t)i];
+        first_seen[i] = hf[(size_t)i] == 0xFFFFFFFFu ? -1 : (int64_t)hf[(size_t)i];
+    }
+    return SCT_OK;
 }

@@ -39,6 +39,8 @@ def _iolib():
         lib.sctio_count_lines.restype = i64
         lib.sctio_parse_lr.argtypes = [vp, i64, i64, vp, vp, vp, vp]
         lib.sctio_parse_lr.restype = i64
+        lib.sctio_parse_lr4.argtypes = [vp, i64, i64, vp, vp, vp]
+        lib.sctio_parse_lr4.restype = i64
         lib.sctio_render.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, i64, i64, vp]
         lib.sctio_render.restype = i64
         _io = lib
@@ -141,6 +143,24 @@ def parse_long_reads(data):
     if bad >= 0:
         raise IndexError("list index out of range")     # fewer than 4 columns on line `bad`
     return LazyNames(buf, ns, ne), segs[:int(offs[-1])].copy(), offs
+
+
+def parse_rows4(data):
+    """Rows of the extract_sr_bc_from_lr input (scTagger.py:819): exactly four tab-separated fields per line.
+    -> (na uint8[n] (1 where the third field is 'NA'), segs uint8[total], offs int64[n+1]) or None (fast path
+    not applicable).  A line with another field count raises ValueError like the reference's unpacking."""
+    if not data.isascii() or b"\r" in data:
+        return None
+    lib = _iolib()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    n = int(lib.sctio_count_lines(buf.ctypes.data, buf.size)) if buf.size else 0
+    na = np.zeros(n, dtype=np.uint8)
+    segs = np.empty(buf.size, dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    bad = lib.sctio_parse_lr4(buf.ctypes.data, buf.size, n, na.ctypes.data, segs.ctypes.data, offs.ctypes.data)
+    if bad >= 0:
+        raise ValueError("line %d does not have exactly 4 tab-separated fields" % (bad + 1))
+    return na, segs[:int(offs[-1])].copy(), offs
 
 
 def render_matches(names, segs, offs, min_e, hit_offs, hits, pattern_text, r0=0, r1=None):
