@@ -300,6 +300,7 @@ template <typename W>
 struct FilterWaveLds {
     W em[4][64];         // em[c][lane]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
     W va[64];            // bits 0..len
+    uint32_t best[64];   // smallest distance verified so far for the lane's segment
     uint32_t hcnt[64];
     uint32_t hlist[HMAX][64];
     uint32_t qk[QCAP];   // queue: global table entry index f*np + k
@@ -343,11 +344,19 @@ struct FilterWave {
             const int d = wm_anchored<E, F, W>(EmLds<W>{&L.em[0][src]}, L.va[src], tab_code[gk], t, t2);
             if (d <= E) {
                 const uint32_t pid = tab_ent[gk];
+                atomicMin(&L.best[src], (uint32_t)d);
                 const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
                 if (k < HMAX) L.hlist[k][src] = ((uint32_t)d << 30) | pid;
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+
+    // Tiering: the families are ordered so that after H1 every barcode at distance 0 has been verified, and after
+    // H1 + H2 every barcode at distance <= 1 (one half is untouched).  A segment whose minimum is already settled
+    // stops generating candidates for the later families — only the minimum tier is reported.
+    __device__ __forceinline__ void settle(uint32_t tier) {
+        if (active && L.best[lane] <= tier) active = false;
     }
 
     // append the entry indices [s, e) for every lane, one per lane and round, draining full batches as they form
@@ -454,12 +463,17 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.em[2][lane] = ~l1 & h1 & ve;
     L.em[3][lane] = l1 & h1 & ve;
     L.va[lane] = va;
+    L.best[lane] = E + 1;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     FilterWave<E, W> W_{L, tab_off, tab_ent, tab_code, np, lane, active, len, lo, hi};
     W_.template run_family<SCT_F_H1>(maxlen);
-    if (E >= 1) W_.template run_family<SCT_F_H2>(maxlen);
+    if (E >= 1) {
+        W_.settle(0);
+        W_.template run_family<SCT_F_H2>(maxlen);
+    }
     if (E >= 2) {
+        W_.settle(1);
         W_.template run_family<SCT_F_MID>(maxlen);
         W_.template run_family<SCT_F_02>(maxlen);
         W_.template run_family<SCT_F_13>(maxlen);
