@@ -291,7 +291,7 @@ k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ h
 // All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
 // needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
 // ------------------------------------------------------------------------------------------------------------
-static constexpr int QCAP = 128;  // >= 64 left over + 64 pushed per round
+static constexpr int QCAP = 256;  // >= 63 left over + 3 x 64 pushed per pass
 static constexpr int HMAX = 16;
 static constexpr int PID_BITS = 26;
 static constexpr uint32_t PID_MASK = (1u << PID_BITS) - 1u;
@@ -310,6 +310,10 @@ struct FilterWaveLds {
 __device__ __forceinline__ uint32_t lane_rank(uint64_t m) {  // number of set bits of m below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+
+struct __attribute__((packed, aligned(4))) OffPair {
+    uint32_t a, b;
+};
 
 template <typename W>
 struct EmLds {
@@ -341,7 +345,13 @@ struct FilterWave {
             const uint32_t gk = L.qk[idx], meta = L.qm[idx];
             const uint32_t src = meta & 63u;
             const int t = (int)((meta >> 8) & 63u), t2 = (int)((meta >> 16) & 63u);
+#ifdef SCT_ABLATE_VERIFY  // timing-only build: candidates are fetched but never run through the automaton
+            const uint32_t code_ = tab_code[gk];
+            asm volatile("" ::"v"(code_), "v"(t), "v"(t2));
+            const int d = E + 1;
+#else
             const int d = wm_anchored<E, F, W>(EmLds<W>{&L.em[0][src]}, L.va[src], tab_code[gk], t, t2);
+#endif
             if (d <= E) {
                 const uint32_t pid = tab_ent[gk];
                 atomicMin(&L.best[src], (uint32_t)d);
@@ -359,27 +369,42 @@ struct FilterWave {
         if (active && L.best[lane] <= tier) active = false;
     }
 
-    // append the entry indices [s, e) for every lane, one per lane and round, draining full batches as they form
+    // Append the entry indices [s, e) of every lane to the queue: up to three entries per lane and pass, placed by
+    // three ballots (entry j of a lane goes after all entries i < j of the wave and after entry j of the lanes
+    // below it); 64-entry batches are verified as they form.  Buckets longer than three entries take more passes.
     template <int F>
     __device__ __forceinline__ void push_range(uint32_t s, uint32_t e, uint32_t meta) {
         uint32_t c = e - s;
         for (;;) {
-            const bool has = c > 0;
-            const uint64_t m = __ballot(has);
-            if (m == 0) break;
-            if (has) {
-                const uint32_t idx = (tail + lane_rank(m)) & (QCAP - 1);
+            const uint64_t m1 = __ballot(c >= 1u);
+            if (m1 == 0) break;
+            const uint64_t m2 = __ballot(c >= 2u), m3 = __ballot(c >= 3u);
+            const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2), n3 = (uint32_t)__popcll(m3);
+            if (c >= 1u) {
+                const uint32_t idx = (tail + lane_rank(m1)) & (QCAP - 1);
                 L.qk[idx] = s;
                 L.qm[idx] = meta;
-                s++;
-                c--;
             }
-            tail += (uint32_t)__popcll(m);
+            if (c >= 2u) {
+                const uint32_t idx = (tail + n1 + lane_rank(m2)) & (QCAP - 1);
+                L.qk[idx] = s + 1;
+                L.qm[idx] = meta;
+            }
+            if (c >= 3u) {
+                const uint32_t idx = (tail + n1 + n2 + lane_rank(m3)) & (QCAP - 1);
+                L.qk[idx] = s + 2;
+                L.qm[idx] = meta;
+            }
+            const uint32_t took = c < 3u ? c : 3u;
+            s += took;
+            c -= took;
+            tail += n1 + n2 + n3;
             __builtin_amdgcn_wave_barrier();
-            if (tail - head >= 64) {
+            while (tail - head >= 64) {
                 verify<F>(true);
                 head += 64;
             }
+            if (m3 == 0) break;  // nobody had more than two entries: nothing is left
         }
     }
 
@@ -397,9 +422,11 @@ struct FilterWave {
             const bool v = w.active && sct_placement_valid(t2, w.len);
             uint32_t s = 0, e = 0;
             if (v) {
+                // bucket start and end are neighbouring words: one 8-byte load (4-byte aligned) instead of two
                 const uint32_t *o = w.tab_off + (size_t)F * (SCT_KEYS + 1) + sct_placement_key<F, W>(w.lo, w.hi, t, t2);
-                s = o[0] + (uint32_t)F * (uint32_t)w.np;
-                e = o[1] + (uint32_t)F * (uint32_t)w.np;
+                const OffPair op = *reinterpret_cast<const OffPair *>(o);
+                s = op.a + (uint32_t)F * (uint32_t)w.np;
+                e = op.b + (uint32_t)F * (uint32_t)w.np;
             }
             w.template flush_pending<F>();  // queue the previous placement's bucket while those loads are in flight
             w.pend = true;
