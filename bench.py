@@ -160,6 +160,8 @@ def main():
         workload_desc = "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, %d-bp segments (SURVEY 8(d))" % (
             args.workload, n_seg, n_bc, bl, max_err, args.seg_len)
         q = pmc_quote(workload_desc) if (roof and not args.force_exhaustive and args.filter_mode == 0) else None
+        if q and q.get("kernel_ms_at_profile") and abs(avg[dominant] / q["kernel_ms_at_profile"] - 1.0) > 0.15:
+            q = None   # the committed counters belong to a different build of the kernel: do not quote them
         if q:
             rd = q.get("hbm_read_bytes_x2_gfx950") or 0
             roof["traffic"] = int(rd + (q.get("hbm_write_bytes") or 0))
