@@ -102,6 +102,7 @@ int sct_sync(sct_ctx *ctx);
  *   "force_exhaustive" 0|1   skip the seed-filter kernel and scan every barcode for every segment
  *   "timing"           0|1   record HIP events around each kernel of sct_run (default 1)
  *   "filter_mode"      0|1   0 = wave-cooperative seed-filter kernel (default), 1 = lane-per-segment variant
+ *   "no_thirds"        0|1   1 = never use the 20/22-bit seed families chosen for >= 2^19 patterns at max_err <= 1
  */
 int sct_set_option(sct_ctx *ctx, const char *key, int64_t value);
 

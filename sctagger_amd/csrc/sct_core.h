@@ -106,58 +106,91 @@ SCT_HD int wm_verify(uint32_t tls, uint32_t ths, uint32_t ve, uint32_t va, uint3
 // With <= 1 edit one half is untouched (families H1, H2); with 0 edits H1 alone suffices.
 // Keys are built from the bit-planes: low byte from the lo plane, high byte from the hi plane.
 // ---------------------------------------------------------------------------------------------------
-enum { SCT_F_H1 = 0, SCT_F_H2 = 1, SCT_F_MID = 2, SCT_F_02 = 3, SCT_F_13 = 4, SCT_F_03 = 5, SCT_NFAM = 6 };
+//
+// For very large barcode sets (the 3.6 M-entry whitelist scale) 16-bit keys leave ~100 barcodes per bucket; when
+// max_err <= 1 a second scheme cuts the barcode into THIRDS of 5, 5 and 6 characters: with <= 1 edit two thirds are
+// untouched, giving the families T01 (10-mer at offset 0), T12 (11-mer at offset 5) and T02 (5-mer + 6-mer,
+// |delta| <= 1) with 20- and 22-bit keys.
+// ---------------------------------------------------------------------------------------------------
+enum {
+    SCT_F_H1 = 0, SCT_F_H2 = 1, SCT_F_MID = 2, SCT_F_02 = 3, SCT_F_13 = 4, SCT_F_03 = 5, SCT_NFAM = 6,  // quarters
+    SCT_F_T01 = 6, SCT_F_T12 = 7, SCT_F_T02 = 8, SCT_NFAM_ALL = 9                                       // thirds
+};
 #define SCT_KEYS 65536
 
-// W = uint32_t (texts up to 31 characters) or uint64_t (up to 63)
-template <typename W>
-SCT_HD uint32_t sct_key8(W lo, W hi, int t) {  // 8 consecutive characters starting at t
-    return ((uint32_t)(lo >> t) & 0xFFu) | (((uint32_t)(hi >> t) & 0xFFu) << 8);
+// A family F fixes which two pieces (A < B) of the barcode are assumed untouched.
+//   PA, LA / PB, LB  start and length of the two pieces in the barcode
+//   GAP              nominal distance of the two piece starts in the text, SLACK = pieces in between: the second
+//                    piece is looked for at t2 = t + GAP + d, |d| <= SLACK (each piece in between holds one edit)
+//   KEYCH            characters in the key (2 bits each)
+template <int F>
+struct SctFamily {
+    static constexpr bool THIRDS = F >= SCT_F_T01;
+    static constexpr int A = F == SCT_F_H1 ? 0 : F == SCT_F_H2 ? 2 : F == SCT_F_MID ? 1 : F == SCT_F_02 ? 0 : F == SCT_F_13 ? 1
+                             : F == SCT_F_03 ? 0 : F == SCT_F_T01 ? 0 : F == SCT_F_T12 ? 1 : 0;
+    static constexpr int B = F == SCT_F_H1 ? 1 : F == SCT_F_H2 ? 3 : F == SCT_F_MID ? 2 : F == SCT_F_02 ? 2 : F == SCT_F_13 ? 3
+                             : F == SCT_F_03 ? 3 : F == SCT_F_T01 ? 1 : F == SCT_F_T12 ? 2 : 2;
+    static constexpr int piece_start(int i) { return THIRDS ? (i == 0 ? 0 : i == 1 ? 5 : i == 2 ? 10 : 16) : 4 * i; }
+    static constexpr int PA = piece_start(A), LA = piece_start(A + 1) - piece_start(A);
+    static constexpr int PB = piece_start(B), LB = piece_start(B + 1) - piece_start(B);
+    static constexpr int GAP = PB - PA;
+    static constexpr int SLACK = B - A - 1;
+    static constexpr bool ADJ = B == A + 1;
+    static constexpr int KEYCH = LA + LB;
+    static constexpr uint32_t NKEYS = 1u << (2 * KEYCH);
+};
+
+// key of the text (planes lo/hi, W = uint32_t up to 31 characters, uint64_t up to 63) for pieces at t and t2:
+// the low KEYCH bits come from the lo plane, the next KEYCH bits from the hi plane
+template <int F, typename W>
+SCT_HD uint32_t sct_placement_key(W lo, W hi, int t, int t2) {
+    constexpr int LA = SctFamily<F>::LA, LB = SctFamily<F>::LB, K = SctFamily<F>::KEYCH;
+    if (SctFamily<F>::ADJ) {
+        return ((uint32_t)(lo >> t) & ((1u << K) - 1u)) | (((uint32_t)(hi >> t) & ((1u << K) - 1u)) << K);
+    } else {
+        const uint32_t l = ((uint32_t)(lo >> t) & ((1u << LA) - 1u)) | (((uint32_t)(lo >> t2) & ((1u << LB) - 1u)) << LA);
+        const uint32_t h = ((uint32_t)(hi >> t) & ((1u << LA) - 1u)) | (((uint32_t)(hi >> t2) & ((1u << LB) - 1u)) << LA);
+        return l | (h << K);
+    }
 }
-template <typename W>
-SCT_HD uint32_t sct_key44(W lo, W hi, int t, int t2) {  // 4 characters at t and 4 at t2
-    const uint32_t l = ((uint32_t)(lo >> t) & 0xFu) | (((uint32_t)(lo >> t2) & 0xFu) << 4);
-    const uint32_t h = ((uint32_t)(hi >> t) & 0xFu) | (((uint32_t)(hi >> t2) & 0xFu) << 4);
-    return l | (h << 8);
+template <int F>
+SCT_HD uint32_t sct_pattern_key_f(uint32_t plo, uint32_t phi) {
+    return sct_placement_key<F, uint32_t>(plo, phi, SctFamily<F>::PA, SctFamily<F>::PB);
 }
-// key of a 16-character barcode for family f
+// key of a 16-character barcode for family f (run-time f)
 SCT_HD uint32_t sct_pattern_key(int f, uint32_t plo, uint32_t phi) {
     switch (f) {
-    case SCT_F_H1: return sct_key8(plo, phi, 0);
-    case SCT_F_H2: return sct_key8(plo, phi, 8);
-    case SCT_F_MID: return sct_key8(plo, phi, 4);
-    case SCT_F_02: return sct_key44(plo, phi, 0, 8);
-    case SCT_F_13: return sct_key44(plo, phi, 4, 12);
-    default: return sct_key44(plo, phi, 0, 12);
+    case SCT_F_H1: return sct_pattern_key_f<SCT_F_H1>(plo, phi);
+    case SCT_F_H2: return sct_pattern_key_f<SCT_F_H2>(plo, phi);
+    case SCT_F_MID: return sct_pattern_key_f<SCT_F_MID>(plo, phi);
+    case SCT_F_02: return sct_pattern_key_f<SCT_F_02>(plo, phi);
+    case SCT_F_13: return sct_pattern_key_f<SCT_F_13>(plo, phi);
+    case SCT_F_03: return sct_pattern_key_f<SCT_F_03>(plo, phi);
+    case SCT_F_T01: return sct_pattern_key_f<SCT_F_T01>(plo, phi);
+    case SCT_F_T12: return sct_pattern_key_f<SCT_F_T12>(plo, phi);
+    default: return sct_pattern_key_f<SCT_F_T02>(plo, phi);
+    }
+}
+SCT_HD uint32_t sct_family_nkeys(int f) {
+    switch (f) {
+    case SCT_F_T01: return SctFamily<SCT_F_T01>::NKEYS;
+    case SCT_F_T12: return SctFamily<SCT_F_T12>::NKEYS;
+    case SCT_F_T02: return SctFamily<SCT_F_T02>::NKEYS;
+    default: return SCT_KEYS;
     }
 }
 
-// Seed placements.  A family F fixes which two quarters (A < B) are assumed untouched; a placement is the pair
-// of text positions (t, t2) at which those quarters are looked for:
-//   adjacent quarters (H1, MID, H2): one exact 8-mer at t (t2 = t + 4)
-//   (0,2), (1,3): t2 = t + 8 + d, |d| <= 1;   (0,3): t2 = t + 12 + d, |d| <= 2
-// A placement is valid for a text of length L iff the second quarter ends inside it: t2 + 4 <= L.
-// Kernels walk the placements wave-uniformly up to the longest length in the wave and test validity per lane;
-// the host-side completeness test (tests/host_core_check.cpp) goes through the same enumeration.
+// Seed placements: the pair of text positions (t, t2) at which the two pieces are looked for.  A placement is
+// valid for a text of length L iff the second piece ends inside it: t2 + LB <= L.  Kernels walk the placements
+// wave-uniformly up to the longest length in the wave and test validity per lane; the host-side completeness
+// test (tests/host_core_check.cpp) goes through the same enumeration.
 template <int F>
-struct SctFamily {
-    static constexpr int A = F == SCT_F_H1 ? 0 : F == SCT_F_H2 ? 2 : F == SCT_F_MID ? 1 : F == SCT_F_02 ? 0 : F == SCT_F_13 ? 1 : 0;
-    static constexpr int B = F == SCT_F_H1 ? 1 : F == SCT_F_H2 ? 3 : F == SCT_F_MID ? 2 : F == SCT_F_02 ? 2 : F == SCT_F_13 ? 3 : 3;
-    static constexpr int GAP = 4 * (B - A);               // nominal distance of the two quarters in the text
-    static constexpr int SLACK = B - A - 1;               // |d| <= number of quarters in between (each holds one edit)
-    static constexpr int MIN_ERR = B - A == 1 ? (F == SCT_F_H1 ? 0 : F == SCT_F_H2 ? 1 : 2) : 2;  // smallest E that needs F
-};
-
-SCT_HD bool sct_placement_valid(int t2, int len) { return t2 + 4 <= len; }
-template <int F, typename W>
-SCT_HD uint32_t sct_placement_key(W lo, W hi, int t, int t2) {
-    return SctFamily<F>::GAP == 4 ? sct_key8(lo, hi, t) : sct_key44(lo, hi, t, t2);
-}
+SCT_HD bool sct_placement_valid(int t2, int len) { return t2 + SctFamily<F>::LB <= len; }
 
 template <int F, typename Fn>
 SCT_HD void sct_for_each_placement(int len, Fn &&fn) {
     for (int d = -SctFamily<F>::SLACK; d <= SctFamily<F>::SLACK; d++)
-        for (int t = 0; t + SctFamily<F>::GAP + d + 4 <= len; t++) fn(t, t + SctFamily<F>::GAP + d);
+        for (int t = 0; t + SctFamily<F>::GAP + d + SctFamily<F>::LB <= len; t++) fn(t, t + SctFamily<F>::GAP + d);
 }
 
 // Every (family, key) lookup for one text (planes lo/hi), family by family.
@@ -167,6 +200,16 @@ struct SctSeedExpand {
     Fn &fn;
     SCT_HDM void operator()(int t, int t2) { fn(F, sct_placement_key<F, W>(lo, hi, t, t2)); }
 };
+// thirds scheme (max_err <= 1)
+template <int E, typename W, typename Fn>
+SCT_HD void sct_for_each_seed_thirds(W lo, W hi, int len, Fn &&fn) {
+    { SctSeedExpand<SCT_F_T01, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_T01>(len, x); }
+    if (E >= 1) {
+        { SctSeedExpand<SCT_F_T12, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_T12>(len, x); }
+        { SctSeedExpand<SCT_F_T02, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_T02>(len, x); }
+    }
+}
+// quarters scheme (max_err <= 2)
 template <int E, typename W, typename Fn>
 SCT_HD void sct_for_each_seed(W lo, W hi, int len, Fn &&fn) {
     { SctSeedExpand<SCT_F_H1, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H1>(len, x); }
@@ -235,18 +278,18 @@ SCT_HD W sct_valid_mask(int len) {
 
 template <int E, int F, typename W, typename EmFetch>
 SCT_HD int wm_anchored(EmFetch &&em, W va, uint32_t code, int t, int t2) {
-    constexpr int A = SctFamily<F>::A, B = SctFamily<F>::B;
+    using Fam = SctFamily<F>;
     WmState<E, W> s;
-    s.set(A == 0 ? ((W)1 << t) : va);
-    for (int j = 0; j < 4 * A; j++) s.step(em((code >> (2 * j)) & 3u));
-    if (B == A + 1) {
-        s.anchor(t, 8);
+    s.set(Fam::PA == 0 ? ((W)1 << t) : va);
+    for (int j = 0; j < Fam::PA; j++) s.step(em((code >> (2 * j)) & 3u));
+    if (Fam::ADJ) {
+        s.anchor(t, Fam::LA + Fam::LB);
     } else {
-        s.anchor(t, 4);
-        for (int j = 4 * (A + 1); j < 4 * B; j++) s.step(em((code >> (2 * j)) & 3u));
-        s.anchor(t2, 4);
+        s.anchor(t, Fam::LA);
+        for (int j = Fam::PA + Fam::LA; j < Fam::PB; j++) s.step(em((code >> (2 * j)) & 3u));
+        s.anchor(t2, Fam::LB);
     }
-    for (int j = 4 * (B + 1); j < 16; j++) s.step(em((code >> (2 * j)) & 3u));
+    for (int j = Fam::PB + Fam::LB; j < 16; j++) s.step(em((code >> (2 * j)) & 3u));
     return s.result(va);
 }
 

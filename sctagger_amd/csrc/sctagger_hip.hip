@@ -54,6 +54,7 @@ static int fail(int code, const char *fmt, ...) {
 
 static constexpr int K_SLOTS = 8;          // hits kept per segment by the filter kernel before it defers
 static constexpr uint32_t CNT_DEFER = 0xFFFFFFFFu;
+static constexpr int THIRDS_MIN_PATTERNS = 1 << 19;  // from here on (8 barcodes per 16-bit bucket) the thirds scheme pays
 static constexpr int META_NONACGT = 1 << 8;
 static constexpr int META_LONG = 1 << 9;   // more than 63 characters: not representable in the filter's planes
 static constexpr int PLANE_MAX = 63;       // characters kept in the packed bit-planes
@@ -293,8 +294,13 @@ k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ h
 // ------------------------------------------------------------------------------------------------------------
 static constexpr int QCAP = 256;  // >= 63 left over + 3 x 64 pushed per pass
 static constexpr int HMAX = 16;
-static constexpr int PID_BITS = 26;
-static constexpr uint32_t PID_MASK = (1u << PID_BITS) - 1u;
+static constexpr uint32_t PID_MASK = (1u << 30) - 1u;  // pattern id in a hit-list entry (2 bits of distance above it)
+
+// where each family's offsets and entries start inside the concatenated tables
+struct FamTables {
+    uint32_t off_base[SCT_NFAM_ALL];
+    uint32_t ent_base[SCT_NFAM_ALL];
+};
 
 template <typename W>
 struct FilterWaveLds {
@@ -327,7 +333,7 @@ struct FilterWave {
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
     const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
-    int np;
+    FamTables ft;
     int lane;
     bool active;
     int len;
@@ -419,14 +425,14 @@ struct FilterWave {
     struct Place {
         FilterWave &w;
         __device__ __forceinline__ void operator()(int t, int t2) {
-            const bool v = w.active && sct_placement_valid(t2, w.len);
+            const bool v = w.active && sct_placement_valid<F>(t2, w.len);
             uint32_t s = 0, e = 0;
             if (v) {
                 // bucket start and end are neighbouring words: one 8-byte load (4-byte aligned) instead of two
-                const uint32_t *o = w.tab_off + (size_t)F * (SCT_KEYS + 1) + sct_placement_key<F, W>(w.lo, w.hi, t, t2);
+                const uint32_t *o = w.tab_off + w.ft.off_base[F] + sct_placement_key<F, W>(w.lo, w.hi, t, t2);
                 const OffPair op = *reinterpret_cast<const OffPair *>(o);
-                s = op.a + (uint32_t)F * (uint32_t)w.np;
-                e = op.b + (uint32_t)F * (uint32_t)w.np;
+                s = op.a + w.ft.ent_base[F];
+                e = op.b + w.ft.ent_base[F];
             }
             w.template flush_pending<F>();  // queue the previous placement's bucket while those loads are in flight
             w.pend = true;
@@ -456,11 +462,12 @@ __device__ __forceinline__ int wave_max_i(int v) {
 
 // W = uint32_t handles the waves whose longest segment has at most 31 characters, W = uint64_t the others
 // (up to 63); both instantiations are launched over all rows and a wave leaves at once if it is not its kind.
-template <int E, typename W>
+// THIRDS = true (max_err <= 1 only) walks the 20/22-bit families of the thirds scheme instead of the quarters.
+template <int E, typename W, bool THIRDS>
 __global__ void __launch_bounds__(256)
 k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
          int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
-         const uint32_t *__restrict__ tab_code, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
+         const uint32_t *__restrict__ tab_code, FamTables ft, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
          uint32_t *__restrict__ slots, uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_scan,
          uint32_t *__restrict__ counters) {
     __shared__ FilterWaveLds<W> lds[4];
@@ -493,18 +500,27 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.best[lane] = E + 1;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    FilterWave<E, W> W_{L, tab_off, tab_ent, tab_code, np, lane, active, len, lo, hi};
-    W_.template run_family<SCT_F_H1>(maxlen);
-    if (E >= 1) {
-        W_.settle(0);
-        W_.template run_family<SCT_F_H2>(maxlen);
-    }
-    if (E >= 2) {
-        W_.settle(1);
-        W_.template run_family<SCT_F_MID>(maxlen);
-        W_.template run_family<SCT_F_02>(maxlen);
-        W_.template run_family<SCT_F_13>(maxlen);
-        W_.template run_family<SCT_F_03>(maxlen);
+    FilterWave<E, W> W_{L, tab_off, tab_ent, tab_code, ft, lane, active, len, lo, hi};
+    if (THIRDS) {
+        W_.template run_family<SCT_F_T01>(maxlen);
+        if (E >= 1) {
+            W_.settle(0);
+            W_.template run_family<SCT_F_T12>(maxlen);
+            W_.template run_family<SCT_F_T02>(maxlen);
+        }
+    } else {
+        W_.template run_family<SCT_F_H1>(maxlen);
+        if (E >= 1) {
+            W_.settle(0);
+            W_.template run_family<SCT_F_H2>(maxlen);
+        }
+        if (E >= 2) {
+            W_.settle(1);
+            W_.template run_family<SCT_F_MID>(maxlen);
+            W_.template run_family<SCT_F_02>(maxlen);
+            W_.template run_family<SCT_F_13>(maxlen);
+            W_.template run_family<SCT_F_03>(maxlen);
+        }
     }
     const uint32_t nc = active ? L.hcnt[lane] : 0u;
     LaneResult<E> res;
@@ -560,9 +576,10 @@ k_scan(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const
         if (FILL) {
             target = min_e[r];
             if (target == SCT_NO_HIT) continue;
-            // hits of the earlier slices at the same minimum come first (lane s holds slice s, n_slices <= 64)
+            // hits of the earlier slices at the same minimum come first
             uint32_t mine = 0;
-            if (lane < slice && part_best[li * n_slices + lane] == (uint32_t)target) mine = part_cnt[li * n_slices + lane];
+            for (int sl = lane; sl < slice; sl += 64)
+                if (part_best[li * n_slices + sl] == (uint32_t)target) mine += part_cnt[li * n_slices + sl];
             out_base = hit_offs[r] + wave_sum(mine);
         }
         int lane_best = max_err + 1;
@@ -874,7 +891,8 @@ struct sct_ctx {
     hipStream_t stream = nullptr;
     // barcodes
     int n_bc = 0, bl = 0, np = 0;
-    bool have_bc = false, have_tables = false;
+    bool have_bc = false, have_tables = false, have_thirds = false;
+    FamTables ft{};
     DevBuf pat, tab_off, tab_ent, tab_code;
     // segments
     int64_t n_seg = -1, seg_bytes = 0;
@@ -888,7 +906,7 @@ struct sct_ctx {
     uint32_t wl_mask = 0, wl_len_set = 0;
     int32_t wl_n = -1;
     // options
-    bool force_exhaustive = false, timing = true;
+    bool force_exhaustive = false, timing = true, no_thirds = false;
     int filter_mode = 0;  // 0 = wave-cooperative k_filter, 1 = k_filter_lane
     // timing
     std::vector<TimedKernel> timed;
@@ -990,6 +1008,7 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "force_exhaustive")) c->force_exhaustive = value != 0;
     else if (!strcmp(key, "timing")) c->timing = value != 0;
     else if (!strcmp(key, "filter_mode")) c->filter_mode = (int)value;
+    else if (!strcmp(key, "no_thirds")) c->no_thirds = value != 0;
     else return fail(SCT_E_ARG, "unknown option '%s'", key);
     return SCT_OK;
 }
@@ -1034,33 +1053,52 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
     if (c->pat.ensure(sizeof(uint2) * (size_t)(np ? np : 1))) return SCT_E_HIP;
     if (np) HIPCHK(hipMemcpyAsync(c->pat.p, pat.data(), sizeof(uint2) * (size_t)np, hipMemcpyHostToDevice, c->stream));
     c->have_tables = false;
+    c->have_thirds = false;
     if (bl == 16) {
-        // seed tables: counting sort of the pattern ids by key, per family (ids ascending inside a bucket)
-        std::vector<uint32_t> off((size_t)SCT_NFAM * (SCT_KEYS + 1), 0u), ent((size_t)SCT_NFAM * (np ? np : 1)),
-            code((size_t)SCT_NFAM * (np ? np : 1));
-        for (int f = 0; f < SCT_NFAM; f++) {
-            uint32_t *o = off.data() + (size_t)f * (SCT_KEYS + 1);
+        // seed tables: counting sort of the pattern ids by key, per family (ids ascending inside a bucket).
+        // The thirds families (20/22-bit keys) are only worth their 38 MB of offsets for very large barcode sets.
+        const bool thirds = np >= THIRDS_MIN_PATTERNS;
+        const int nfam = thirds ? SCT_NFAM_ALL : SCT_NFAM;
+        FamTables ft{};
+        size_t off_total = 0;
+        for (int f = 0; f < nfam; f++) {
+            if (off_total + sct_family_nkeys(f) + 1 > 0xFFFFFFFFull || (uint64_t)(f + 1) * (uint64_t)np > 0xFFFFFFFFull)
+                return fail(SCT_E_UNSUPPORTED, "too many barcodes for the seed tables");
+            ft.off_base[f] = (uint32_t)off_total;
+            ft.ent_base[f] = (uint32_t)((size_t)f * np);
+            off_total += (size_t)sct_family_nkeys(f) + 1;
+        }
+        std::vector<uint32_t> off(off_total, 0u), ent((size_t)nfam * (np ? np : 1)), code((size_t)nfam * (np ? np : 1));
+        std::vector<uint32_t> inter((size_t)(np ? np : 1));
+        for (int p = 0; p < np; p++) {
+            uint32_t v = 0;
+            for (int j = 0; j < 16; j++) v |= (((pat[p].x >> j) & 1u) | (((pat[p].y >> j) & 1u) << 1)) << (2 * j);
+            inter[p] = v;
+        }
+        for (int f = 0; f < nfam; f++) {
+            const uint32_t nk = sct_family_nkeys(f);
+            uint32_t *o = off.data() + ft.off_base[f];
             for (int p = 0; p < np; p++) o[sct_pattern_key(f, pat[p].x, pat[p].y) + 1]++;
-            for (int k = 0; k < SCT_KEYS; k++) o[k + 1] += o[k];
-            std::vector<uint32_t> cur(o, o + SCT_KEYS);
+            for (uint32_t k = 0; k < nk; k++) o[k + 1] += o[k];
+            std::vector<uint32_t> cur(o, o + nk);
             uint32_t *e = ent.data() + (size_t)f * np;
             uint32_t *cd = code.data() + (size_t)f * np;
             for (int p = 0; p < np; p++) {
                 const uint32_t at = cur[sct_pattern_key(f, pat[p].x, pat[p].y)]++;
                 e[at] = (uint32_t)p;
-                uint32_t inter = 0;
-                for (int j = 0; j < 16; j++) inter |= (((pat[p].x >> j) & 1u) | (((pat[p].y >> j) & 1u) << 1)) << (2 * j);
-                cd[at] = inter;
+                cd[at] = inter[p];
             }
         }
-        if (c->tab_off.ensure(off.size() * sizeof(uint32_t))) return SCT_E_HIP;
+        if (c->tab_off.ensure(off.size() * sizeof(uint32_t) + 16)) return SCT_E_HIP;
         if (c->tab_ent.ensure(ent.size() * sizeof(uint32_t))) return SCT_E_HIP;
         if (c->tab_code.ensure(code.size() * sizeof(uint32_t))) return SCT_E_HIP;
         HIPCHK(hipMemcpyAsync(c->tab_code.p, code.data(), code.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->tab_off.p, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->tab_ent.p, ent.data(), ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        c->ft = ft;
         c->have_tables = true;
+        c->have_thirds = thirds;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     c->n_bc = n;
@@ -1111,7 +1149,8 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     const int64_t n = c->n_seg;
     const int np = c->np, bl = c->bl;
     const int prefix_len = sct_prefix_len(threads);
-    const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && (int64_t)np * SCT_NFAM <= (int64_t)PID_MASK;
+    const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && np <= (int)PID_MASK;
+    const bool use_thirds = filter_ok && c->have_thirds && max_err <= 1 && c->filter_mode != 1 && !c->no_thirds;
     const size_t n1 = (size_t)(n ? n : 1);
     if (c->lo.ensure(8 * n1) || c->hi.ensure(8 * n1) || c->meta.ensure(4 * n1) || c->min_e.ensure(n1) ||
         c->cnt.ensure(4 * n1) || c->route.ensure(4 * n1) || c->list_scan.ensure(4 * n1) || c->list_dp.ensure(4 * n1) ||
@@ -1138,23 +1177,27 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         if (filter_ok) {
             Timer t(c, "k_filter");
             const unsigned g = blocks_for(n, 256);
-#define FILTER_ARGS(THIRD)                                                                                            \
+#define FILTER_ARGS(THIRD, NPARG)                                                                                     \
     c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), n, c->tab_off.as<uint32_t>(),                  \
-        c->tab_ent.as<uint32_t>(), THIRD, np, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(),  \
+        c->tab_ent.as<uint32_t>(), THIRD, NPARG, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), \
         c->slot_off.as<uint64_t>(), c->list_scan.as<int32_t>(), counters
+#define LAUNCH_WAVE(E, TH)                                                                                            \
+    do {                                                                                                              \
+        k_filter<E, uint32_t, TH><<<g, 256, 0, st>>>(FILTER_ARGS(c->tab_code.as<uint32_t>(), c->ft));                  \
+        k_filter<E, uint64_t, TH><<<g, 256, 0, st>>>(FILTER_ARGS(c->tab_code.as<uint32_t>(), c->ft));                  \
+    } while (0)
 #define LAUNCH_FILTER(E)                                                                                              \
     do {                                                                                                              \
-        if (c->filter_mode == 1) {                                                                                    \
-            k_filter_lane<E><<<g, 256, 0, st>>>(FILTER_ARGS(c->pat.as<uint2>()));                                      \
-        } else {                                                                                                      \
-            k_filter<E, uint32_t><<<g, 256, 0, st>>>(FILTER_ARGS(c->tab_code.as<uint32_t>()));                         \
-            k_filter<E, uint64_t><<<g, 256, 0, st>>>(FILTER_ARGS(c->tab_code.as<uint32_t>()));                         \
-        }                                                                                                             \
+        if (c->filter_mode == 1) k_filter_lane<E><<<g, 256, 0, st>>>(FILTER_ARGS(c->pat.as<uint2>(), np));             \
+        else LAUNCH_WAVE(E, false);                                                                                   \
     } while (0)
-            if (max_err == 0) LAUNCH_FILTER(0);
+            if (use_thirds && max_err == 0) LAUNCH_WAVE(0, true);
+            else if (use_thirds) LAUNCH_WAVE(1, true);
+            else if (max_err == 0) LAUNCH_FILTER(0);
             else if (max_err == 1) LAUNCH_FILTER(1);
             else LAUNCH_FILTER(2);
 #undef LAUNCH_FILTER
+#undef LAUNCH_WAVE
 #undef FILTER_ARGS
         }
         // remember which rows were deferred (cnt is about to be overwritten by the scan path's count pass)
@@ -1168,8 +1211,8 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     auto slices_for = [&](uint32_t rows) {
         if (rows == 0) return 1;
         const int tiles = (np + 63) / 64;
-        int64_t sl = (4096 + rows - 1) / rows;
-        if (sl > 64) sl = 64;
+        int64_t sl = (16384 + rows - 1) / rows;   // aim at 16 k waves in flight
+        if (sl > 4096) sl = 4096;
         if (sl > tiles) sl = tiles;
         return (int)(sl < 1 ? 1 : sl);
     };

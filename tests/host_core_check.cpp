@@ -107,8 +107,19 @@ static int anchored(const std::vector<int> &p, const std::vector<int> &t) {
     return b;
 }
 
+// the thirds scheme (families T01, T12, T02), complete for <= 1 edit
+template <int E, typename W = uint32_t>
+static int anchored_thirds(const std::vector<int> &p, const std::vector<int> &t) {
+    int b = anchored_family<E, SCT_F_T01, W>(p, t);
+    if (E >= 1) {
+        b = std::min(b, anchored_family<E, SCT_F_T12, W>(p, t));
+        b = std::min(b, anchored_family<E, SCT_F_T02, W>(p, t));
+    }
+    return b;
+}
+
 struct SeedHit {
-    const uint32_t *keys;  // the pattern's six family keys
+    const uint32_t *keys;  // the pattern's family keys
     bool hit = false;
     void operator()(int f, uint32_t k) {
         if (keys[f] == k) hit = true;
@@ -120,8 +131,8 @@ static bool seeds_cover(const std::vector<int> &p, const std::vector<int> &t) {
     uint64_t plo, phi, tlo, thi;
     planes(p, plo, phi);
     planes(t, tlo, thi);
-    uint32_t keys[SCT_NFAM];
-    for (int f = 0; f < SCT_NFAM; f++) keys[f] = sct_pattern_key(f, (uint32_t)plo, (uint32_t)phi);
+    uint32_t keys[SCT_NFAM_ALL];
+    for (int f = 0; f < SCT_NFAM_ALL; f++) keys[f] = sct_pattern_key(f, (uint32_t)plo, (uint32_t)phi);
     SeedHit sh;
     sh.keys = keys;
     sct_for_each_seed<E, uint32_t>((uint32_t)tlo, (uint32_t)thi, (int)t.size(), sh);
@@ -175,6 +186,8 @@ int main() {
         if (wm<0>(p, t) != std::min(want, 1)) { printf("FAIL wm0\n"); return 1; }
         if (wm<1>(p, t) != std::min(want, 2)) { printf("FAIL wm1\n"); return 1; }
         if (wm<2>(p, t) != std::min(want, 3)) { printf("FAIL wm2 want=%d got=%d n=%zu\n", want, wm<2>(p, t), t.size()); return 1; }
+        if (anchored_thirds<0>(p, t) != std::min(want, 1)) { printf("FAIL thirds0 want=%d got=%d\n", want, anchored_thirds<0>(p, t)); return 1; }
+        if (anchored_thirds<1>(p, t) != std::min(want, 2)) { printf("FAIL thirds1 want=%d got=%d n=%zu\n", want, anchored_thirds<1>(p, t), t.size()); return 1; }
         if (anchored<0>(p, t) != std::min(want, 1)) { printf("FAIL anchored0 want=%d got=%d\n", want, anchored<0>(p, t)); return 1; }
         if (anchored<1>(p, t) != std::min(want, 2)) { printf("FAIL anchored1 want=%d got=%d\n", want, anchored<1>(p, t)); return 1; }
         if (anchored<2>(p, t) != std::min(want, 3)) { printf("FAIL anchored2 want=%d got=%d n=%zu\n", want, anchored<2>(p, t), t.size()); return 1; }
@@ -202,6 +215,7 @@ int main() {
         while ((int)t.size() < n) t.push_back(rnd(alpha));
         if ((int)t.size() > 63) t.resize(63);
         const int want = brute_infix(p, t);
+        if (anchored_thirds<1, uint64_t>(p, t) != std::min(want, 2)) { printf("FAIL thirds64/1\n"); return 1; }
         if (anchored<0, uint64_t>(p, t) != std::min(want, 1)) { printf("FAIL anchored64/0\n"); return 1; }
         if (anchored<1, uint64_t>(p, t) != std::min(want, 2)) { printf("FAIL anchored64/1\n"); return 1; }
         if (anchored<2, uint64_t>(p, t) != std::min(want, 3)) { printf("FAIL anchored64/2 want=%d got=%d n=%zu\n", want, anchored<2, uint64_t>(p, t), t.size()); return 1; }
@@ -241,6 +255,7 @@ int main() {
                 if (wm<2>(p, t) != std::min(want, 3)) { printf("FAIL wm2 exhaustive\n"); return 1; }
                 if (anchored<2>(p, t) != std::min(want, 3)) { printf("FAIL anchored2 exhaustive\n"); return 1; }
                 if (anchored<1>(p, t) != std::min(want, 2)) { printf("FAIL anchored1 exhaustive\n"); return 1; }
+                if (anchored_thirds<1>(p, t) != std::min(want, 2)) { printf("FAIL thirds1 exhaustive\n"); return 1; }
                 if (s.size() <= 31 && anchored<2>(p, s) != std::min(w2 <= 2 ? w2 : 3, 3)) { printf("FAIL anchored2 bare\n"); return 1; }
                 if (s.size() <= 31 && w2 <= 2 && !seeds_cover<2>(p, s)) { printf("FAIL seeds2 bare\n"); return 1; }
                 n_texts++;

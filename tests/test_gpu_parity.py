@@ -255,6 +255,24 @@ def test_cfg5_scale_barcode_set(m):
     assert np.array_equal(a[0][:k], want[0]) and np.array_equal(a[2][:a[1][k]], want[2])
 
 
+@pytest.mark.parametrize("e", [0, 1])
+def test_thirds_scheme_equals_quarters(m, e):
+    """From 2^19 patterns on, max_err <= 1 uses the 20/22-bit 'thirds' seed families; they must agree with the
+    16-bit quarter families (option no_thirds) and with the oracle."""
+    bc = synth.make_barcodes(400_000, seed=17)
+    segs, offs = ragged(6000, bc, 17 + e, 40)
+    m.set_barcodes(bc)
+    m.set_option("no_thirds", 0)
+    a = m.match(segs, offs, e, 16)
+    m.set_option("no_thirds", 1)
+    b = m.match(segs, offs, e, 16)
+    m.set_option("no_thirds", 0)
+    util.assert_same(a, b, "thirds vs quarters")
+    k = 400
+    want = trie_oracle.match(bc, segs[:offs[k]], offs[:k + 1], e, threads=16, workers=8)
+    assert np.array_equal(a[0][:k], want[0]) and np.array_equal(a[2][:a[1][k]], want[2])
+
+
 def test_resident_three_step_api(m):
     bc = synth.make_barcodes(1000, seed=9)
     segs, offs = synth.make_segments(50000, bc, seed=9)
