@@ -216,8 +216,8 @@ class Matcher:
         return counts[:self.n_wl], first[:self.n_wl]
 
     def last_stats(self):
-        out = (ctypes.c_int64 * 4)()
-        k = self._lib.sct_last_stats(self._ctx, out, 4)
+        out = (ctypes.c_int64 * 5)()
+        k = self._lib.sct_last_stats(self._ctx, out, 5)
         if k < 0:
             self._check(k)
-        return {"filter": out[0], "exhaustive": out[1], "restricted_start": out[2], "hits": out[3]}
+        return {"filter": out[0], "exhaustive": out[1], "restricted_start": out[2], "hits": out[3], "retried": out[4]}

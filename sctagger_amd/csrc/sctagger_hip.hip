@@ -133,11 +133,12 @@ __global__ void k_pack(const uint8_t *__restrict__ segs, const int64_t *__restri
 // Per-lane result of the filter kernels: running minimum distance and up to K_SLOTS distinct pattern ids at
 // that minimum, in registers (static indexing only).  More than K_SLOTS ties defer the segment to the scan path.
 // ------------------------------------------------------------------------------------------------------------
-template <int E>
+template <int E, int KS = K_SLOTS>
 struct LaneResult {
+    static constexpr int K_SLOTS = KS;  // shadows the global default inside this struct
     int best = E + 1;
     int nh = 0;
-    uint32_t h[K_SLOTS];
+    uint32_t h[KS];
 
     __device__ __forceinline__ void init() {
         best = E + 1;
@@ -167,8 +168,9 @@ struct LaneResult {
     // list starts.  Rows with too many ties are pushed to the scan list instead.
     __device__ __forceinline__ void store(bool row, int64_t r, bool overflow, uint8_t *__restrict__ min_e,
                                           uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
-                                          uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_scan,
-                                          uint32_t *__restrict__ counters) {
+                                          uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer,
+                                          uint32_t *__restrict__ defer_count, unsigned long long *__restrict__ slot_cursor,
+                                          uint64_t slot_tag) {
         const int lane = threadIdx.x & 63;
         const bool defer = row && (overflow || nh > K_SLOTS);
         const uint32_t mine = (row && !defer) ? (uint32_t)nh : 0u;
@@ -180,12 +182,12 @@ struct LaneResult {
         }
         const uint32_t total = __shfl(inc, 63, 64);
         unsigned long long base = 0;
-        if (lane == 0 && total) base = atomicAdd(reinterpret_cast<unsigned long long *>(counters + 4), (unsigned long long)total);
+        if (lane == 0 && total) base = atomicAdd(slot_cursor, (unsigned long long)total);
         base = __shfl(base, 0, 64);
         if (!row) return;
         if (defer) {
-            const uint32_t k = atomicAdd(&counters[0], 1u);
-            list_scan[k] = (int32_t)r;
+            const uint32_t k = atomicAdd(defer_count, 1u);
+            list_defer[k] = (int32_t)r;
             cnt[r] = CNT_DEFER;
             return;
         }
@@ -210,7 +212,7 @@ struct LaneResult {
         }
         min_e[r] = (uint8_t)best;
         const uint64_t start = base + inc - mine;
-        slot_off[r] = start;
+        slot_off[r] = start | slot_tag;
 #pragma unroll
         for (int i = 0; i < K_SLOTS; i++)
             if (i < nh) slots[start + i] = h[i];
@@ -271,7 +273,8 @@ k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ h
         L.ve = L.va & ~1u;
         sct_for_each_seed<E, uint32_t>(lo, hi, len, L);
     }
-    L.res.store(active, r, false, min_e, cnt, slots, slot_off, list_scan, counters);
+    L.res.store(active, r, false, min_e, cnt, slots, slot_off, list_scan, counters + 0,
+                reinterpret_cast<unsigned long long *>(counters + 4), 0ull);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -293,7 +296,9 @@ k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ h
 // needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
 // ------------------------------------------------------------------------------------------------------------
 static constexpr int QCAP = 256;  // >= 63 left over + 3 x 64 pushed per pass
-static constexpr int HMAX = 16;
+static constexpr int HMAX = 16;        // main launch
+static constexpr int K_RETRY = 32, H_RETRY = 64;  // retry launch
+static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
 static constexpr uint32_t PID_MASK = (1u << 30) - 1u;  // pattern id in a hit-list entry (2 bits of distance above it)
 
 // where each family's offsets and entries start inside the concatenated tables
@@ -302,13 +307,14 @@ struct FamTables {
     uint32_t ent_base[SCT_NFAM_ALL];
 };
 
-template <typename W>
+template <typename W, int HM>
 struct FilterWaveLds {
+    static constexpr int HMAX = HM;
     W em[4][64];         // em[c][lane]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
     W va[64];            // bits 0..len
     uint32_t best[64];   // smallest distance verified so far for the lane's segment
     uint32_t hcnt[64];
-    uint32_t hlist[HMAX][64];
+    uint32_t hlist[HM][64];
     uint32_t qk[QCAP];   // queue: global table entry index f*np + k
     uint32_t qm[QCAP];   //        lane | t << 8 | t2 << 16
 };
@@ -327,9 +333,10 @@ struct EmLds {
     __device__ __forceinline__ W operator()(uint32_t c) const { return base[c * 64]; }
 };
 
-template <int E, typename W>
+template <int E, typename W, int HM>
 struct FilterWave {
-    FilterWaveLds<W> &L;
+    static constexpr int HMAX = HM;
+    FilterWaveLds<W, HM> &L;
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
     const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
@@ -463,20 +470,28 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // W = uint32_t handles the waves whose longest segment has at most 31 characters, W = uint64_t the others
 // (up to 63); both instantiations are launched over all rows and a wave leaves at once if it is not its kind.
 // THIRDS = true (max_err <= 1 only) walks the 20/22-bit families of the thirds scheme instead of the quarters.
-template <int E, typename W, bool THIRDS>
+// KS / HM: ties kept per segment / verified matches kept per segment before the row is deferred.  The main launch
+// (KS 8, HM 16) covers all rows; rows it defers are retried by a launch with KS 32, HM 64 over the list `rows`
+// (one lane per listed row), and only what that launch defers again goes to the exhaustive scan.
+template <int E, typename W, bool THIRDS, int KS, int HM>
 __global__ void __launch_bounds__(256)
 k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
-         int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
-         const uint32_t *__restrict__ tab_code, FamTables ft, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
-         uint32_t *__restrict__ slots, uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_scan,
-         uint32_t *__restrict__ counters) {
-    __shared__ FilterWaveLds<W> lds[4];
-    FilterWaveLds<W> &L = lds[threadIdx.x >> 6];
+         int64_t n, const int32_t *__restrict__ rows, const uint32_t *__restrict__ tab_off,
+         const uint32_t *__restrict__ tab_ent, const uint32_t *__restrict__ tab_code, FamTables ft,
+         uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
+         uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer, uint32_t *__restrict__ defer_count,
+         unsigned long long *__restrict__ slot_cursor, uint64_t slot_tag) {
+    __shared__ FilterWaveLds<W, HM> lds[4];
+    FilterWaveLds<W, HM> &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = r < n;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = gid < n;
+    int64_t r = gid;
     int len = 0;
-    if (active) active = cnt[r] != CNT_DEFER;  // routed to a scan path by k_pack
+    if (active) {
+        if (rows) r = rows[gid];                       // a retried row: listed explicitly
+        else active = cnt[r] != CNT_DEFER;             // routed to a scan path by k_pack
+    }
     if (active) {
         len = (int)(meta_in[r] & 0xFF);
         active = len >= 16 - E;  // shorter rows were finished by k_pack
@@ -500,7 +515,7 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.best[lane] = E + 1;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    FilterWave<E, W> W_{L, tab_off, tab_ent, tab_code, ft, lane, active, len, lo, hi};
+    FilterWave<E, W, HM> W_{L, tab_off, tab_ent, tab_code, ft, lane, active, len, lo, hi};
     if (THIRDS) {
         W_.template run_family<SCT_F_T01>(maxlen);
         if (E >= 1) {
@@ -523,14 +538,14 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
         }
     }
     const uint32_t nc = active ? L.hcnt[lane] : 0u;
-    LaneResult<E> res;
+    LaneResult<E, KS> res;
     res.init();
-    const uint32_t lim = nc < HMAX ? nc : HMAX;
+    const uint32_t lim = nc < (uint32_t)HM ? nc : (uint32_t)HM;
     for (uint32_t k = 0; k < lim; k++) {
         const uint32_t v = L.hlist[k][lane];
         res.add((int)(v >> 30), v & PID_MASK);
     }
-    res.store(active, r, nc > HMAX, min_e, cnt, slots, slot_off, list_scan, counters);
+    res.store(active, r, nc > (uint32_t)HM, min_e, cnt, slots, slot_off, list_defer, defer_count, slot_cursor, slot_tag);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -779,6 +794,7 @@ __global__ void __launch_bounds__(256) k_offsets(const uint32_t *__restrict__ cn
 
 // filter path: slots -> CSR
 __global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ slots,
+                                               const uint32_t *__restrict__ slots_retry,
                                                const uint64_t *__restrict__ slot_off, const int64_t *__restrict__ hit_offs,
                                                const uint32_t *__restrict__ route_cnt, int64_t n, uint32_t *__restrict__ hits) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -788,7 +804,9 @@ __global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, 
     const int64_t o = hit_offs[r];
     if (c == 0) return;
     const uint64_t so = slot_off[r];
-    for (uint32_t i = 0; i < c; i++) hits[o + i] = slots[so + i];
+    const uint32_t *src = (so & SLOT_TAG_RETRY) ? slots_retry : slots;
+    const uint64_t at = so & ~SLOT_TAG_RETRY;
+    for (uint32_t i = 0; i < c; i++) hits[o + i] = src[at + i];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -898,7 +916,7 @@ struct sct_ctx {
     int64_t n_seg = -1, seg_bytes = 0;
     DevBuf segs, offs;
     // work / results
-    DevBuf lo, hi, meta, min_e, cnt, route, slots, slot_off, list_scan, list_dp, counters, hit_offs, sums, total, hits, part_best, part_cnt;
+    DevBuf lo, hi, meta, min_e, cnt, route, slots, slots_retry, list_retry, slot_off, list_scan, list_dp, counters, hit_offs, sums, total, hits, part_best, part_cnt;
     int64_t n_hits = 0;
     bool have_result = false;
     // whitelist dictionary (extract_sr_bc_from_lr)
@@ -913,7 +931,7 @@ struct sct_ctx {
     std::vector<std::pair<const char *, float>> last_ms;
     std::vector<hipEvent_t> pool;
     size_t pool_used = 0;
-    int64_t stats[4] = {0, 0, 0, 0};
+    int64_t stats[5] = {0, 0, 0, 0, 0};
 
     hipEvent_t ev() {
         if (pool_used == pool.size()) {
@@ -988,7 +1006,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
-                      &c->cnt, &c->route, &c->slots, &c->slot_off, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
+                      &c->cnt, &c->route, &c->slots, &c->slots_retry, &c->list_retry, &c->slot_off, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
                       &c->total, &c->hits, &c->part_best, &c->part_cnt, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
@@ -1156,7 +1174,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         c->cnt.ensure(4 * n1) || c->route.ensure(4 * n1) || c->list_scan.ensure(4 * n1) || c->list_dp.ensure(4 * n1) ||
         c->counters.ensure(64) || c->hit_offs.ensure(8 * (n1 + 1)) || c->total.ensure(8))
         return SCT_E_HIP;
-    if (filter_ok && (c->slots.ensure(4 * n1 * K_SLOTS) || c->slot_off.ensure(8 * n1))) return SCT_E_HIP;
+    if (filter_ok && (c->slots.ensure(4 * n1 * K_SLOTS) || c->slot_off.ensure(8 * n1) || c->list_retry.ensure(4 * n1))) return SCT_E_HIP;
     const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (c->sums.ensure(8 * (size_t)(nb ? nb : 1))) return SCT_E_HIP;
     c->timed.clear();
@@ -1177,18 +1195,23 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         if (filter_ok) {
             Timer t(c, "k_filter");
             const unsigned g = blocks_for(n, 256);
-#define FILTER_ARGS(THIRD, NPARG)                                                                                     \
+#define LANE_ARGS                                                                                                     \
     c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), n, c->tab_off.as<uint32_t>(),                  \
-        c->tab_ent.as<uint32_t>(), THIRD, NPARG, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), \
-        c->slot_off.as<uint64_t>(), c->list_scan.as<int32_t>(), counters
+        c->tab_ent.as<uint32_t>(), c->pat.as<uint2>(), np, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(),              \
+        c->slots.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_scan.as<int32_t>(), counters
+#define WAVE_ARGS                                                                                                     \
+    c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), n, (const int32_t *)nullptr,                   \
+        c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->ft, c->min_e.as<uint8_t>(), \
+        c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_retry.as<int32_t>(),       \
+        counters + 2, reinterpret_cast<unsigned long long *>(counters + 4), 0ull
 #define LAUNCH_WAVE(E, TH)                                                                                            \
     do {                                                                                                              \
-        k_filter<E, uint32_t, TH><<<g, 256, 0, st>>>(FILTER_ARGS(c->tab_code.as<uint32_t>(), c->ft));                  \
-        k_filter<E, uint64_t, TH><<<g, 256, 0, st>>>(FILTER_ARGS(c->tab_code.as<uint32_t>(), c->ft));                  \
+        k_filter<E, uint32_t, TH, K_SLOTS, HMAX><<<g, 256, 0, st>>>(WAVE_ARGS);                                        \
+        k_filter<E, uint64_t, TH, K_SLOTS, HMAX><<<g, 256, 0, st>>>(WAVE_ARGS);                                        \
     } while (0)
 #define LAUNCH_FILTER(E)                                                                                              \
     do {                                                                                                              \
-        if (c->filter_mode == 1) k_filter_lane<E><<<g, 256, 0, st>>>(FILTER_ARGS(c->pat.as<uint2>(), np));             \
+        if (c->filter_mode == 1) k_filter_lane<E><<<g, 256, 0, st>>>(LANE_ARGS);                                       \
         else LAUNCH_WAVE(E, false);                                                                                   \
     } while (0)
             if (use_thirds && max_err == 0) LAUNCH_WAVE(0, true);
@@ -1198,15 +1221,47 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
             else LAUNCH_FILTER(2);
 #undef LAUNCH_FILTER
 #undef LAUNCH_WAVE
-#undef FILTER_ARGS
+#undef WAVE_ARGS
+#undef LANE_ARGS
         }
-        // remember which rows were deferred (cnt is about to be overwritten by the scan path's count pass)
-        HIPCHK(hipMemcpyAsync(c->route.p, c->cnt.p, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
     }
-    // host sync #1: how many rows go through the scan paths (normally none or a handful)
+    // host sync #1: how many rows go through the scan paths (normally none or a handful) / are to be retried
     uint32_t hc[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(hc, c->counters.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const int64_t n_retried = hc[2];
+    if (n > 0 && filter_ok && c->filter_mode != 1 && hc[2] > 0) {
+        // rows with more ties / verified matches than the main launch keeps: once more with larger lists
+        const int64_t nr = hc[2];
+        if (c->slots_retry.ensure(4 * (size_t)nr * K_RETRY)) return SCT_E_HIP;
+        Timer t(c, "k_filter_retry");
+        const unsigned g = blocks_for(nr, 256);
+#define RETRY_ARGS                                                                                                    \
+    c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), nr, c->list_retry.as<int32_t>(),               \
+        c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->ft, c->min_e.as<uint8_t>(), \
+        c->cnt.as<uint32_t>(), c->slots_retry.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_scan.as<int32_t>(),  \
+        counters + 0, reinterpret_cast<unsigned long long *>(counters + 6), SLOT_TAG_RETRY
+#define LAUNCH_RETRY(E, TH)                                                                                           \
+    do {                                                                                                              \
+        k_filter<E, uint32_t, TH, K_RETRY, H_RETRY><<<g, 256, 0, st>>>(RETRY_ARGS);                                    \
+        k_filter<E, uint64_t, TH, K_RETRY, H_RETRY><<<g, 256, 0, st>>>(RETRY_ARGS);                                    \
+    } while (0)
+        if (use_thirds && max_err == 0) LAUNCH_RETRY(0, true);
+        else if (use_thirds) LAUNCH_RETRY(1, true);
+        else if (max_err == 0) LAUNCH_RETRY(0, false);
+        else if (max_err == 1) LAUNCH_RETRY(1, false);
+        else LAUNCH_RETRY(2, false);
+#undef LAUNCH_RETRY
+#undef RETRY_ARGS
+    }
+    if (n > 0) {
+        // remember which rows are (still) deferred: cnt is about to be overwritten by the scan path's count pass
+        HIPCHK(hipMemcpyAsync(c->route.p, c->cnt.p, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
+        if (hc[2] > 0) {  // the retry may have deferred rows to the scan list
+            HIPCHK(hipMemcpyAsync(hc, c->counters.p, 16, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
     // a short list is cut into pattern slices so that the whole chip works on it; a long one needs no slicing
     auto slices_for = [&](uint32_t rows) {
         if (rows == 0) return 1;
@@ -1263,7 +1318,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     if (n > 0 && total > 0) {
         if (filter_ok) {
             Timer t(c, "k_fill");
-            k_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->hit_offs.as<int64_t>(),
+            k_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->slots_retry.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->hit_offs.as<int64_t>(),
                                                        c->route.as<uint32_t>(), n, c->hits.as<uint32_t>());
         }
         if (hc[0]) {
@@ -1291,6 +1346,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     c->stats[1] = hc[0];
     c->stats[2] = hc[1];
     c->stats[3] = (int64_t)total;
+    c->stats[4] = n_retried;
     c->have_result = true;
     if (n_hits_out) *n_hits_out = (int64_t)total;
     return SCT_OK;
@@ -1344,8 +1400,8 @@ extern "C" int sct_last_timing(sct_ctx *c, const char **names, float *ms, int ca
 
 extern "C" int sct_last_stats(sct_ctx *c, int64_t *out, int cap) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
-    for (int i = 0; i < 4 && i < cap; i++) out[i] = c->stats[i];
-    return 4;
+    for (int i = 0; i < 5 && i < cap; i++) out[i] = c->stats[i];
+    return 5;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -138,6 +138,30 @@ def test_many_ties_defer_to_the_scan_path(m):
     assert m.last_stats()["exhaustive"] >= 1
 
 
+def test_moderate_ties_are_retried_not_scanned(m):
+    """9..32 ties: handled by the filter's retry launch (larger lists), not by the exhaustive scan."""
+    rng = np.random.default_rng(6)
+    core = synth.make_barcodes(1, seed=61)[0]
+    bc = synth.make_barcodes(2000, seed=62)
+    for i in range(20):                                  # 20 barcodes one substitution away from `core`
+        b = core.copy()
+        b[i % 16] = ord("ACGT"[(int("ACGT".index(chr(b[i % 16]))) + 1 + i // 16) % 4])
+        bc[100 + i] = b
+    segs = np.concatenate([np.frombuffer(b"TCT", np.uint8), core, np.frombuffer(b"GGA", np.uint8)])
+    base, bo = synth.make_segments(500, bc, seed=63)
+    segs_all = np.concatenate([base, segs])
+    offs = np.concatenate([bo, [bo[-1] + segs.size]]).astype(np.int64)
+    want = trie_oracle.match(bc, segs_all, offs, 2, threads=1, workers=4)
+    assert 8 < np.diff(want[1])[-1] <= 32
+    a, b = run_both(m, bc, segs_all, offs, 2)
+    util.assert_same(a, want, "filter path")
+    util.assert_same(b, want, "exhaustive path")
+    m.set_barcodes(bc)
+    m.match(segs_all, offs, 2, 1)
+    st = m.last_stats()
+    assert st["retried"] >= 1 and st["exhaustive"] == 0
+
+
 def test_empty_and_degenerate_inputs(m):
     bc = synth.make_barcodes(50, seed=7)
     m.set_barcodes(bc)
