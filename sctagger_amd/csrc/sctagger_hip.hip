@@ -295,8 +295,14 @@ k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ h
 // All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
 // needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
 // ------------------------------------------------------------------------------------------------------------
-static constexpr int QCAP = 256;  // >= 63 left over + 3 x 64 pushed per pass
-static constexpr int HMAX = 16;        // main launch
+#ifndef SCT_PUSH_PER_PASS
+#define SCT_PUSH_PER_PASS 1  // entries a lane appends per pass (1 or 3; measured equal, 1 needs half the queue)
+#endif
+static constexpr int QCAP = SCT_PUSH_PER_PASS == 3 ? 256 : 128;  // >= 63 left over + 64 x entries pushed per pass
+#ifndef SCT_HMAX
+#define SCT_HMAX 8  // with the tiers a settled segment stops early, so few rows collect more than 8 verified matches
+#endif
+static constexpr int HMAX = SCT_HMAX;  // main launch
 static constexpr int K_RETRY = 32, H_RETRY = 64;  // retry launch
 static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
 static constexpr uint32_t PID_MASK = (1u << 30) - 1u;  // pattern id in a hit-list entry (2 bits of distance above it)
@@ -312,6 +318,10 @@ struct FilterWaveLds {
     static constexpr int HMAX = HM;
     W em[4][64];         // em[c][lane]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
     W va[64];            // bits 0..len
+    W lo[64], hi[64];    // the segments' bit-planes (lookup lanes read the planes of the segment they work for)
+    uint32_t slen[64];   // and lengths
+    uint32_t alist[64];  // lanes whose segment still generates candidates, compacted
+    uint16_t ptab[sizeof(W) == 4 ? 128 : 320];  // this family's placements for the longest segment: t | t2 << 8
     uint32_t best[64];   // smallest distance verified so far for the lane's segment
     uint32_t hcnt[64];
     uint32_t hlist[HM][64];
@@ -346,10 +356,6 @@ struct FilterWave {
     int len;
     W lo, hi;
     uint32_t head = 0, tail = 0;  // wave-uniform
-    // bucket range of the placement whose offsets were loaded last; pushed when the NEXT placement arrives, so
-    // that the offset loads of a placement overlap the queue work of the one before
-    bool pend = false;  // wave-uniform
-    uint32_t ps = 0, pe = 0, pmeta = 0;
 
     template <int F>
     __device__ __forceinline__ void verify(bool take) {
@@ -388,6 +394,27 @@ struct FilterWave {
     template <int F>
     __device__ __forceinline__ void push_range(uint32_t s, uint32_t e, uint32_t meta) {
         uint32_t c = e - s;
+#if SCT_PUSH_PER_PASS == 1
+        for (;;) {
+            const bool has = c > 0;
+            const uint64_t m = __ballot(has);
+            if (m == 0) break;
+            if (has) {
+                const uint32_t idx = (tail + lane_rank(m)) & (QCAP - 1);
+                L.qk[idx] = s;
+                L.qm[idx] = meta;
+                s++;
+                c--;
+            }
+            tail += (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (tail - head >= 64) {
+                verify<F>(true);
+                head += 64;
+            }
+        }
+        return;
+#endif
         for (;;) {
             const uint64_t m1 = __ballot(c >= 1u);
             if (m1 == 0) break;
@@ -421,39 +448,69 @@ struct FilterWave {
         }
     }
 
-    template <int F>
-    __device__ __forceinline__ void flush_pending() {
-        if (!pend) return;
-        push_range<F>(ps, pe, pmeta);
-        pend = false;
-    }
-
-    template <int F>
-    struct Place {
-        FilterWave &w;
-        __device__ __forceinline__ void operator()(int t, int t2) {
-            const bool v = w.active && sct_placement_valid<F>(t2, w.len);
-            uint32_t s = 0, e = 0;
-            if (v) {
-                // bucket start and end are neighbouring words: one 8-byte load (4-byte aligned) instead of two
-                const uint32_t *o = w.tab_off + w.ft.off_base[F] + sct_placement_key<F, W>(w.lo, w.hi, t, t2);
-                const OffPair op = *reinterpret_cast<const OffPair *>(o);
-                s = op.a + w.ft.ent_base[F];
-                e = op.b + w.ft.ent_base[F];
-            }
-            w.template flush_pending<F>();  // queue the previous placement's bucket while those loads are in flight
-            w.pend = true;
-            w.ps = s;
-            w.pe = e;
-            w.pmeta = (uint32_t)w.lane | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
-        }
-    };
-
+    // One family.  The lookups are spread over the lanes as (active segment, placement) PAIRS: with A segments of
+    // the wave still generating candidates, G = 64 / A placements are looked up per pass (lane = g * A + a works on
+    // placement p0 + g for the a-th active segment), so the wave-uniform cost of a pass is shared by 64 lookups
+    // even when most segments have settled.  The placements of the family for the longest segment of the wave are
+    // tabulated in LDS once; a lane skips those its own segment is too short for.  The bucket range of a pass is
+    // queued while the loads of the next pass are in flight.
     template <int F>
     __device__ __forceinline__ void run_family(int maxlen) {
-        Place<F> pl{*this};
-        sct_for_each_placement<F>(maxlen, pl);
-        flush_pending<F>();
+        using Fam = SctFamily<F>;
+        const uint64_t am = __ballot(active);
+        if (am == 0) return;
+        const int A = (int)__popcll(am);
+        if (active) L.alist[lane_rank(am)] = (uint32_t)lane;
+        // placement table
+        int P = 0;
+#pragma unroll
+        for (int d = -Fam::SLACK; d <= Fam::SLACK; d++) {
+            const int c = maxlen - Fam::GAP - d - Fam::LB + 1;
+            if (c > 0) {
+                for (int t = lane; t < c; t += 64) L.ptab[P + t] = (uint16_t)(t | ((t + Fam::GAP + d) << 8));
+                P += c;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (P == 0) return;
+        const int G = 64 / A;
+        const uint32_t inv = 65536u / (uint32_t)A + 1u;           // lane / A for lane < 64 (checked for every A <= 64)
+        const int g = (int)(((uint32_t)lane * inv) >> 16), a = lane - g * A;
+        const bool worker = g < G;
+        uint32_t sl = 0;
+        W slo = 0, shi = 0;
+        int slen = 0;
+        if (worker) {
+            sl = L.alist[a];
+            slo = L.lo[sl];
+            shi = L.hi[sl];
+            slen = (int)L.slen[sl];
+        }
+        const uint32_t *off = tab_off + ft.off_base[F];
+        const uint32_t ebase = ft.ent_base[F];
+        uint32_t ps = 0, pe = 0, pmeta = 0;  // the pass whose loads were issued last
+        bool pend = false;
+        for (int p0 = 0; p0 < P; p0 += G) {
+            const int p = p0 + g;
+            uint32_t s = 0, e = 0, meta = 0;
+            if (worker && p < P) {
+                const uint32_t tt = L.ptab[p];
+                const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
+                if (sct_placement_valid<F>(t2, slen)) {
+                    // bucket start and end are neighbouring words: one 8-byte load (4-byte aligned)
+                    const OffPair op = *reinterpret_cast<const OffPair *>(off + sct_placement_key<F, W>(slo, shi, t, t2));
+                    s = op.a + ebase;
+                    e = op.b + ebase;
+                    meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
+                }
+            }
+            if (pend) push_range<F>(ps, pe, pmeta);
+            pend = true;
+            ps = s;
+            pe = e;
+            pmeta = meta;
+        }
+        if (pend) push_range<F>(ps, pe, pmeta);
         if (tail != head) {  // the family's last, partial batch
             verify<F>((uint32_t)lane < tail - head);
             head = tail;
@@ -472,8 +529,8 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // THIRDS = true (max_err <= 1 only) walks the 20/22-bit families of the thirds scheme instead of the quarters.
 // KS / HM: ties kept per segment / verified matches kept per segment before the row is deferred.  The main launch
 // (KS 8, HM 16) covers all rows; rows it defers are retried by a launch with KS 32, HM 64 over the list `rows`
-// (one lane per listed row), and only what that launch defers again goes to the exhaustive scan.
-template <int E, typename W, bool THIRDS, int KS, int HM>
+// (16 listed rows per wave), and only what that launch defers again goes to the exhaustive scan.
+template <int E, typename W, bool THIRDS, int KS, int HM, int RPW>
 __global__ void __launch_bounds__(256)
 k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
          int64_t n, const int32_t *__restrict__ rows, const uint32_t *__restrict__ tab_off,
@@ -484,8 +541,10 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     __shared__ FilterWaveLds<W, HM> lds[4];
     FilterWaveLds<W, HM> &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = gid < n;
+    // RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows, so that the pair
+    // compaction of run_family spreads each row's lookups over four lanes and the few retried rows finish sooner
+    const int64_t gid = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * RPW + lane;
+    bool active = lane < RPW && gid < n;
     int64_t r = gid;
     int len = 0;
     if (active) {
@@ -512,6 +571,9 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.em[2][lane] = ~l1 & h1 & ve;
     L.em[3][lane] = l1 & h1 & ve;
     L.va[lane] = va;
+    L.lo[lane] = lo;
+    L.hi[lane] = hi;
+    L.slen[lane] = (uint32_t)len;
     L.best[lane] = E + 1;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -1206,8 +1268,8 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         counters + 2, reinterpret_cast<unsigned long long *>(counters + 4), 0ull
 #define LAUNCH_WAVE(E, TH)                                                                                            \
     do {                                                                                                              \
-        k_filter<E, uint32_t, TH, K_SLOTS, HMAX><<<g, 256, 0, st>>>(WAVE_ARGS);                                        \
-        k_filter<E, uint64_t, TH, K_SLOTS, HMAX><<<g, 256, 0, st>>>(WAVE_ARGS);                                        \
+        k_filter<E, uint32_t, TH, K_SLOTS, HMAX, 64><<<g, 256, 0, st>>>(WAVE_ARGS);                                    \
+        k_filter<E, uint64_t, TH, K_SLOTS, HMAX, 64><<<g, 256, 0, st>>>(WAVE_ARGS);                                    \
     } while (0)
 #define LAUNCH_FILTER(E)                                                                                              \
     do {                                                                                                              \
@@ -1235,7 +1297,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         const int64_t nr = hc[2];
         if (c->slots_retry.ensure(4 * (size_t)nr * K_RETRY)) return SCT_E_HIP;
         Timer t(c, "k_filter_retry");
-        const unsigned g = blocks_for(nr, 256);
+        const unsigned g = blocks_for(nr, 64);  // 4 waves x 16 rows per block
 #define RETRY_ARGS                                                                                                    \
     c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), nr, c->list_retry.as<int32_t>(),               \
         c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->ft, c->min_e.as<uint8_t>(), \
@@ -1243,8 +1305,8 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         counters + 0, reinterpret_cast<unsigned long long *>(counters + 6), SLOT_TAG_RETRY
 #define LAUNCH_RETRY(E, TH)                                                                                           \
     do {                                                                                                              \
-        k_filter<E, uint32_t, TH, K_RETRY, H_RETRY><<<g, 256, 0, st>>>(RETRY_ARGS);                                    \
-        k_filter<E, uint64_t, TH, K_RETRY, H_RETRY><<<g, 256, 0, st>>>(RETRY_ARGS);                                    \
+        k_filter<E, uint32_t, TH, K_RETRY, H_RETRY, 16><<<g, 256, 0, st>>>(RETRY_ARGS);                                \
+        k_filter<E, uint64_t, TH, K_RETRY, H_RETRY, 16><<<g, 256, 0, st>>>(RETRY_ARGS);                                \
     } while (0)
         if (use_thirds && max_err == 0) LAUNCH_RETRY(0, true);
         else if (use_thirds) LAUNCH_RETRY(1, true);
