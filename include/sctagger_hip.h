@@ -136,6 +136,23 @@ int sct_wl_set(sct_ctx *ctx, const char *keys, const int32_t *key_lens, int32_t 
 int sct_wl_count(sct_ctx *ctx, const char *segs, const int64_t *offs, const uint8_t *skip, int64_t n, int64_t *counts,
                  int64_t *first_seen);
 
+/*
+ * --- extract_lr_bc (reference scTagger.py:176-196) ----------------------------
+ * The reference aligns the short-read adapter and its reverse complement to every long read with the third-party
+ * edlib (`edlib.align(adapter, read, 'HW', 'locations')`) and keeps the strictly better strand.
+ *
+ * sct_adapter_align   adapter: m raw bytes (1..32); reads/offs: CSR of the n reads (bytes < 128).  Per read:
+ *     strand[r]  0 = both strands equally good (the reference's 'NA'), 1 = '+', 2 = '-'
+ *     dist[r]    the edit distance of the winning strand, -1 when strand is 0
+ *     locations  CSR loc_offs[n+1] into *locs (library-allocated, release with sct_free_locs): for '+' every
+ *                end position (0-based, inclusive) at which the adapter reaches that distance; for '-' for every
+ *                such end position of the reverse complement the start of the longest optimal alignment ending
+ *                there, stored as start - len(read) - 1 exactly like the reference (:189); ascending by end.
+ */
+int sct_adapter_align(sct_ctx *ctx, const char *adapter, int32_t m, const char *reads, const int64_t *offs, int64_t n,
+                      int8_t *strand, int32_t *dist, int64_t *loc_offs, int32_t **locs, int64_t *n_locs);
+void sct_free_locs(sct_ctx *ctx, int32_t *locs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ MAX_BL = 32
 EXPORTS = (
     "sct_device_count", "sct_create", "sct_destroy", "sct_last_error", "sct_prefix_len", "sct_set_barcodes",
     "sct_match", "sct_free_hits", "sct_upload_segments", "sct_run", "sct_download", "sct_sync", "sct_set_option",
-    "sct_last_timing", "sct_last_stats", "sct_wl_set", "sct_wl_count",
+    "sct_last_timing", "sct_last_stats", "sct_wl_set", "sct_wl_count", "sct_adapter_align", "sct_free_locs",
 )
 
 _lib = None
@@ -61,6 +61,9 @@ def load():
     lib.sct_last_stats.argtypes = [vp, ctypes.POINTER(i64), ctypes.c_int]
     lib.sct_wl_set.argtypes = [vp, vp, vp, i32]
     lib.sct_wl_count.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+    lib.sct_adapter_align.argtypes = [vp, ctypes.c_char_p, i32, vp, vp, i64, vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    lib.sct_free_locs.argtypes = [vp, vp]
+    lib.sct_free_locs.restype = None
     _lib = lib
     return lib
 
@@ -214,6 +217,25 @@ class Matcher:
         first = np.zeros(max(self.n_wl, 1), dtype=np.int64)
         self._check(self._lib.sct_wl_count(self._ctx, _ptr(segs), _ptr(offs), _ptr(skip), offs.size - 1, _ptr(counts), _ptr(first)))
         return counts[:self.n_wl], first[:self.n_wl]
+
+    def adapter_align(self, adapter, reads, offs):
+        """sct_adapter_align (reference scTagger.py:176-196).
+        -> (strand int8[n] 0/1/2 = NA/+/-, dist int32[n], loc_offs int64[n+1], locs int32[total])."""
+        reads, offs = self._csr(reads, offs)
+        n = offs.size - 1
+        a = adapter.encode("latin-1") if isinstance(adapter, str) else bytes(adapter)
+        strand = np.zeros(max(n, 1), dtype=np.int8)
+        dist = np.zeros(max(n, 1), dtype=np.int32)
+        loc_offs = np.zeros(n + 1, dtype=np.int64)
+        lp = ctypes.c_void_p()
+        nl = ctypes.c_int64()
+        self._check(self._lib.sct_adapter_align(self._ctx, a, len(a), _ptr(reads), _ptr(offs), n, _ptr(strand), _ptr(dist),
+                                                _ptr(loc_offs), ctypes.byref(lp), ctypes.byref(nl)))
+        try:
+            locs = np.ctypeslib.as_array(ctypes.cast(lp, ctypes.POINTER(ctypes.c_int32)), shape=(max(nl.value, 1),))[:nl.value].copy()
+        finally:
+            self._lib.sct_free_locs(self._ctx, lp)
+        return strand[:n], dist[:n], loc_offs, locs
 
     def last_stats(self):
         out = (ctypes.c_int64 * 5)()

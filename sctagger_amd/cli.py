@@ -9,7 +9,7 @@ import sys
 
 from . import match_trie as _mt
 
-OTHER_SUBCOMMANDS = ("extract_lr_bc", "extract_sr_bc")
+OTHER_SUBCOMMANDS = ("extract_sr_bc",)
 
 
 def parse_args(argv=None):
@@ -31,6 +31,17 @@ def parse_args(argv=None):
                    help="Path to output file; gzipped if it ends with 'gz'. Default: stdout")
     p.add_argument("--devices", type=int, nargs="+", default=None, help="GPU ids to shard the segments over. Default: 0")
     p.add_argument("--gzip-level", type=int, default=4, help="gzip level of the output (the reference writes level 9; the bytes after decompression are identical). Default: 4")
+    l = subparsers.add_parser("extract_lr_bc")             # reference scTagger.py:25-49
+    l.add_argument("-r", "--reads", nargs="+", type=str, required=True, help="Space separated paths to reads in FASTQ")
+    l.add_argument("-g", "--ranges", nargs="+", type=str, default=list(),
+                   help="Ranges where the SR adapter should be found, e.g. f20:40 r1:30 (1-indexed, inclusive). Default: detect from data")
+    l.add_argument("-z", "--gzipped", dest="gzipped", action="store_true", help="Input is gzipped (default: by the .gz suffix)")
+    l.add_argument("-t", "--threads", default=1, type=int, help="Accepted for compatibility; must be positive. Default: 1")
+    l.add_argument("-sa", "--short-read-adapter", type=str, default="CTACACGACGCTCTTCCGATCT",
+                   help="Short-read adapter. Default: CTACACGACGCTCTTCCGATCT")
+    l.add_argument("-o", "--outfile", type=str, default=None, help="Path to output file (gzipped). Default: stdout")
+    l.add_argument("-p", "--plotfile", type=str, default=None, help="Accepted for compatibility; the plot is not produced")
+    l.add_argument("--num-bp-after", type=int, default=20, help="Bases after the end of the adapter alignment to output. Default: 20")
     q = subparsers.add_parser("extract_sr_bc_from_lr")     # reference scTagger.py:67-79
     q.add_argument("-i", "--input", type=str, required=True, help="Input TSV file generated from extract_lr_bc step")
     q.add_argument("-o", "--outfile", type=str, default=None, help="Path to output file (gzipped). Default: STDOUT")
@@ -45,6 +56,9 @@ def parse_args(argv=None):
         parser.error("sub-command %r is not part of this build" % args.subcommand)
     if rest:
         parser.error("unrecognized arguments: %s" % " ".join(rest))
+    if args.subcommand == "extract_lr_bc":           # reference :100-101, :128 (the -g syntax is checked when it is parsed)
+        assert 0 < args.num_bp_after
+        assert args.threads > 0
     if args.subcommand == "extract_sr_bc_from_lr":   # reference :135-138
         assert 0 <= args.thresh <= 1
         assert 0 < args.step_size
@@ -59,7 +73,10 @@ def parse_args(argv=None):
 def main(argv=None):
     args = parse_args(argv)
     print(args, file=sys.stderr)
-    if args.subcommand == "extract_sr_bc_from_lr":
+    if args.subcommand == "extract_lr_bc":
+        from . import extract_lr_bc as _l
+        _l.extract_lr_bc(args)
+    elif args.subcommand == "extract_sr_bc_from_lr":
         from . import extract_sr_bc_from_lr as _x
         _x.extract_sr_bc_from_lr(args)
     else:

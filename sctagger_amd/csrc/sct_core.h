@@ -58,6 +58,23 @@ SCT_HD void myers_step(MyersState<W> &s, W lo, W hi, uint32_t c, int m) {
     s.Mv = Ph & Xv;
 }
 
+// The same step with the match mask Eq supplied by the caller (bit i = pattern[i] == text character), as used
+// for arbitrary byte alphabets.  GLOBAL_START = true charges the characters before the match (horizontal delta +1
+// enters row 0): the pattern must then start at the first column ("SHW" / prefix mode).
+template <typename W, bool GLOBAL_START>
+SCT_HD void myers_step_eq(MyersState<W> &s, W Eq, int m) {
+    const W Xv = Eq | s.Mv;
+    const W Xh = ((((Eq & s.Pv) + s.Pv)) ^ s.Pv) | Eq;
+    W Ph = s.Mv | ~(Xh | s.Pv);
+    W Mh = s.Pv & Xh;
+    s.score += (int)((Ph >> (m - 1)) & 1);
+    s.score -= (int)((Mh >> (m - 1)) & 1);
+    Ph = (Ph << 1) | (GLOBAL_START ? (W)1 : (W)0);
+    Mh <<= 1;
+    s.Pv = Mh | ~(Xv | Ph);
+    s.Mv = Ph & Xv;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Transposed Wu-Manber automaton for short texts (L <= 31): bit i of R_d = "some substring of the text
 // ending at position i matches the pattern prefix consumed so far with <= d edits".  The pattern is the

@@ -132,3 +132,73 @@ int64_t sctio_render(const uint8_t *namebuf, const int64_t *name_start, const in
     }
     return out ? (int64_t)(o - out) : size;
 }
+
+/* ---- extract_lr_bc host helpers (reference scTagger.py:159-173 reader, :317-320 writer) ---- */
+static int is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }  /* str.split() / str.rstrip() whitespace (ASCII) */
+
+/*
+ * read_fastqs for one file: line idx % 4 == 0 -> rnames.append(l.split()[0][1:]), idx % 4 == 1 -> seqs.append(l.rstrip()).
+ * names / reads receive the bytes back to back, name_offs / read_offs the CSR offsets (capacity: number of lines / 4 + 2).
+ * counts[0] = names written, counts[1] = reads written.  Returns -1, or the number of the first header line without a token
+ * (the reference raises IndexError there).
+ */
+int64_t sctio_parse_fastq(const uint8_t *buf, int64_t len, uint8_t *names, int64_t *name_offs, uint8_t *reads, int64_t *read_offs,
+                          int64_t *counts) {
+    int64_t p = 0, idx = 0, nn = 0, nr = 0, no = 0, ro = 0;
+    name_offs[0] = 0;
+    read_offs[0] = 0;
+    while (p < len) {
+        int64_t q = p;
+        while (q < len && buf[q] != '\n') q++;
+        if ((idx & 3) == 0) {
+            int64_t a = p;
+            while (a < q && is_space(buf[a])) a++;
+            if (a >= q) return idx;
+            int64_t b = a;
+            while (b < q && !is_space(buf[b])) b++;
+            for (int64_t k = a + 1; k < b; k++) names[no++] = buf[k];
+            name_offs[++nn] = no;
+        } else if ((idx & 3) == 1) {
+            int64_t b = q;
+            while (b > p && is_space(buf[b - 1])) b--;
+            for (int64_t k = p; k < b; k++) reads[ro++] = buf[k];
+            read_offs[++nr] = ro;
+        }
+        idx++;
+        p = q + 1;
+    }
+    counts[0] = nn;
+    counts[1] = nr;
+    return -1;
+}
+
+/*
+ * output_matches (scTagger.py:317-320): name \t dist \t loc \t seq[start:stop] \n for rows [r0, r1).
+ * loc_na[r] != 0 prints "NA" for loc; start/stop are already resolved to 0 <= start <= stop <= len(read).
+ */
+int64_t sctio_render_lr(const uint8_t *names, const int64_t *name_offs, const uint8_t *reads, const int64_t *read_offs,
+                        const int32_t *dist, const int64_t *loc, const uint8_t *loc_na, const int64_t *start, const int64_t *stop,
+                        int64_t r0, int64_t r1, uint8_t *out) {
+    int64_t size = 0;
+    uint8_t *o = out;
+    for (int64_t r = r0; r < r1; r++) {
+        const int64_t ln = name_offs[r + 1] - name_offs[r], ls = stop[r] - start[r];
+        const int neg_d = dist[r] < 0, neg_l = !loc_na[r] && loc[r] < 0;
+        const uint64_t ad = (uint64_t)(neg_d ? -(int64_t)dist[r] : dist[r]), al = (uint64_t)(neg_l ? -loc[r] : loc[r]);
+        if (!out) {
+            size += ln + neg_d + ndigits(ad) + (loc_na[r] ? 2 : neg_l + ndigits(al)) + ls + 4;
+            continue;
+        }
+        memcpy(o, names + name_offs[r], (size_t)ln); o += ln;
+        *o++ = '\t';
+        if (neg_d) *o++ = '-';
+        o = put_num(o, ad);
+        *o++ = '\t';
+        if (loc_na[r]) { *o++ = 'N'; *o++ = 'A'; }
+        else { if (neg_l) *o++ = '-'; o = put_num(o, al); }
+        *o++ = '\t';
+        memcpy(o, reads + read_offs[r] + start[r], (size_t)ls); o += ls;
+        *o++ = '\n';
+    }
+    return out ? (int64_t)(o - out) : size;
+}

@@ -936,6 +936,119 @@ k_wl_count(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, c
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// extract_lr_bc (reference scTagger.py:176-196): the adapter and its reverse complement are aligned to every whole
+// read in edlib's HW (infix) mode.  One lane per read, Myers bit-vector over the read's bytes (fetched as aligned
+// 32-bit words), match masks from a 256-entry table in LDS (symbols are raw bytes, as in edlib).
+//   k_adapter_count   both patterns in one pass: minimum distance of each and the number of end positions at
+//                     which it is reached; decides the strand ('+' if the adapter is strictly better, '-' if its
+//                     reverse complement is, none on a tie) and how many locations the read will report
+//   k_adapter_fill    second pass with the winning pattern only: writes the locations — end positions for '+';
+//                     for '-' the start of the longest optimal alignment ending there (edlib: reverse alignment in
+//                     prefix mode, last position with the same score), stored as start - len - 1 like the reference
+// ------------------------------------------------------------------------------------------------------------
+struct ByteStream {  // the bytes of one read, fetched word by word
+    const uint32_t *wp;
+    int sk;
+    uint32_t word = 0;
+    __device__ __forceinline__ ByteStream(const uint8_t *base, int64_t b0) : wp(reinterpret_cast<const uint32_t *>(base) + (b0 >> 2)), sk((int)(b0 & 3)) {}
+    __device__ __forceinline__ uint32_t at(int64_t i) {
+        const int64_t g = i + sk;
+        if ((g & 3) == 0 || i == 0) word = wp[g >> 2];
+        return (word >> (8 * (g & 3))) & 0xFFu;
+    }
+};
+
+__global__ void __launch_bounds__(256)
+k_adapter_count(const uint8_t *__restrict__ reads, const int64_t *__restrict__ offs, int64_t n, const uint32_t *__restrict__ peq,
+                int m, int8_t *__restrict__ strand, int32_t *__restrict__ dist, uint32_t *__restrict__ cnt) {
+    __shared__ uint32_t P1[256], P2[256];
+    P1[threadIdx.x] = peq[threadIdx.x];
+    P2[threadIdx.x] = peq[256 + threadIdx.x];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t b0 = offs[r], len = offs[r + 1] - b0;
+    MyersState<uint32_t> s1, s2;
+    myers_init(s1, m);
+    myers_init(s2, m);
+    int best1 = m + 1, best2 = m + 1;
+    uint32_t c1 = 0, c2 = 0;
+    ByteStream bs(reads, b0);
+    for (int64_t i = 0; i < len; i++) {
+        const uint32_t b = bs.at(i);
+        myers_step_eq<uint32_t, false>(s1, P1[b], m);
+        myers_step_eq<uint32_t, false>(s2, P2[b], m);
+        if (s1.score <= best1) {
+            c1 = s1.score < best1 ? 1u : c1 + 1u;
+            best1 = s1.score;
+        }
+        if (s2.score <= best2) {
+            c2 = s2.score < best2 ? 1u : c2 + 1u;
+            best2 = s2.score;
+        }
+    }
+    int8_t st = 0;
+    int32_t d = -1;
+    uint32_t c = 0;
+    if (len > 0 && best1 != best2) {
+        if (best1 < best2) {
+            st = 1;
+            d = best1;
+            c = c1;
+        } else {
+            st = 2;
+            d = best2;
+            c = c2;
+        }
+    }
+    strand[r] = st;
+    dist[r] = d;
+    cnt[r] = c;
+}
+
+__global__ void __launch_bounds__(256)
+k_adapter_fill(const uint8_t *__restrict__ reads, const int64_t *__restrict__ offs, int64_t n, const uint32_t *__restrict__ peq,
+               int m, const int8_t *__restrict__ strand, const int32_t *__restrict__ dist,
+               const int64_t *__restrict__ loc_offs, int32_t *__restrict__ locs) {
+    __shared__ uint32_t P1[256], P2[256], P2R[256];
+    P1[threadIdx.x] = peq[threadIdx.x];
+    P2[threadIdx.x] = peq[256 + threadIdx.x];
+    P2R[threadIdx.x] = peq[512 + threadIdx.x];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int st = strand[r];
+    if (st == 0) return;
+    const int64_t b0 = offs[r], len = offs[r + 1] - b0;
+    const int d = dist[r];
+    const uint32_t *P = st == 1 ? P1 : P2;
+    int64_t out = loc_offs[r];
+    MyersState<uint32_t> s;
+    myers_init(s, m);
+    ByteStream bs(reads, b0);
+    for (int64_t i = 0; i < len; i++) {
+        myers_step_eq<uint32_t, false>(s, P[bs.at(i)], m);
+        if (s.score == d) {
+            if (st == 1) {
+                locs[out++] = (int32_t)i;
+            } else {
+                // reverse alignment in prefix mode from this end; a position further back than m + d characters
+                // cannot reach score d (the characters before the match are charged)
+                MyersState<uint32_t> q;
+                myers_init(q, m);
+                int last = 0;
+                const int lim = (int)((int64_t)(m + d) < i + 1 ? (int64_t)(m + d) : i + 1);
+                for (int t = 0; t < lim; t++) {
+                    myers_step_eq<uint32_t, true>(q, P2R[reads[b0 + i - t]], m);
+                    if (q.score == d) last = t;
+                }
+                locs[out++] = (int32_t)((i - last) - len - 1);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -983,6 +1096,7 @@ struct sct_ctx {
     bool have_result = false;
     // whitelist dictionary (extract_sr_bc_from_lr)
     DevBuf wl_table, wl_counts, wl_first, wl_skip;
+    DevBuf ad_peq, ad_strand, ad_dist, ad_locs;
     uint32_t wl_mask = 0, wl_len_set = 0;
     int32_t wl_n = -1;
     // options
@@ -1069,7 +1183,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
                       &c->cnt, &c->route, &c->slots, &c->slots_retry, &c->list_retry, &c->slot_off, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
-                      &c->total, &c->hits, &c->part_best, &c->part_cnt, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip};
+                      &c->total, &c->hits, &c->part_best, &c->part_cnt, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip, &c->ad_peq, &c->ad_strand, &c->ad_dist, &c->ad_locs};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1569,3 +1683,90 @@ extern "C" int sct_wl_count(sct_ctx *c, const char *segs, const int64_t *offs, c
     }
     return SCT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// extract_lr_bc (reference scTagger.py:176-196): adapter alignment over whole reads
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, const char *reads, const int64_t *offs, int64_t n,
+                                 int8_t *strand, int32_t *dist, int64_t *loc_offs, int32_t **locs, int64_t *n_locs) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    if (!adapter || !strand || !dist || !loc_offs || !locs || !n_locs) return fail(SCT_E_ARG, "sct_adapter_align: NULL argument");
+    *locs = nullptr;
+    *n_locs = 0;
+    if (m < 1) return fail(SCT_E_ARG, "adapter length must be positive");
+    if (m > 32) return fail(SCT_E_UNSUPPORTED, "adapter length %d exceeds the supported maximum 32", m);
+    for (int i = 0; i < m; i++)
+        if ((uint8_t)adapter[i] >= 128) return fail(SCT_E_ARG, "adapter contains a byte >= 128");
+    int rc = sct_upload_segments(c, reads, offs, n);
+    if (rc) return rc;
+    // match masks: adapter, its reverse complement (rev_compl, scTagger.py:148-156, :365), and that one reversed
+    std::vector<uint32_t> peq(3 * 256, 0u);
+    std::vector<uint8_t> a2((size_t)m);
+    for (int i = 0; i < m; i++) a2[i] = comp_byte((uint8_t)adapter[m - 1 - i]);
+    for (int i = 0; i < m; i++) {
+        peq[(uint8_t)adapter[i]] |= 1u << i;
+        peq[256 + a2[i]] |= 1u << i;
+        peq[512 + a2[m - 1 - i]] |= 1u << i;
+    }
+    const size_t n1 = (size_t)(n ? n : 1);
+    if (c->ad_peq.ensure(peq.size() * 4) || c->ad_strand.ensure(n1) || c->ad_dist.ensure(4 * n1) || c->cnt.ensure(4 * n1) ||
+        c->hit_offs.ensure(8 * (n1 + 1)) || c->total.ensure(8))
+        return SCT_E_HIP;
+    const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (c->sums.ensure(8 * (size_t)(nb ? nb : 1))) return SCT_E_HIP;
+    hipStream_t st = c->stream;
+    c->timed.clear();
+    c->pool_used = 0;
+    c->have_result = false;
+    HIPCHK(hipMemcpyAsync(c->ad_peq.p, peq.data(), peq.size() * 4, hipMemcpyHostToDevice, st));
+    uint64_t total = 0;
+    if (n > 0) {
+        {
+            Timer t(c, "k_adapter_count");
+            k_adapter_count<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), n, c->ad_peq.as<uint32_t>(), m,
+                                                               c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), c->cnt.as<uint32_t>());
+        }
+        {
+            Timer t(c, "k_offsets");
+            k_sum_blocks<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>());
+            k_scan_sums<<<1, 256, 0, st>>>(c->sums.as<uint64_t>(), nb, c->total.as<uint64_t>());
+            k_offsets<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>(), c->total.as<uint64_t>(),
+                                                    c->hit_offs.as<int64_t>());
+        }
+        HIPCHK(hipMemcpyAsync(&total, c->total.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (c->ad_locs.ensure(4 * (size_t)(total ? total : 1))) return SCT_E_HIP;
+        if (total) {
+            Timer t(c, "k_adapter_fill");
+            k_adapter_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), n, c->ad_peq.as<uint32_t>(), m,
+                                                              c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), c->hit_offs.as<int64_t>(),
+                                                              c->ad_locs.as<int32_t>());
+        }
+    } else {
+        loc_offs[0] = 0;
+    }
+    int32_t *h = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total ? total : 1));
+    if (!h) return fail(SCT_E_ARG, "out of host memory");
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(strand, c->ad_strand.p, (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(dist, c->ad_dist.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(loc_offs, c->hit_offs.p, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
+        if (total) HIPCHK(hipMemcpyAsync(h, c->ad_locs.p, 4 * (size_t)total, hipMemcpyDeviceToHost, st));
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        free(h);
+        return fail(SCT_E_HIP, "adapter alignment failed: %s", hipGetErrorString(e));
+    }
+    c->last_ms.clear();
+    for (const TimedKernel &t : c->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) c->last_ms.emplace_back(t.name, ms);
+    }
+    *locs = h;
+    *n_locs = (int64_t)total;
+    return SCT_OK;
+}
+
+extern "C" void sct_free_locs(sct_ctx *, int32_t *locs) { free(locs); }

@@ -139,6 +139,61 @@ static bool seeds_cover(const std::vector<int> &p, const std::vector<int> &t) {
     return sh.hit;
 }
 
+// ---- adapter alignment (edlib HW + reverse SHW for the start), as k_adapter_count / k_adapter_fill compute it ----
+static std::vector<int> dp_last_row(const std::vector<int> &q, const std::vector<int> &t, bool global_start) {
+    const int m = (int)q.size(), n = (int)t.size();
+    std::vector<int> col(m + 1), nw(m + 1), out(n);
+    for (int i = 0; i <= m; i++) col[i] = i;
+    for (int j = 0; j < n; j++) {
+        nw[0] = global_start ? j + 1 : 0;
+        for (int i = 1; i <= m; i++) nw[i] = std::min({col[i - 1] + (q[i - 1] != t[j]), col[i] + 1, nw[i - 1] + 1});
+        col = nw;
+        out[j] = col[m];
+    }
+    return out;
+}
+static bool check_adapter(const std::vector<int> &q, const std::vector<int> &t) {
+    const int m = (int)q.size(), n = (int)t.size();
+    uint32_t peq[4] = {0, 0, 0, 0}, peqr[4] = {0, 0, 0, 0};
+    for (int i = 0; i < m; i++) { peq[q[i]] |= 1u << i; peqr[q[m - 1 - i]] |= 1u << i; }
+    // forward: best and ends
+    std::vector<int> row = dp_last_row(q, t, false);
+    MyersState<uint32_t> s;
+    myers_init(s, m);
+    int best = m + 1, cnt = 0;
+    std::vector<int> sc(n);
+    for (int j = 0; j < n; j++) {
+        myers_step_eq<uint32_t, false>(s, peq[t[j]], m);
+        sc[j] = s.score;
+        if (s.score != row[j]) return false;
+        if (s.score <= best) { cnt = s.score < best ? 1 : cnt + 1; best = s.score; }
+    }
+    if (n == 0) return true;
+    int want_best = *std::min_element(row.begin(), row.end());
+    if (best != want_best || cnt != (int)std::count(row.begin(), row.end(), want_best)) return false;
+    for (int j = 0; j < n; j++) {
+        if (sc[j] != best) continue;
+        // kernel's reverse SHW
+        MyersState<uint32_t> qy;
+        myers_init(qy, m);
+        int last = 0;
+        const int lim = std::min(m + best, j + 1);
+        for (int x = 0; x < lim; x++) {
+            myers_step_eq<uint32_t, true>(qy, peqr[t[j - x]], m);
+            if (qy.score == best) last = x;
+        }
+        // definition: reversed query vs reversed prefix, SHW, last position with the best score
+        std::vector<int> rq(q.rbegin(), q.rend()), rt(t.begin(), t.begin() + j + 1);
+        std::reverse(rt.begin(), rt.end());
+        std::vector<int> rr = dp_last_row(rq, rt, true);
+        if (*std::min_element(rr.begin(), rr.end()) != best) return false;
+        int wl = 0;
+        for (int x = 0; x <= j; x++) if (rr[x] == best) wl = x;
+        if (wl != last) return false;
+    }
+    return true;
+}
+
 int main() {
     std::mt19937_64 rng(12345);
     auto rnd = [&](int n) { return (int)(rng() % (uint64_t)n); };
@@ -157,6 +212,20 @@ int main() {
         const int want = brute_infix(p, t);
         if (m <= 32 && myers_infix<uint32_t>(p, t) != want) { printf("FAIL myers32 m=%d n=%d\n", m, n); return 1; }
         if (myers_infix<uint64_t>(p, t) != want) { printf("FAIL myers64 m=%d n=%d\n", m, n); return 1; }
+        checked++;
+    }
+    // 1b. adapter alignment arithmetic (HW ends + reverse SHW starts), query 1..32, text 0..120
+    for (int it = 0; it < 40000; it++) {
+        const int m = 1 + rnd(32), n = rnd(121), alpha = 1 + rnd(4);
+        std::vector<int> q(m), t(n);
+        for (auto &x : q) x = rnd(alpha);
+        for (auto &x : t) x = rnd(alpha);
+        if (n >= m && rnd(2)) {
+            int at = rnd(n - m + 1);
+            for (int i = 0; i < m; i++) t[at + i] = q[i];
+            for (int k = rnd(5); k > 0; k--) t[rnd(n)] = rnd(4);
+        }
+        if (!check_adapter(q, t)) { printf("FAIL adapter m=%d n=%d\n", m, n); return 1; }
         checked++;
     }
     // 2. transposed Wu-Manber + seed completeness, bl = 16, texts 0..31, planted copies with 0..3 edits

@@ -34,7 +34,7 @@ def test_cli_asserts(argv):
 
 
 def test_cli_rejects_other_subcommands_and_missing_args():
-    for argv in (["extract_lr_bc", "-r", "a.fq"], ["match_trie", "-lr", "x"], []):
+    for argv in (["extract_sr_bc", "-i", "a.bam"], ["match_trie", "-lr", "x"], []):
         with pytest.raises(SystemExit):
             cli.parse_args(argv)
 
