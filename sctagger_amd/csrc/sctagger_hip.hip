@@ -958,58 +958,111 @@ struct ByteStream {  // the bytes of one read, fetched word by word
     }
 };
 
+// one text byte through both automata, tracking for each the minimum, how often it is reached and where first / last
+struct AdapterTrack {
+    MyersState<uint32_t> s1, s2;
+    int best1, best2;
+    uint32_t c1 = 0, c2 = 0;
+    int64_t first1 = 0, last1 = 0, first2 = 0, last2 = 0;
+    __device__ __forceinline__ void step(uint32_t e1, uint32_t e2, int m, int64_t i) {
+        myers_step_eq<uint32_t, false>(s1, e1, m);
+        myers_step_eq<uint32_t, false>(s2, e2, m);
+        if (s1.score <= best1) {
+            if (s1.score < best1) {
+                c1 = 0;
+                first1 = i;
+            }
+            c1++;
+            last1 = i;
+            best1 = s1.score;
+        }
+        if (s2.score <= best2) {
+            if (s2.score < best2) {
+                c2 = 0;
+                first2 = i;
+            }
+            c2++;
+            last2 = i;
+            best2 = s2.score;
+        }
+    }
+};
+
+// The read is streamed in 64-byte aligned chunks held in registers (four 16-byte loads per lane and chunk: every
+// cache line is fetched exactly once, although neighbouring lanes walk different reads); bytes of the first and
+// last chunk that lie outside the read are skipped.  (Fetching word by word made every lane revisit its line 16
+// times with 64 different lines per wave instruction in between: 8.5 ms instead of 2.5 ms per 2 GB.)
 __global__ void __launch_bounds__(256)
 k_adapter_count(const uint8_t *__restrict__ reads, const int64_t *__restrict__ offs, int64_t n, const uint32_t *__restrict__ peq,
-                int m, int8_t *__restrict__ strand, int32_t *__restrict__ dist, uint32_t *__restrict__ cnt) {
+                int m, int8_t *__restrict__ strand, int32_t *__restrict__ dist, uint32_t *__restrict__ cnt,
+                int64_t *__restrict__ win_first, int64_t *__restrict__ win_last) {
     __shared__ uint32_t P1[256], P2[256];
     P1[threadIdx.x] = peq[threadIdx.x];
     P2[threadIdx.x] = peq[256 + threadIdx.x];
     __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const int64_t b0 = offs[r], len = offs[r + 1] - b0;
-    MyersState<uint32_t> s1, s2;
-    myers_init(s1, m);
-    myers_init(s2, m);
-    int best1 = m + 1, best2 = m + 1;
-    uint32_t c1 = 0, c2 = 0;
-    ByteStream bs(reads, b0);
-    for (int64_t i = 0; i < len; i++) {
-        const uint32_t b = bs.at(i);
-        myers_step_eq<uint32_t, false>(s1, P1[b], m);
-        myers_step_eq<uint32_t, false>(s2, P2[b], m);
-        if (s1.score <= best1) {
-            c1 = s1.score < best1 ? 1u : c1 + 1u;
-            best1 = s1.score;
-        }
-        if (s2.score <= best2) {
-            c2 = s2.score < best2 ? 1u : c2 + 1u;
-            best2 = s2.score;
+    const int64_t b0 = offs[r], b1 = offs[r + 1], len = b1 - b0;
+    AdapterTrack T;
+    myers_init(T.s1, m);
+    myers_init(T.s2, m);
+    T.best1 = T.best2 = m + 1;
+    const uint4 *base = reinterpret_cast<const uint4 *>(reads);
+    for (int64_t c = b0 >> 6; (c << 6) < b1; c++) {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = base[c * 4 + q];
+        const int64_t p0 = c << 6;
+        const bool whole = p0 >= b0 && p0 + 64 <= b1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int64_t pos = p0 + q * 16 + k * 4 + j;
+                    if (whole || (pos >= b0 && pos < b1)) {
+                        const uint32_t b = (w[k] >> (8 * j)) & 0xFFu;
+                        T.step(P1[b], P2[b], m, pos - b0);
+                    }
+                }
+            }
         }
     }
     int8_t st = 0;
     int32_t d = -1;
-    uint32_t c = 0;
-    if (len > 0 && best1 != best2) {
-        if (best1 < best2) {
+    uint32_t cc = 0;
+    int64_t wf = 0, wl = -1;
+    if (len > 0 && T.best1 != T.best2) {
+        if (T.best1 < T.best2) {
             st = 1;
-            d = best1;
-            c = c1;
+            d = T.best1;
+            cc = T.c1;
+            wf = T.first1;
+            wl = T.last1;
         } else {
             st = 2;
-            d = best2;
-            c = c2;
+            d = T.best2;
+            cc = T.c2;
+            wf = T.first2;
+            wl = T.last2;
         }
     }
     strand[r] = st;
     dist[r] = d;
-    cnt[r] = c;
+    cnt[r] = cc;
+    win_first[r] = wf;
+    win_last[r] = wl;
 }
 
+// Second pass, winning pattern only, over the window [first end - 2m, last end] of the read: D[m][j] depends on at
+// most the 2m characters before j (an alignment of an m-character pattern with <= m edits is at most 2m long and the
+// start is free), so an automaton started 2m characters before the first reported end gives the same scores there.
 __global__ void __launch_bounds__(256)
 k_adapter_fill(const uint8_t *__restrict__ reads, const int64_t *__restrict__ offs, int64_t n, const uint32_t *__restrict__ peq,
-               int m, const int8_t *__restrict__ strand, const int32_t *__restrict__ dist,
-               const int64_t *__restrict__ loc_offs, int32_t *__restrict__ locs) {
+               int m, const int8_t *__restrict__ strand, const int32_t *__restrict__ dist, const int64_t *__restrict__ win_first,
+               const int64_t *__restrict__ win_last, const int64_t *__restrict__ loc_offs, int32_t *__restrict__ locs) {
     __shared__ uint32_t P1[256], P2[256], P2R[256];
     P1[threadIdx.x] = peq[threadIdx.x];
     P2[threadIdx.x] = peq[256 + threadIdx.x];
@@ -1023,12 +1076,25 @@ k_adapter_fill(const uint8_t *__restrict__ reads, const int64_t *__restrict__ of
     const int d = dist[r];
     const uint32_t *P = st == 1 ? P1 : P2;
     int64_t out = loc_offs[r];
+    const int64_t first = win_first[r], last = win_last[r];
+    const int64_t from = first - 2 * m > 0 ? first - 2 * m : 0;
     MyersState<uint32_t> s;
     myers_init(s, m);
-    ByteStream bs(reads, b0);
-    for (int64_t i = 0; i < len; i++) {
-        myers_step_eq<uint32_t, false>(s, P[bs.at(i)], m);
-        if (s.score == d) {
+    // bytes through a one-word cache: the forward walk and the short backward walks touch each word once
+    const uint32_t *wp = reinterpret_cast<const uint32_t *>(reads);
+    int64_t wi = -1;
+    uint32_t word = 0;
+    auto byte_at = [&](int64_t i) {
+        const int64_t g = b0 + i;
+        if ((g >> 2) != wi) {
+            wi = g >> 2;
+            word = wp[wi];
+        }
+        return (word >> (8 * (g & 3))) & 0xFFu;
+    };
+    for (int64_t i = from; i <= last; i++) {
+        myers_step_eq<uint32_t, false>(s, P[byte_at(i)], m);
+        if (i >= first && s.score == d) {
             if (st == 1) {
                 locs[out++] = (int32_t)i;
             } else {
@@ -1036,13 +1102,13 @@ k_adapter_fill(const uint8_t *__restrict__ reads, const int64_t *__restrict__ of
                 // cannot reach score d (the characters before the match are charged)
                 MyersState<uint32_t> q;
                 myers_init(q, m);
-                int last = 0;
+                int lastpos = 0;
                 const int lim = (int)((int64_t)(m + d) < i + 1 ? (int64_t)(m + d) : i + 1);
                 for (int t = 0; t < lim; t++) {
-                    myers_step_eq<uint32_t, true>(q, P2R[reads[b0 + i - t]], m);
-                    if (q.score == d) last = t;
+                    myers_step_eq<uint32_t, true>(q, P2R[byte_at(i - t)], m);
+                    if (q.score == d) lastpos = t;
                 }
-                locs[out++] = (int32_t)((i - last) - len - 1);
+                locs[out++] = (int32_t)((i - lastpos) - len - 1);
             }
         }
     }
@@ -1096,7 +1162,7 @@ struct sct_ctx {
     bool have_result = false;
     // whitelist dictionary (extract_sr_bc_from_lr)
     DevBuf wl_table, wl_counts, wl_first, wl_skip;
-    DevBuf ad_peq, ad_strand, ad_dist, ad_locs;
+    DevBuf ad_peq, ad_strand, ad_dist, ad_locs, ad_first, ad_last;
     uint32_t wl_mask = 0, wl_len_set = 0;
     int32_t wl_n = -1;
     // options
@@ -1183,7 +1249,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
                       &c->cnt, &c->route, &c->slots, &c->slots_retry, &c->list_retry, &c->slot_off, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
-                      &c->total, &c->hits, &c->part_best, &c->part_cnt, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip, &c->ad_peq, &c->ad_strand, &c->ad_dist, &c->ad_locs};
+                      &c->total, &c->hits, &c->part_best, &c->part_cnt, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip, &c->ad_peq, &c->ad_strand, &c->ad_dist, &c->ad_locs, &c->ad_first, &c->ad_last};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1710,6 +1776,7 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
     }
     const size_t n1 = (size_t)(n ? n : 1);
     if (c->ad_peq.ensure(peq.size() * 4) || c->ad_strand.ensure(n1) || c->ad_dist.ensure(4 * n1) || c->cnt.ensure(4 * n1) ||
+        c->ad_first.ensure(8 * n1) || c->ad_last.ensure(8 * n1) ||
         c->hit_offs.ensure(8 * (n1 + 1)) || c->total.ensure(8))
         return SCT_E_HIP;
     const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -1724,7 +1791,8 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
         {
             Timer t(c, "k_adapter_count");
             k_adapter_count<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), n, c->ad_peq.as<uint32_t>(), m,
-                                                               c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), c->cnt.as<uint32_t>());
+                                                               c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), c->cnt.as<uint32_t>(),
+                                                               c->ad_first.as<int64_t>(), c->ad_last.as<int64_t>());
         }
         {
             Timer t(c, "k_offsets");
@@ -1739,8 +1807,8 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
         if (total) {
             Timer t(c, "k_adapter_fill");
             k_adapter_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), n, c->ad_peq.as<uint32_t>(), m,
-                                                              c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), c->hit_offs.as<int64_t>(),
-                                                              c->ad_locs.as<int32_t>());
+                                                              c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), c->ad_first.as<int64_t>(),
+                                                              c->ad_last.as<int64_t>(), c->hit_offs.as<int64_t>(), c->ad_locs.as<int32_t>());
         }
     } else {
         loc_offs[0] = 0;

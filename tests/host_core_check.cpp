@@ -169,6 +169,15 @@ static bool check_adapter(const std::vector<int> &q, const std::vector<int> &t) 
         if (s.score <= best) { cnt = s.score < best ? 1 : cnt + 1; best = s.score; }
     }
     if (n == 0) return true;
+    // a fresh automaton started at `from` reproduces the scores from position from + 2m on (windowed second pass)
+    for (int from = 1; from < n; from += 7) {
+        MyersState<uint32_t> w;
+        myers_init(w, m);
+        for (int j = from; j < n; j++) {
+            myers_step_eq<uint32_t, false>(w, peq[t[j]], m);
+            if (j >= from + 2 * m && w.score != row[j]) return false;
+        }
+    }
     int want_best = *std::min_element(row.begin(), row.end());
     if (best != want_best || cnt != (int)std::count(row.begin(), row.end(), want_best)) return false;
     for (int j = 0; j < n; j++) {
