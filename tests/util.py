@@ -69,3 +69,20 @@ def assert_same(a, b, what=""):
         if not np.array_equal(x, y):
             bad = np.flatnonzero(x != y)[:5]
             raise AssertionError("%s %s differs at %s: %s vs %s" % (what, nm, bad, x[bad], y[bad]))
+
+
+def read_inputs_gz(lr, sr):
+    """read_inputs for gzipped -lr files too."""
+    op = gzip.open if sr.endswith(".gz") else open
+    with op(sr, "rt") as f:
+        bcs = [l.rstrip("\n").split("\t")[0] for l in f]
+    names, segs = [], []
+    op = gzip.open if lr.endswith(".gz") else open
+    with op(lr, "rt") as f:
+        for l in f:
+            p = l.rstrip("\n").split("\t")
+            names.append(p[0])
+            segs.append(p[3])
+    offs = np.zeros(len(segs) + 1, dtype=np.int64)
+    np.cumsum([len(s) for s in segs], out=offs[1:])
+    return bcs, names, np.frombuffer("".join(segs).encode("latin-1"), dtype=np.uint8), offs
