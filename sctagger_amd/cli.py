@@ -1,7 +1,7 @@
 """`scTagger.py match_trie` (and `extract_sr_bc_from_lr`) command line (reference scTagger.py:67-97, :135-143, :847-861).
 
-Flags, defaults and asserts are the reference's for this sub-command; `-m/--mem` and `-p/--plotfile`
-are accepted and unused, exactly as there.  Optional extras: `--devices` (GPU ids, one shard each) and
+Flags, defaults and asserts are the reference's for this sub-command; `-m/--mem` is accepted and unused, exactly
+as there; `-p/--plotfile` draws the distance histogram the reference's README advertises.  Optional extras: `--devices` (GPU ids, one shard each) and
 `--gzip-level`.  The other scTagger sub-commands are outside this build's scope.
 """
 import argparse
@@ -26,7 +26,7 @@ def parse_args(argv=None):
     p.add_argument("-t", "--threads", default=16, type=int,
                    help="Reference thread count; here it only selects the reference's window-prefix length "
                         "(affects segments with non-ACGT bytes). Default: 16")
-    p.add_argument("-p", "--plotfile", default=None, type=str, help="Accepted for compatibility; unused")
+    p.add_argument("-p", "--plotfile", default=None, type=str, help="Path of plot file (histogram of the minimum edit distance). Default: no plotting")
     p.add_argument("-o", "--outfile", type=str, default=None,
                    help="Path to output file; gzipped if it ends with 'gz'. Default: stdout")
     p.add_argument("--devices", type=int, nargs="+", default=None, help="GPU ids to shard the segments over. Default: 0")
@@ -40,7 +40,7 @@ def parse_args(argv=None):
     l.add_argument("-sa", "--short-read-adapter", type=str, default="CTACACGACGCTCTTCCGATCT",
                    help="Short-read adapter. Default: CTACACGACGCTCTTCCGATCT")
     l.add_argument("-o", "--outfile", type=str, default=None, help="Path to output file (gzipped). Default: stdout")
-    l.add_argument("-p", "--plotfile", type=str, default=None, help="Accepted for compatibility; the plot is not produced")
+    l.add_argument("-p", "--plotfile", type=str, default=None, help="Path to plot file. Default: no plotting")
     l.add_argument("--num-bp-after", type=int, default=20, help="Bases after the end of the adapter alignment to output. Default: 20")
     q = subparsers.add_parser("extract_sr_bc_from_lr")     # reference scTagger.py:67-79
     q.add_argument("-i", "--input", type=str, required=True, help="Input TSV file generated from extract_lr_bc step")

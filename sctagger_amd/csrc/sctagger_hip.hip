@@ -1,25 +1,32 @@
-// sctagger_hip.hip — gfx950 kernels and the C-ABI (include/sctagger_hip.h) of the match_trie path.
+// sctagger_hip.hip — gfx950 kernels and the C-ABI (include/sctagger_hip.h).
 //
-// What is computed (reference scTagger.py:643-716, observable semantics in SURVEY.md §8(a)-Q): for every
-// long-read segment the minimum infix edit distance (<= max_err) to any barcode on either strand, and the
-// sorted list of all (bid, strand) at that minimum.  The reference gets there with a trie of segment windows
-// and a recursive DFS per barcode; none of that is imitated here.
+// match_trie (reference scTagger.py:643-716, observable semantics in SURVEY.md §8(a)-Q): for every long-read
+// segment the minimum infix edit distance (<= max_err) to any barcode on either strand, and the sorted list of
+// all (bid, strand) at that minimum.  The reference gets there with a trie of segment windows and a recursive
+// DFS per barcode; none of that is imitated here.
 //
 // Device data (all in HBM, resident for the life of the context / upload):
 //   patterns   np = 2*n_bc entries, index p = bid*2 + strand (strand 1 = forward, 0 = reverse complement, so
 //              ascending p is the reference's sorted(bids) order), stored as bit-planes uint2{lo, hi}
-//   seed tables (bl == 16): six families x (65536+1 offsets, np pattern ids), see sct_core.h
+//   seed tables (bl == 16): per family an offsets array (65537 entries; 2^20+1 / 2^22+1 for the thirds scheme of
+//              large barcode sets) and np entries as pattern ids and as 2-bit codes, see sct_core.h
 //   segments   the caller's CSR bytes + int64 offsets, plus per segment the packed bit-planes {lo, hi, meta}
-//   results    min_e u8[n], cnt u32[n], slot_off u64[n] + dense slots u32[] (filter path), hit_offs i64[n+1], hits u32[total]
+//   results    min_e u8[n], cnt u32[n], slot_off u64[n] + dense slots u32[] (filter path), hit_offs i64[n+1],
+//              hits u32[total]
 //
-// Kernels:
-//   k_pack        ASCII -> bit-planes, routes each segment to the filter / exhaustive / restricted-start path
-//   k_filter<E>   one lane per segment: seed lookups + transposed Wu-Manber verification (bl = 16, e <= 2)
-//   k_scan<...>   one wave per segment, lanes = barcodes: Myers bit-vector over every barcode (any bl <= 32,
-//                 any max_err) or, for segments with non-ACGT bytes when the reference's prefix length k > 0,
-//                 a plain DP whose row 0 encodes the allowed window starts; count pass + fill pass
+// Kernels of the match_trie path:
+//   k_pack          ASCII -> bit-planes, routes each segment to the filter / exhaustive / restricted-start path
+//   k_filter<...>   one wave per 64 segments: seed lookups spread over the lanes, candidates queued in LDS and
+//                   verified 64 at a time by the anchored transposed Wu-Manber automaton, tiers, retry launch
+//   k_filter_lane   the first, lane-per-segment version of the filter (option filter_mode = 1, for A/B)
+//   k_scan<...>     one wave per (segment, barcode slice), lanes = barcodes: Myers bit-vector over every barcode
+//                   (any bl <= 32, any max_err) or, for segments with non-ACGT bytes when the reference's prefix
+//                   length k > 0, a plain DP whose row 0 encodes the allowed window starts; count + fill pass
 //   k_sum_* / k_offsets   exclusive scan of the per-segment hit counts into the CSR offsets
-//   k_fill        copies the filter path's slot lists into the CSR hit array
+//   k_fill          copies the filter path's hit lists into the CSR hit array
+// Kernels of the two neighbouring stages:
+//   k_wl_count                        extract_sr_bc_from_lr: whitelist dictionary probes (scTagger.py:818-826)
+//   k_adapter_count / k_adapter_fill  extract_lr_bc: adapter alignment over whole reads (scTagger.py:176-196)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -946,18 +953,6 @@ k_wl_count(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, c
 //                     for '-' the start of the longest optimal alignment ending there (edlib: reverse alignment in
 //                     prefix mode, last position with the same score), stored as start - len - 1 like the reference
 // ------------------------------------------------------------------------------------------------------------
-struct ByteStream {  // the bytes of one read, fetched word by word
-    const uint32_t *wp;
-    int sk;
-    uint32_t word = 0;
-    __device__ __forceinline__ ByteStream(const uint8_t *base, int64_t b0) : wp(reinterpret_cast<const uint32_t *>(base) + (b0 >> 2)), sk((int)(b0 & 3)) {}
-    __device__ __forceinline__ uint32_t at(int64_t i) {
-        const int64_t g = i + sk;
-        if ((g & 3) == 0 || i == 0) word = wp[g >> 2];
-        return (word >> (8 * (g & 3))) & 0xFFu;
-    }
-};
-
 // one text byte through both automata, tracking for each the minimum, how often it is reached and where first / last
 struct AdapterTrack {
     MyersState<uint32_t> s1, s2;

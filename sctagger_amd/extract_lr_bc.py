@@ -5,7 +5,7 @@ task 'locations'), finds where on the reads the adapter usually sits (peak detec
 adapter locations fall inside one such range, and writes for each read the window right after the adapter — the
 long-read segment that match_trie consumes.  Here the alignment runs on the GPU (sct_adapter_align); reading,
 peak detection, the range filter and writing stay on the host, vectorised.  Nothing is aligned on the CPU and there
-is no fallback.  The coverage plot (-p) is not produced.
+is no fallback.
 """
 import ctypes
 import gzip
@@ -264,7 +264,7 @@ def compute(names, name_offs, reads, read_offs, adapter, range_specs, num_bp_aft
     chunks = []
     for c0 in range(0, n_out, 500_000):
         chunks.append(render(names, name_offs, reads, read_offs, out_dist, loc, loc_na, start, stop, c0, min(n_out, c0 + 500_000)))
-    return chunks
+    return chunks, out_dist
 
 
 def extract_lr_bc(args, device=0):
@@ -274,7 +274,7 @@ def extract_lr_bc(args, device=0):
     adapter = args.short_read_adapter
     _log("Aligning %s and %s to the reads" % (adapter, rev_compl(adapter)))
     names, name_offs, reads, read_offs = read_fastqs(args.reads, args.gzipped)
-    chunks = compute(names, name_offs, reads, read_offs, adapter, args.ranges or [], args.num_bp_after, device)
+    chunks, out_dist = compute(names, name_offs, reads, read_offs, adapter, args.ranges or [], args.num_bp_after, device)
     if args.outfile:
         w = fastio.GzipChunkWriter(args.outfile, level=getattr(args, "gzip_level", 4))   # the reference always gzips (:377)
         try:
@@ -285,5 +285,6 @@ def extract_lr_bc(args, device=0):
     else:
         for c in chunks:
             sys.stdout.buffer.write(c)
-    if getattr(args, "plotfile", None) is not None:
-        _log("note: the -p plot of the reference is not produced by this build")
+    if getattr(args, "plotfile", None) is not None:      # reference :382-383
+        from . import plots
+        plots.plot_extract_lr_bc(out_dist, args.plotfile)

@@ -196,7 +196,7 @@ def write_matches(outfile, min_e, hit_offs, hits, chunk=200_000):
 
 def match_trie(args):
     """reference :758-790. args: long_read_segments, short_read_barcodes, max_error, barcode_length,
-    threads, outfile (and mem/plotfile, accepted and unused as in the reference)."""
+    threads, outfile; mem is accepted and unused as in the reference; plotfile draws the distance histogram."""
     read_sr_barcodes(args.short_read_barcodes)
     barcode_lens = {len(b) for b in barcodes}
     assert barcode_lens == {args.barcode_length}, barcode_lens
@@ -204,6 +204,9 @@ def match_trie(args):
     devices = getattr(args, "devices", None) or (0,)
     min_e, hit_offs, hits = run_get_matches_prefix_arrays(
         max_error=args.max_error, threads=args.threads, devices=devices, barcode_length=args.barcode_length)
+    if getattr(args, "plotfile", None) is not None:
+        from . import plots
+        plots.plot_match_trie(min_e, args.plotfile, _native.NO_HIT)
     level = getattr(args, "gzip_level", 4)
     if isinstance(lr_names, fastio.LazyNames):
         table = fastio.pattern_text_table(barcodes, barcodes_rc)

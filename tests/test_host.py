@@ -100,3 +100,12 @@ def test_match_trie_asserts_barcode_length(tmp_path):
                                  max_error=2, threads=1, outfile=None)
     with pytest.raises(AssertionError):     # reference :760-761
         mt.match_trie(args)
+
+
+def test_plots(tmp_path):
+    """The -p figures are drawn by host code (no GPU): just check that files are produced."""
+    from sctagger_amd import plots
+    a, b = tmp_path / "m.png", tmp_path / "l.png"
+    plots.plot_match_trie(np.array([0, 0, 1, 2, 255, 1], dtype=np.uint8), str(a))
+    plots.plot_extract_lr_bc(np.array([0, 0, 1, -1, 3, 7], dtype=np.int32), str(b))
+    assert a.stat().st_size > 1000 and b.stat().st_size > 1000
