@@ -1,5 +1,7 @@
 """Randomised small cases: every code path of the library (filter kernels, retry, exhaustive scan, restricted-start DP)
 against the oracle, and the oracle against the independent brute force (hypothesis, CPU only)."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st
@@ -67,7 +69,7 @@ def test_gpu_fuzz_all_paths():
     from sctagger_amd import _native
     rng = np.random.default_rng(2024)
     with _native.Matcher(0) as m:
-        for trial in range(120):
+        for trial in range(int(os.environ.get("SCT_FUZZ_TRIALS", "120"))):
             bl = int(rng.choice([16, 16, 16, 16, 8, 12, 20, 32]))
             e = int(rng.integers(0, 4))
             if e >= bl:
