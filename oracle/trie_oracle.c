@@ -275,6 +275,7 @@ int orc_match(const char *bc, int n_bc, int bl, const char *segs, const int64_t 
     for (int b = 0; b < n_bc; b++) rev_compl(bc + (size_t)b * bl, bl, bc_rc + (size_t)b * bl);
 
     int plen = orc_prefix_len(threads);
+    if (plen > 10) { free(bc_rc); return -2; } /* more than 4^10 prefix tasks: not a configuration the reference is run with */
     int n_tasks = 1;
     for (int i = 0; i < plen; i++) n_tasks *= 4;
     char *prefixes = (char *)malloc((size_t)n_tasks * (plen ? plen : 1));

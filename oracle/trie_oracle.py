@@ -55,6 +55,8 @@ def match(bc, segs, offs, max_error, threads=1, workers=1):
     nh = ctypes.c_int64()
     rc = lib.orc_match(bc.ctypes.data, n_bc, bl, segs.ctypes.data, offs.ctypes.data, n, int(max_error), int(threads),
                        int(workers), min_e.ctypes.data, hit_offs.ctypes.data, ctypes.byref(hp), ctypes.byref(nh))
+    if rc == -2:
+        raise ValueError("oracle: more than 4^10 prefix tasks requested")
     if rc != 0:
         raise ValueError("oracle: byte >= 128 in the input (the reference raises there)")
     hits = np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_uint32)), shape=(max(nh.value, 1),))[:nh.value].copy()
