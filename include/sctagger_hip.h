@@ -94,6 +94,14 @@ int sct_upload_segments(sct_ctx *ctx, const char *segs, const int64_t *offs, int
 int sct_run(sct_ctx *ctx, int32_t max_err, int32_t threads, int64_t *n_hits);
 int sct_download(sct_ctx *ctx, uint8_t *min_e, int64_t *hit_offs, uint32_t *hits);
 
+/*
+ * Page-locked host memory.  Optional: every entry point accepts ordinary (pageable) buffers; buffers obtained here
+ * are copied to and from the device by DMA at the full PCIe rate instead of through the runtime's bounce buffer.
+ * sct_host_alloc returns NULL on failure (message in sct_last_error).
+ */
+void *sct_host_alloc(sct_ctx *ctx, size_t bytes);
+void sct_host_free(sct_ctx *ctx, void *p);
+
 /* Block until everything queued on the context's stream has finished. */
 int sct_sync(sct_ctx *ctx);
 

@@ -20,6 +20,7 @@ EXPORTS = (
     "sct_device_count", "sct_create", "sct_destroy", "sct_last_error", "sct_prefix_len", "sct_set_barcodes",
     "sct_match", "sct_free_hits", "sct_upload_segments", "sct_run", "sct_download", "sct_sync", "sct_set_option",
     "sct_last_timing", "sct_last_stats", "sct_wl_set", "sct_wl_count", "sct_adapter_align", "sct_free_locs",
+    "sct_host_alloc", "sct_host_free",
 )
 
 _lib = None
@@ -64,6 +65,10 @@ def load():
     lib.sct_adapter_align.argtypes = [vp, ctypes.c_char_p, i32, vp, vp, i64, vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     lib.sct_free_locs.argtypes = [vp, vp]
     lib.sct_free_locs.restype = None
+    lib.sct_host_alloc.argtypes = [vp, ctypes.c_size_t]
+    lib.sct_host_alloc.restype = vp
+    lib.sct_host_free.argtypes = [vp, vp]
+    lib.sct_host_free.restype = None
     _lib = lib
     return lib
 
@@ -88,6 +93,7 @@ class Matcher:
         self._ctx = ctypes.c_void_p()
         self._check(self._lib.sct_create(int(device), ctypes.byref(self._ctx)))
         self.device = int(device)
+        self._pinned = []
         self.n_bc = 0
         self.bl = 0
         self.n_seg = 0
@@ -98,6 +104,9 @@ class Matcher:
 
     def close(self):
         if self._ctx:
+            for p in getattr(self, "_pinned", []):
+                self._lib.sct_host_free(self._ctx, p)
+            self._pinned = []
             self._lib.sct_destroy(self._ctx)
             self._ctx = ctypes.c_void_p()
 
@@ -112,6 +121,18 @@ class Matcher:
 
     def __exit__(self, *a):
         self.close()
+
+    def host_array(self, shape, dtype):
+        """numpy array in page-locked host memory (sct_host_alloc); it is released when the Matcher is closed."""
+        shape = (int(shape),) if np.isscalar(shape) else tuple(int(x) for x in shape)
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        p = self._lib.sct_host_alloc(self._ctx, max(nbytes, 1))
+        if not p:
+            raise SctError(-2, self._lib.sct_last_error().decode("utf-8", "replace"))
+        self._pinned.append(p)
+        buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(p)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
 
     def set_option(self, key, value):
         self._check(self._lib.sct_set_option(self._ctx, key.encode(), int(value)))
@@ -177,13 +198,20 @@ class Matcher:
         self._n_hits = nh.value
         return nh.value
 
-    def download(self):
+    def download(self, pinned=False):
         n = self.n_seg
-        min_e = np.empty(n, dtype=np.uint8)
-        hit_offs = np.empty(n + 1, dtype=np.int64)
-        hits = np.empty(max(self._n_hits, 1), dtype=np.uint32)
+        alloc = self.host_array if pinned else (lambda shape, dtype: np.empty(shape, dtype=dtype))
+        min_e = alloc(max(n, 1), np.uint8)[:n]
+        hit_offs = alloc(n + 1, np.int64)
+        hits = alloc(max(self._n_hits, 1), np.uint32)
         self._check(self._lib.sct_download(self._ctx, _ptr(min_e), _ptr(hit_offs), _ptr(hits)))
         return min_e, hit_offs, hits[:self._n_hits]
+
+    def download_into(self, min_e, hit_offs, hits):
+        """sct_download into caller-provided arrays (e.g. page-locked ones from host_array)."""
+        assert min_e.size >= self.n_seg and hit_offs.size >= self.n_seg + 1 and hits.size >= self._n_hits
+        self._check(self._lib.sct_download(self._ctx, _ptr(min_e), _ptr(hit_offs), _ptr(hits)))
+        return min_e[:self.n_seg], hit_offs[:self.n_seg + 1], hits[:self._n_hits]
 
     def sync(self):
         self._check(self._lib.sct_sync(self._ctx))

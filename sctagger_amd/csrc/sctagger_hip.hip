@@ -1110,6 +1110,33 @@ k_adapter_fill(const uint8_t *__restrict__ reads, const int64_t *__restrict__ of
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_validate: input checks of sct_upload_segments on the device.  bad[0] = smallest row whose offsets are not
+// non-decreasing (or n if offs[n] != bytes), bad[1] = smallest byte offset holding a value >= 128; ~0 = none.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_validate(const uint8_t *__restrict__ segs, int64_t bytes, const int64_t *__restrict__ offs, int64_t n,
+           unsigned long long *__restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int64_t a = offs[i], b = offs[i + 1];
+        if (b < a || a < 0 || b > bytes) atomicMin(&bad[0], (unsigned long long)i);
+    }
+    const int64_t p = i * 16;
+    if (p < bytes) {  // the buffer is padded by 64 bytes, so the 16-byte load may run past `bytes`
+        const uint4 v = *reinterpret_cast<const uint4 *>(segs + p);
+        if ((v.x | v.y | v.z | v.w) & 0x80808080u) {
+            for (int k = 0; k < 16 && p + k < bytes; k++)
+                if (segs[p + k] >= 128) {
+                    atomicMin(&bad[1], (unsigned long long)(p + k));
+                    break;
+                }
+        }
+    }
+}
+
+static inline unsigned blocks_for_n(int64_t n, int per) { return (unsigned)((n + per - 1) / per > 0 ? (n + per - 1) / per : 1); }
+
+// ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -1251,6 +1278,25 @@ extern "C" void sct_destroy(sct_ctx *c) {
     delete c;
 }
 
+// page-locked host memory: buffers allocated here move over PCIe by DMA at the full link rate (pageable
+// buffers are staged through a bounce buffer by the runtime)
+extern "C" void *sct_host_alloc(sct_ctx *c, size_t bytes) {
+    if (!c) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail(SCT_E_HIP, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void sct_host_free(sct_ctx *c, void *p) {
+    if (!p) return;
+    if (c) (void)hipSetDevice(c->device);
+    (void)hipHostFree(p);
+}
+
 extern "C" int sct_sync(sct_ctx *c) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
@@ -1369,23 +1415,29 @@ extern "C" int sct_upload_segments(sct_ctx *c, const char *segs, const int64_t *
     if (n < 0 || !offs) return fail(SCT_E_ARG, "sct_upload_segments: bad offsets");
     if (n >= 0x7FFFFFF0) return fail(SCT_E_ARG, "at most 2^31-16 segments per call (shard the input)");
     if (offs[0] != 0) return fail(SCT_E_ARG, "offs[0] must be 0");
-    for (int64_t i = 0; i < n; i++)
-        if (offs[i + 1] < offs[i]) return fail(SCT_E_ARG, "offs must be non-decreasing (row %lld)", (long long)i);
     const int64_t bytes = offs[n];
+    if (bytes < 0) return fail(SCT_E_ARG, "offs[n] is negative");
     if (bytes > 0 && !segs) return fail(SCT_E_ARG, "segs is NULL");
-    const uint8_t *s = (const uint8_t *)segs;
-    uint8_t acc = 0;
-    for (int64_t i = 0; i < bytes; i++) acc |= s[i];
-    if (acc & 0x80) {
-        for (int64_t i = 0; i < bytes; i++)
-            if (s[i] >= 128) return fail(SCT_E_ARG, "segment bytes contain 0x%02x >= 128 at offset %lld", s[i], (long long)i);
-    }
     HIPCHK(hipSetDevice(c->device));
     if (c->segs.ensure((size_t)bytes + 64)) return SCT_E_HIP;
     if (c->offs.ensure(sizeof(int64_t) * (size_t)(n + 1))) return SCT_E_HIP;
-    if (bytes) HIPCHK(hipMemcpyAsync(c->segs.p, segs, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->offs.p, offs, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->counters.ensure(64)) return SCT_E_HIP;
+    hipStream_t st = c->stream;
+    if (bytes) HIPCHK(hipMemcpyAsync(c->segs.p, segs, (size_t)bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->offs.p, offs, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+    // validation on the device, before any kernel trusts the offsets: non-decreasing, inside the byte buffer, and
+    // no byte >= 128 (the reference raises on those); the host only reads back two words
+    HIPCHK(hipMemsetAsync(c->counters.p, 0xFF, 16, st));
+    const int64_t items = (n + 1) > (bytes + 15) / 16 ? (n + 1) : (bytes + 15) / 16;
+    k_validate<<<blocks_for_n(items, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), bytes, c->offs.as<int64_t>(), n,
+                                                        c->counters.as<unsigned long long>());
+    unsigned long long bad[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(bad, c->counters.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    c->n_seg = -1;
+    if (bad[0] != ~0ull) return fail(SCT_E_ARG, "offs must be non-decreasing and end at the size of segs (row %llu)", bad[0]);
+    if (bad[1] != ~0ull) return fail(SCT_E_ARG, "segment bytes contain a value >= 128 at offset %llu", bad[1]);
     c->n_seg = n;
     c->seg_bytes = bytes;
     c->have_result = false;
