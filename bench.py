@@ -172,9 +172,12 @@ def main():
         if q and q.get("kernel_ms_at_profile") and abs(avg[dominant] / q["kernel_ms_at_profile"] - 1.0) > 0.15:
             q = None   # the committed counters belong to a different build of the kernel: do not quote them
         if q:
-            rd = q.get("hbm_read_bytes_x2_gfx950") or 0
+            # FETCH_SIZE is taken as read: this kernel streams 24 B per segment of packed input with 4- and 8-byte
+            # loads per lane (240 MB at 10 M segments) and the counter reports 248 MB, so the x2 rule of the guide
+            # (calibrated for 16-byte-per-lane streams) does not apply to it
+            rd = q.get("hbm_read_bytes_raw") or 0
             roof["traffic"] = int(rd + (q.get("hbm_write_bytes") or 0))
-            roof["traffic_source"] = q["source"] + "; FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as read"
+            roof["traffic_source"] = q["source"] + "; FETCH_SIZE + WRITE_SIZE as read (FETCH_SIZE matches the kernel's 24 B/segment input)"
             if q.get("valu_insts_per_launch"):
                 w = q["valu_insts_per_launch"] / (avg[dominant] * 1e-3)
                 roof["valu"] = {"insts_per_segment": round(q["valu_insts_per_launch"] / q["segments_per_launch"], 1),
