@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--segments", type=int, default=None, help="override segments per GPU")
+    ap.add_argument("--barcode-length", type=int, default=None, help="override the workload's barcode length (exploration)")
     ap.add_argument("--seg-len", type=int, default=22, help="segment length of the synthetic rows (22 = the reference's nominal length)")
     ap.add_argument("--cpu-sample", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,6 +107,8 @@ def main():
     n_seg, n_bc, bl, max_err = WORKLOADS[args.workload]
     if args.segments:
         n_seg = args.segments
+    if args.barcode_length:
+        bl = args.barcode_length
     bc = synth.make_barcodes(n_bc, bl=bl, seed=3)
     seed = 3 if world == 1 else 40 + rank
     segs, offs = make_batch(n_seg, bc, seed, seg_len=args.seg_len)

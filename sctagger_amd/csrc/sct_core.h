@@ -155,7 +155,53 @@ struct SctFamily {
     static constexpr bool ADJ = B == A + 1;
     static constexpr int KEYCH = LA + LB;
     static constexpr uint32_t NKEYS = 1u << (2 * KEYCH);
+    static constexpr int INDEX = F;
+    static constexpr int BL = 16;
 };
+
+// The same description with run-time piece boundaries, for barcode lengths 8..16 other than 16: the barcode is cut
+// into four pieces at floor(i * bl / 4) (sizes differ by at most one); the completeness argument does not depend on
+// the piece sizes.  Only the quarter families exist at run time.  Keys have at most 8 characters (16 bits).
+struct SctFamilyRT {
+    int A, B, PA, LA, PB, LB, GAP, SLACK, KEYCH, INDEX, BL;
+    bool ADJ;
+};
+SCT_HD SctFamilyRT sct_family_rt(int f, int bl) {
+    SctFamilyRT r;
+    r.A = f == SCT_F_H1 ? 0 : f == SCT_F_H2 ? 2 : f == SCT_F_MID ? 1 : f == SCT_F_02 ? 0 : f == SCT_F_13 ? 1 : 0;
+    r.B = f == SCT_F_H1 ? 1 : f == SCT_F_H2 ? 3 : f == SCT_F_MID ? 2 : f == SCT_F_02 ? 2 : f == SCT_F_13 ? 3 : 3;
+    r.PA = r.A * bl / 4;
+    r.LA = (r.A + 1) * bl / 4 - r.PA;
+    r.PB = r.B * bl / 4;
+    r.LB = (r.B + 1) * bl / 4 - r.PB;
+    r.GAP = r.PB - r.PA;
+    r.SLACK = r.B - r.A - 1;
+    r.ADJ = r.B == r.A + 1;
+    r.KEYCH = r.LA + r.LB;
+    r.INDEX = f;
+    r.BL = bl;
+    return r;
+}
+
+// generic forms over a family description `fam` (SctFamily<F>{} folds to constants, SctFamilyRT does not)
+template <typename W, typename Fam>
+SCT_HD uint32_t sct_key_of(const Fam &fam, W lo, W hi, int t, int t2) {
+    const int LA = fam.LA, LB = fam.LB, K = fam.KEYCH;
+    if (fam.ADJ) {
+        return ((uint32_t)(lo >> t) & ((1u << K) - 1u)) | (((uint32_t)(hi >> t) & ((1u << K) - 1u)) << K);
+    } else {
+        const uint32_t l = ((uint32_t)(lo >> t) & ((1u << LA) - 1u)) | (((uint32_t)(lo >> t2) & ((1u << LB) - 1u)) << LA);
+        const uint32_t h = ((uint32_t)(hi >> t) & ((1u << LA) - 1u)) | (((uint32_t)(hi >> t2) & ((1u << LB) - 1u)) << LA);
+        return l | (h << K);
+    }
+}
+template <typename Fam>
+SCT_HD bool sct_valid_of(const Fam &fam, int t2, int len) { return t2 + fam.LB <= len; }
+template <typename Fam, typename Fn>
+SCT_HD void sct_for_each_placement_of(const Fam &fam, int len, Fn &&fn) {
+    for (int d = -fam.SLACK; d <= fam.SLACK; d++)
+        for (int t = 0; t + fam.GAP + d + fam.LB <= len; t++) fn(t, t + fam.GAP + d);
+}
 
 // key of the text (planes lo/hi, W = uint32_t up to 31 characters, uint64_t up to 63) for pieces at t and t2:
 // the low KEYCH bits come from the lo plane, the next KEYCH bits from the hi plane
@@ -293,21 +339,24 @@ SCT_HD W sct_valid_mask(int len) {
     return len >= (int)(8 * sizeof(W)) - 1 ? ~(W)0 : (((W)1 << (len + 1)) - 1);
 }
 
+template <int E, typename W, typename Fam, typename EmFetch>
+SCT_HD int wm_anchored_of(const Fam &fam, EmFetch &&em, W va, uint32_t code, int t, int t2) {
+    WmState<E, W> s;
+    s.set(fam.PA == 0 ? ((W)1 << t) : va);
+    for (int j = 0; j < fam.PA; j++) s.step(em((code >> (2 * j)) & 3u));
+    if (fam.ADJ) {
+        s.anchor(t, fam.LA + fam.LB);
+    } else {
+        s.anchor(t, fam.LA);
+        for (int j = fam.PA + fam.LA; j < fam.PB; j++) s.step(em((code >> (2 * j)) & 3u));
+        s.anchor(t2, fam.LB);
+    }
+    for (int j = fam.PB + fam.LB; j < fam.BL; j++) s.step(em((code >> (2 * j)) & 3u));
+    return s.result(va);
+}
 template <int E, int F, typename W, typename EmFetch>
 SCT_HD int wm_anchored(EmFetch &&em, W va, uint32_t code, int t, int t2) {
-    using Fam = SctFamily<F>;
-    WmState<E, W> s;
-    s.set(Fam::PA == 0 ? ((W)1 << t) : va);
-    for (int j = 0; j < Fam::PA; j++) s.step(em((code >> (2 * j)) & 3u));
-    if (Fam::ADJ) {
-        s.anchor(t, Fam::LA + Fam::LB);
-    } else {
-        s.anchor(t, Fam::LA);
-        for (int j = Fam::PA + Fam::LA; j < Fam::PB; j++) s.step(em((code >> (2 * j)) & 3u));
-        s.anchor(t2, Fam::LB);
-    }
-    for (int j = Fam::PB + Fam::LB; j < 16; j++) s.step(em((code >> (2 * j)) & 3u));
-    return s.result(va);
+    return wm_anchored_of<E, W>(SctFamily<F>{}, em, va, code, t, t2);
 }
 
 // ---------------------------------------------------------------------------------------------------

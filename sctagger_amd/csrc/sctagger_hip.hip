@@ -364,8 +364,8 @@ struct FilterWave {
     W lo, hi;
     uint32_t head = 0, tail = 0;  // wave-uniform
 
-    template <int F>
-    __device__ __forceinline__ void verify(bool take) {
+    template <typename Fam>
+    __device__ __forceinline__ void verify(const Fam &fam, bool take) {
         if (take) {
             const uint32_t idx = (head + lane) & (QCAP - 1);
             const uint32_t gk = L.qk[idx], meta = L.qm[idx];
@@ -376,7 +376,7 @@ struct FilterWave {
             asm volatile("" ::"v"(code_), "v"(t), "v"(t2));
             const int d = E + 1;
 #else
-            const int d = wm_anchored<E, F, W>(EmLds<W>{&L.em[0][src]}, L.va[src], tab_code[gk], t, t2);
+            const int d = wm_anchored_of<E, W>(fam, EmLds<W>{&L.em[0][src]}, L.va[src], tab_code[gk], t, t2);
 #endif
             if (d <= E) {
                 const uint32_t pid = tab_ent[gk];
@@ -398,8 +398,8 @@ struct FilterWave {
     // Append the entry indices [s, e) of every lane to the queue: up to three entries per lane and pass, placed by
     // three ballots (entry j of a lane goes after all entries i < j of the wave and after entry j of the lanes
     // below it); 64-entry batches are verified as they form.  Buckets longer than three entries take more passes.
-    template <int F>
-    __device__ __forceinline__ void push_range(uint32_t s, uint32_t e, uint32_t meta) {
+    template <typename Fam>
+    __device__ __forceinline__ void push_range(const Fam &fam, uint32_t s, uint32_t e, uint32_t meta) {
         uint32_t c = e - s;
 #if SCT_PUSH_PER_PASS == 1
         for (;;) {
@@ -416,7 +416,7 @@ struct FilterWave {
             tail += (uint32_t)__popcll(m);
             __builtin_amdgcn_wave_barrier();
             if (tail - head >= 64) {
-                verify<F>(true);
+                verify(fam, true);
                 head += 64;
             }
         }
@@ -448,7 +448,7 @@ struct FilterWave {
             tail += n1 + n2 + n3;
             __builtin_amdgcn_wave_barrier();
             while (tail - head >= 64) {
-                verify<F>(true);
+                verify(fam, true);
                 head += 64;
             }
             if (m3 == 0) break;  // nobody had more than two entries: nothing is left
@@ -461,9 +461,8 @@ struct FilterWave {
     // even when most segments have settled.  The placements of the family for the longest segment of the wave are
     // tabulated in LDS once; a lane skips those its own segment is too short for.  The bucket range of a pass is
     // queued while the loads of the next pass are in flight.
-    template <int F>
-    __device__ __forceinline__ void run_family(int maxlen) {
-        using Fam = SctFamily<F>;
+    template <typename Fam>
+    __device__ __forceinline__ void run_family(const Fam &fam, int maxlen) {
         const uint64_t am = __ballot(active);
         if (am == 0) return;
         const int A = (int)__popcll(am);
@@ -471,10 +470,10 @@ struct FilterWave {
         // placement table
         int P = 0;
 #pragma unroll
-        for (int d = -Fam::SLACK; d <= Fam::SLACK; d++) {
-            const int c = maxlen - Fam::GAP - d - Fam::LB + 1;
+        for (int d = -fam.SLACK; d <= fam.SLACK; d++) {
+            const int c = maxlen - fam.GAP - d - fam.LB + 1;
             if (c > 0) {
-                for (int t = lane; t < c; t += 64) L.ptab[P + t] = (uint16_t)(t | ((t + Fam::GAP + d) << 8));
+                for (int t = lane; t < c; t += 64) L.ptab[P + t] = (uint16_t)(t | ((t + fam.GAP + d) << 8));
                 P += c;
             }
         }
@@ -493,8 +492,8 @@ struct FilterWave {
             shi = L.hi[sl];
             slen = (int)L.slen[sl];
         }
-        const uint32_t *off = tab_off + ft.off_base[F];
-        const uint32_t ebase = ft.ent_base[F];
+        const uint32_t *off = tab_off + ft.off_base[fam.INDEX];
+        const uint32_t ebase = ft.ent_base[fam.INDEX];
         uint32_t ps = 0, pe = 0, pmeta = 0;  // the pass whose loads were issued last
         bool pend = false;
         for (int p0 = 0; p0 < P; p0 += G) {
@@ -503,23 +502,23 @@ struct FilterWave {
             if (worker && p < P) {
                 const uint32_t tt = L.ptab[p];
                 const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
-                if (sct_placement_valid<F>(t2, slen)) {
+                if (sct_valid_of(fam, t2, slen)) {
                     // bucket start and end are neighbouring words: one 8-byte load (4-byte aligned)
-                    const OffPair op = *reinterpret_cast<const OffPair *>(off + sct_placement_key<F, W>(slo, shi, t, t2));
+                    const OffPair op = *reinterpret_cast<const OffPair *>(off + sct_key_of<W>(fam, slo, shi, t, t2));
                     s = op.a + ebase;
                     e = op.b + ebase;
                     meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
                 }
             }
-            if (pend) push_range<F>(ps, pe, pmeta);
+            if (pend) push_range(fam, ps, pe, pmeta);
             pend = true;
             ps = s;
             pe = e;
             pmeta = meta;
         }
-        if (pend) push_range<F>(ps, pe, pmeta);
+        if (pend) push_range(fam, ps, pe, pmeta);
         if (tail != head) {  // the family's last, partial batch
-            verify<F>((uint32_t)lane < tail - head);
+            verify(fam, (uint32_t)lane < tail - head);
             head = tail;
         }
     }
@@ -537,14 +536,16 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // KS / HM: ties kept per segment / verified matches kept per segment before the row is deferred.  The main launch
 // (KS 8, HM 16) covers all rows; rows it defers are retried by a launch with KS 32, HM 64 over the list `rows`
 // (16 listed rows per wave), and only what that launch defers again goes to the exhaustive scan.
-template <int E, typename W, bool THIRDS, int KS, int HM, int RPW>
+// RT = true: barcode length `bl` (8..16) other than 16, piece boundaries computed at run time (sct_family_rt).
+template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT>
 __global__ void __launch_bounds__(256)
 k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
          int64_t n, const int32_t *__restrict__ rows, const uint32_t *__restrict__ tab_off,
          const uint32_t *__restrict__ tab_ent, const uint32_t *__restrict__ tab_code, FamTables ft,
          uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
          uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer, uint32_t *__restrict__ defer_count,
-         unsigned long long *__restrict__ slot_cursor, uint64_t slot_tag) {
+         unsigned long long *__restrict__ slot_cursor, uint64_t slot_tag, int bl_arg) {
+    const int bl = RT ? bl_arg : 16;
     __shared__ FilterWaveLds<W, HM> lds[4];
     FilterWaveLds<W, HM> &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
@@ -560,7 +561,7 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     }
     if (active) {
         len = (int)(meta_in[r] & 0xFF);
-        active = len >= 16 - E;  // shorter rows were finished by k_pack
+        active = len >= bl - E;  // shorter rows were finished by k_pack
     }
     if (!active) len = 0;
     const int maxlen = wave_max_i(len);
@@ -585,27 +586,33 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     FilterWave<E, W, HM> W_{L, tab_off, tab_ent, tab_code, ft, lane, active, len, lo, hi};
+#define RUN_FAMILY(FID)                                                         \
+    do {                                                                        \
+        if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \
+        else W_.run_family(SctFamily<FID>{}, maxlen);                           \
+    } while (0)
     if (THIRDS) {
-        W_.template run_family<SCT_F_T01>(maxlen);
+        RUN_FAMILY(SCT_F_T01);
         if (E >= 1) {
             W_.settle(0);
-            W_.template run_family<SCT_F_T12>(maxlen);
-            W_.template run_family<SCT_F_T02>(maxlen);
+            RUN_FAMILY(SCT_F_T12);
+            RUN_FAMILY(SCT_F_T02);
         }
     } else {
-        W_.template run_family<SCT_F_H1>(maxlen);
+        RUN_FAMILY(SCT_F_H1);
         if (E >= 1) {
             W_.settle(0);
-            W_.template run_family<SCT_F_H2>(maxlen);
+            RUN_FAMILY(SCT_F_H2);
         }
         if (E >= 2) {
             W_.settle(1);
-            W_.template run_family<SCT_F_MID>(maxlen);
-            W_.template run_family<SCT_F_02>(maxlen);
-            W_.template run_family<SCT_F_13>(maxlen);
-            W_.template run_family<SCT_F_03>(maxlen);
+            RUN_FAMILY(SCT_F_MID);
+            RUN_FAMILY(SCT_F_02);
+            RUN_FAMILY(SCT_F_13);
+            RUN_FAMILY(SCT_F_03);
         }
     }
+#undef RUN_FAMILY
     const uint32_t nc = active ? L.hcnt[lane] : 0u;
     LaneResult<E, KS> res;
     res.init();
@@ -1355,10 +1362,10 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
     if (np) HIPCHK(hipMemcpyAsync(c->pat.p, pat.data(), sizeof(uint2) * (size_t)np, hipMemcpyHostToDevice, c->stream));
     c->have_tables = false;
     c->have_thirds = false;
-    if (bl == 16) {
+    if (bl >= 8 && bl <= 16) {
         // seed tables: counting sort of the pattern ids by key, per family (ids ascending inside a bucket).
         // The thirds families (20/22-bit keys) are only worth their 38 MB of offsets for very large barcode sets.
-        const bool thirds = np >= THIRDS_MIN_PATTERNS;
+        const bool thirds = bl == 16 && np >= THIRDS_MIN_PATTERNS;
         const int nfam = thirds ? SCT_NFAM_ALL : SCT_NFAM;
         FamTables ft{};
         size_t off_total = 0;
@@ -1373,19 +1380,24 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
         std::vector<uint32_t> inter((size_t)(np ? np : 1));
         for (int p = 0; p < np; p++) {
             uint32_t v = 0;
-            for (int j = 0; j < 16; j++) v |= (((pat[p].x >> j) & 1u) | (((pat[p].y >> j) & 1u) << 1)) << (2 * j);
+            for (int j = 0; j < bl; j++) v |= (((pat[p].x >> j) & 1u) | (((pat[p].y >> j) & 1u) << 1)) << (2 * j);
             inter[p] = v;
         }
         for (int f = 0; f < nfam; f++) {
             const uint32_t nk = sct_family_nkeys(f);
             uint32_t *o = off.data() + ft.off_base[f];
-            for (int p = 0; p < np; p++) o[sct_pattern_key(f, pat[p].x, pat[p].y) + 1]++;
+            auto key_of = [&](int p) {  // quarter families: piece boundaries from the barcode length
+                if (f >= SCT_NFAM) return sct_pattern_key(f, pat[p].x, pat[p].y);
+                const SctFamilyRT fam = sct_family_rt(f, bl);
+                return sct_key_of<uint32_t>(fam, pat[p].x, pat[p].y, fam.PA, fam.PB);
+            };
+            for (int p = 0; p < np; p++) o[key_of(p) + 1]++;
             for (uint32_t k = 0; k < nk; k++) o[k + 1] += o[k];
             std::vector<uint32_t> cur(o, o + nk);
             uint32_t *e = ent.data() + (size_t)f * np;
             uint32_t *cd = code.data() + (size_t)f * np;
             for (int p = 0; p < np; p++) {
-                const uint32_t at = cur[sct_pattern_key(f, pat[p].x, pat[p].y)]++;
+                const uint32_t at = cur[key_of(p)]++;
                 e[at] = (uint32_t)p;
                 cd[at] = inter[p];
             }
@@ -1458,6 +1470,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     const int prefix_len = sct_prefix_len(threads);
     const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && np <= (int)PID_MASK;
     const bool use_thirds = filter_ok && c->have_thirds && max_err <= 1 && c->filter_mode != 1 && !c->no_thirds;
+    const bool rt_families = bl != 16;  // quarter families with run-time piece boundaries
     const size_t n1 = (size_t)(n ? n : 1);
     if (c->lo.ensure(8 * n1) || c->hi.ensure(8 * n1) || c->meta.ensure(4 * n1) || c->min_e.ensure(n1) ||
         c->cnt.ensure(4 * n1) || c->route.ensure(4 * n1) || c->list_scan.ensure(4 * n1) || c->list_dp.ensure(4 * n1) ||
@@ -1476,7 +1489,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         {
             Timer t(c, "k_pack");
             k_pack<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), n, bl, max_err, prefix_len,
-                                                       !filter_ok ? 0 : (c->filter_mode == 1 ? 31 : PLANE_MAX), c->lo.as<uint64_t>(),
+                                                       !filter_ok ? 0 : ((c->filter_mode == 1 && bl == 16) ? 31 : PLANE_MAX), c->lo.as<uint64_t>(),
                                                        c->hi.as<uint64_t>(),
                                                        c->meta.as<uint32_t>(), c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(),
                                                        c->list_scan.as<int32_t>(), c->list_dp.as<int32_t>(), counters);
@@ -1492,15 +1505,20 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), n, (const int32_t *)nullptr,                   \
         c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->ft, c->min_e.as<uint8_t>(), \
         c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_retry.as<int32_t>(),       \
-        counters + 2, reinterpret_cast<unsigned long long *>(counters + 4), 0ull
+        counters + 2, reinterpret_cast<unsigned long long *>(counters + 4), 0ull, bl
 #define LAUNCH_WAVE(E, TH)                                                                                            \
     do {                                                                                                              \
-        k_filter<E, uint32_t, TH, K_SLOTS, HMAX, 64><<<g, 256, 0, st>>>(WAVE_ARGS);                                    \
-        k_filter<E, uint64_t, TH, K_SLOTS, HMAX, 64><<<g, 256, 0, st>>>(WAVE_ARGS);                                    \
+        if (rt_families) {                                                                                            \
+            k_filter<E, uint32_t, false, K_SLOTS, HMAX, 64, true><<<g, 256, 0, st>>>(WAVE_ARGS);                       \
+            k_filter<E, uint64_t, false, K_SLOTS, HMAX, 64, true><<<g, 256, 0, st>>>(WAVE_ARGS);                       \
+        } else {                                                                                                      \
+            k_filter<E, uint32_t, TH, K_SLOTS, HMAX, 64, false><<<g, 256, 0, st>>>(WAVE_ARGS);                         \
+            k_filter<E, uint64_t, TH, K_SLOTS, HMAX, 64, false><<<g, 256, 0, st>>>(WAVE_ARGS);                         \
+        }                                                                                                             \
     } while (0)
 #define LAUNCH_FILTER(E)                                                                                              \
     do {                                                                                                              \
-        if (c->filter_mode == 1) k_filter_lane<E><<<g, 256, 0, st>>>(LANE_ARGS);                                       \
+        if (c->filter_mode == 1 && !rt_families) k_filter_lane<E><<<g, 256, 0, st>>>(LANE_ARGS);                                       \
         else LAUNCH_WAVE(E, false);                                                                                   \
     } while (0)
             if (use_thirds && max_err == 0) LAUNCH_WAVE(0, true);
@@ -1519,7 +1537,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     HIPCHK(hipMemcpyAsync(hc, c->counters.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const int64_t n_retried = hc[2];
-    if (n > 0 && filter_ok && c->filter_mode != 1 && hc[2] > 0) {
+    if (n > 0 && filter_ok && !(c->filter_mode == 1 && !rt_families) && hc[2] > 0) {
         // rows with more ties / verified matches than the main launch keeps: once more with larger lists
         const int64_t nr = hc[2];
         if (c->slots_retry.ensure(4 * (size_t)nr * K_RETRY)) return SCT_E_HIP;
@@ -1529,11 +1547,16 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), nr, c->list_retry.as<int32_t>(),               \
         c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->ft, c->min_e.as<uint8_t>(), \
         c->cnt.as<uint32_t>(), c->slots_retry.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_scan.as<int32_t>(),  \
-        counters + 0, reinterpret_cast<unsigned long long *>(counters + 6), SLOT_TAG_RETRY
+        counters + 0, reinterpret_cast<unsigned long long *>(counters + 6), SLOT_TAG_RETRY, bl
 #define LAUNCH_RETRY(E, TH)                                                                                           \
     do {                                                                                                              \
-        k_filter<E, uint32_t, TH, K_RETRY, H_RETRY, 16><<<g, 256, 0, st>>>(RETRY_ARGS);                                \
-        k_filter<E, uint64_t, TH, K_RETRY, H_RETRY, 16><<<g, 256, 0, st>>>(RETRY_ARGS);                                \
+        if (rt_families) {                                                                                            \
+            k_filter<E, uint32_t, false, K_RETRY, H_RETRY, 16, true><<<g, 256, 0, st>>>(RETRY_ARGS);                   \
+            k_filter<E, uint64_t, false, K_RETRY, H_RETRY, 16, true><<<g, 256, 0, st>>>(RETRY_ARGS);                   \
+        } else {                                                                                                      \
+            k_filter<E, uint32_t, TH, K_RETRY, H_RETRY, 16, false><<<g, 256, 0, st>>>(RETRY_ARGS);                     \
+            k_filter<E, uint64_t, TH, K_RETRY, H_RETRY, 16, false><<<g, 256, 0, st>>>(RETRY_ARGS);                     \
+        }                                                                                                             \
     } while (0)
         if (use_thirds && max_err == 0) LAUNCH_RETRY(0, true);
         else if (use_thirds) LAUNCH_RETRY(1, true);

@@ -118,6 +118,31 @@ static int anchored_thirds(const std::vector<int> &p, const std::vector<int> &t)
     return b;
 }
 
+// run-time families (barcode lengths 8..16): minimum anchored distance over all six quarter families
+template <int E>
+static int anchored_rt(const std::vector<int> &p, const std::vector<int> &t) {
+    const int bl = (int)p.size(), L = (int)t.size();
+    uint64_t plo, phi, tlo, thi;
+    planes(p, plo, phi);
+    planes(t, tlo, thi);
+    EmArray<uint32_t> em;
+    const uint32_t va = sct_valid_mask<uint32_t>(L), ve = va & ~1u, l1 = (uint32_t)tlo << 1, h1 = (uint32_t)thi << 1;
+    em.m[0] = ~l1 & ~h1 & ve; em.m[1] = l1 & ~h1 & ve; em.m[2] = ~l1 & h1 & ve; em.m[3] = l1 & h1 & ve;
+    uint32_t code = 0;
+    for (int j = 0; j < bl; j++) code |= (uint32_t)p[j] << (2 * j);
+    int best = E + 1;
+    const int nf = E == 0 ? 1 : E == 1 ? 2 : 6;
+    for (int f = 0; f < nf; f++) {
+        const SctFamilyRT fam = sct_family_rt(f, bl);
+        const uint32_t pkey = sct_key_of<uint32_t>(fam, (uint32_t)plo, (uint32_t)phi, fam.PA, fam.PB);
+        sct_for_each_placement_of(fam, L, [&](int a, int b) {
+            if (sct_key_of<uint32_t>(fam, (uint32_t)tlo, (uint32_t)thi, a, b) != pkey) return;
+            best = std::min(best, wm_anchored_of<E, uint32_t>(fam, em, va, code, a, b));
+        });
+    }
+    return best;
+}
+
 struct SeedHit {
     const uint32_t *keys;  // the pattern's family keys
     bool hit = false;
@@ -298,6 +323,31 @@ int main() {
         if (anchored<1, uint64_t>(p, t) != std::min(want, 2)) { printf("FAIL anchored64/1\n"); return 1; }
         if (anchored<2, uint64_t>(p, t) != std::min(want, 3)) { printf("FAIL anchored64/2 want=%d got=%d n=%zu\n", want, anchored<2, uint64_t>(p, t), t.size()); return 1; }
         if (t.size() <= 31 && anchored<2, uint32_t>(p, t) != std::min(want, 3)) { printf("FAIL anchored32 vs 64\n"); return 1; }
+        checked++;
+    }
+    // 2c. run-time piece boundaries: barcode lengths 8..16, texts 0..31
+    for (int it = 0; it < 200000; it++) {
+        const int m = 8 + rnd(9), alpha = (it % 7 == 0) ? 2 : 4;
+        int n = rnd(32);
+        std::vector<int> p(m), t;
+        for (auto &x : p) x = rnd(alpha);
+        std::vector<int> c(p);
+        for (int k = rnd(4); k > 0; k--) {
+            int kind = rnd(3), pos = rnd((int)c.size() + (kind == 1));
+            if (kind == 0 && !c.empty()) c[std::min(pos, (int)c.size() - 1)] = rnd(4);
+            else if (kind == 1) c.insert(c.begin() + pos, rnd(4));
+            else if (!c.empty()) c.erase(c.begin() + std::min(pos, (int)c.size() - 1));
+        }
+        int left = rnd(8);
+        for (int i = 0; i < left; i++) t.push_back(rnd(alpha));
+        if (rnd(5)) t.insert(t.end(), c.begin(), c.end());
+        while ((int)t.size() < n) t.push_back(rnd(alpha));
+        if ((int)t.size() > 31) t.resize(31);
+        const int want = brute_infix(p, t);
+        if (anchored_rt<0>(p, t) != std::min(want, 1)) { printf("FAIL rt0 m=%d\n", m); return 1; }
+        if (anchored_rt<1>(p, t) != std::min(want, 2)) { printf("FAIL rt1 m=%d want=%d got=%d\n", m, want, anchored_rt<1>(p, t)); return 1; }
+        if (anchored_rt<2>(p, t) != std::min(want, 3)) { printf("FAIL rt2 m=%d want=%d got=%d n=%zu\n", m, want, anchored_rt<2>(p, t), t.size()); return 1; }
+        if (m == 16 && anchored_rt<2>(p, t) != anchored<2>(p, t)) { printf("FAIL rt vs static\n"); return 1; }
         checked++;
     }
     // 3. exhaustive seed completeness around one pattern: every text obtained by <= 2 edits of it

@@ -70,7 +70,7 @@ def test_gpu_fuzz_all_paths():
     rng = np.random.default_rng(2024)
     with _native.Matcher(0) as m:
         for trial in range(int(os.environ.get("SCT_FUZZ_TRIALS", "120"))):
-            bl = int(rng.choice([16, 16, 16, 16, 8, 12, 20, 32]))
+            bl = int(rng.choice([16, 16, 16, 16, 8, 9, 10, 11, 12, 13, 14, 15, 20, 32]))
             e = int(rng.integers(0, 4))
             if e >= bl:
                 e = bl - 1

@@ -54,6 +54,10 @@ def test_golden_reference_output(m, case):
     (20000, 2000, 16, 2, 1, 21), (20000, 3000, 16, 1, 1, 22), (20000, 3000, 16, 0, 16, 23),
     (3000, 300, 12, 3, 4, 24), (3000, 200, 20, 2, 1, 25), (2000, 100, 32, 4, 1, 26), (2000, 50, 5, 1, 1, 27),
     (1000, 4, 1, 0, 1, 28), (600, 64, 16, 4, 1, 29),
+    # barcode lengths 8..15 go through the seed filter with run-time piece boundaries
+    (5000, 500, 12, 2, 1, 40), (5000, 500, 8, 1, 4, 41), (5000, 800, 13, 2, 16, 42), (5000, 800, 15, 1, 1, 43),
+    (3000, 300, 10, 0, 1, 44), (3000, 400, 9, 2, 1, 45), (3000, 400, 11, 2, 1, 46), (3000, 400, 14, 2, 64, 47),
+    (20000, 3000, 12, 2, 1, 48),
 ])
 def test_seeded_vs_oracle(m, nseg, nbc, bl, e, t, seed):
     bc = synth.make_barcodes(nbc, bl=bl, seed=seed)
