@@ -57,6 +57,7 @@ int sct_prefix_len(int threads);
  *       are derived inside exactly as rev_compl does (:148-156: A<->T, C<->G, other bytes unchanged),
  *       and every byte is then mapped as map_char does (:512-516: ACGT -> 0..3, anything else -> 0).
  *   bl  barcode length (the reference asserts all barcodes have length -bl, :760-761), 1..SCT_MAX_BL.
+ *       Lengths 8..16 with max_err <= 2 use the seed-filter kernels, everything else the exhaustive scan.
  * A byte >= 128 is rejected with SCT_E_ARG (the reference raises IndexError there).
  */
 int sct_set_barcodes(sct_ctx *ctx, const char *bc, int32_t n, int32_t bl);
