@@ -44,7 +44,8 @@ def main():
     with open("profiles/%s_pmc_summary.json" % tag, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     # the dominant kernel's per-launch counters in the form bench.py quotes (roofline.traffic / roofline.valu)
-    dom = [k for k in out if k.startswith("k_filter<")]
+    dom = sorted([k for k in out if k.startswith("k_filter<")],
+                 key=lambda k: -out[k]["counters_avg_per_launch"].get("SQ_INSTS_VALU", 0))
     if dom and os.path.exists(bench):
         b = json.load(open(bench))
         d, c = out[dom[0]], out[dom[0]]["counters_avg_per_launch"]
