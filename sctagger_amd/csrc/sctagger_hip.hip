@@ -667,6 +667,8 @@ k_scan(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const
         if (FILL) {
             target = min_e[r];
             if (target == SCT_NO_HIT) continue;
+            // a slice whose own minimum is worse than the row's holds no hit: nothing to recompute
+            if (part_best[w] != (uint32_t)target) continue;
             // hits of the earlier slices at the same minimum come first
             uint32_t mine = 0;
             for (int sl = lane; sl < slice; sl += 64)
@@ -1579,6 +1581,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         if (rows == 0) return 1;
         const int tiles = (np + 63) / 64;
         int64_t sl = (16384 + rows - 1) / rows;   // aim at 16 k waves in flight
+        if (sl < 16) sl = 16;                       // and at least 16 slices: the fill pass skips the slices without a hit
         if (sl > 4096) sl = 4096;
         if (sl > tiles) sl = tiles;
         return (int)(sl < 1 ? 1 : sl);
