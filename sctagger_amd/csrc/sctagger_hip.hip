@@ -771,6 +771,121 @@ k_scan(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_scan_pk<FILL>: the Myers scan of k_scan for barcodes of at most 16 characters with TWO barcodes per lane, one in
+// each 16-bit half of the 32-bit state words (128 barcodes per wave step).  Bitwise operations and the +-1 score
+// updates act on both halves at once; only the addition of the carry chain needs the packed 16-bit add
+// (v_pk_add_u16) and the running minimum the packed min; the shifted words are masked so that nothing crosses from
+// the low half into the high one.  Same task decomposition, partial results and output order as k_scan.
+// ------------------------------------------------------------------------------------------------------------
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b));
+}
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_scan_pk(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const int32_t *__restrict__ list,
+          int64_t n_list, int n_slices, const uint2 *__restrict__ pat, int np, int bl, int max_err,
+          const uint8_t *__restrict__ min_e, uint32_t *__restrict__ part_best, uint32_t *__restrict__ part_cnt,
+          const int64_t *__restrict__ hit_offs, uint32_t *__restrict__ hits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int tiles = (np + 63) / 64;
+    const int tiles_per_slice = (tiles + n_slices - 1) / n_slices;
+    const uint32_t one = 0x00010001u;
+    for (int64_t w = wave; w < n_list * n_slices; w += n_waves) {
+        const int64_t li = w / n_slices;
+        const int slice = (int)(w - li * n_slices);
+        const int64_t r = (int64_t)list[li];
+        const int64_t b0 = offs[r];
+        const int64_t len = offs[r + 1] - b0;
+        const int p_begin = slice * tiles_per_slice * 64;
+        const int p_end = min(np, p_begin + tiles_per_slice * 64);
+        int target = 0;
+        int64_t out_base = 0;
+        if (FILL) {
+            target = min_e[r];
+            if (target == SCT_NO_HIT) continue;
+            if (part_best[w] != (uint32_t)target) continue;  // a slice whose own minimum is worse holds no hit
+            uint32_t mine = 0;
+            for (int sl = lane; sl < slice; sl += 64)
+                if (part_best[li * n_slices + sl] == (uint32_t)target) mine += part_cnt[li * n_slices + sl];
+            out_base = hit_offs[r] + wave_sum(mine);
+        }
+        int lane_best = max_err + 1;
+        uint32_t lane_cnt = 0;
+        uint32_t written = 0;  // wave-uniform
+        for (int p0 = p_begin; p0 < p_end; p0 += 128) {
+            const int pa = p0 + lane, pb = p0 + 64 + lane;
+            const bool va = pa < p_end, vb = pb < p_end;
+            const uint2 qa = va ? pat[pa] : make_uint2(0, 0);
+            const uint2 qb = vb ? pat[pb] : make_uint2(0, 0);
+            const uint32_t LO = (qa.x & 0xFFFFu) | (qb.x << 16), HI = (qa.y & 0xFFFFu) | (qb.y << 16);
+            uint32_t Pv = 0xFFFFFFFFu, Mv = 0u;
+            uint32_t score = (uint32_t)bl * one, best = score;
+            for (int64_t c0 = 0; c0 < len; c0 += 64) {
+                const int64_t ci = c0 + lane;
+                const uint32_t my = ci < len ? sct_code(segs[b0 + ci]) : 0u;
+                const int ncol = (int)(len - c0 < 64 ? len - c0 : 64);
+                for (int j = 0; j < ncol; j++) {
+                    const uint32_t c = __builtin_amdgcn_readlane(my, j);
+                    const uint32_t ml = 0u - (c & 1u), mh = 0u - (c >> 1);
+                    const uint32_t Eq = ~(LO ^ ml) & ~(HI ^ mh);
+                    const uint32_t Xv = Eq | Mv;
+                    const uint32_t Xh = (pk_add16(Eq & Pv, Pv) ^ Pv) | Eq;
+                    uint32_t Ph = Mv | ~(Xh | Pv);
+                    uint32_t Mh = Pv & Xh;
+                    score = score + ((Ph >> (bl - 1)) & one) - ((Mh >> (bl - 1)) & one);
+                    Ph = (Ph << 1) & 0xFFFEFFFEu;
+                    Mh = (Mh << 1) & 0xFFFEFFFEu;
+                    Pv = Mh | ~(Xv | Ph);
+                    Mv = Ph & Xv;
+                    best = pk_min16(best, score);
+                }
+            }
+            const int da = (int)(best & 0xFFFFu), db = (int)(best >> 16);
+            const bool oka = va && da <= max_err, okb = vb && db <= max_err;
+            if (!FILL) {
+                if (oka) {
+                    if (da < lane_best) {
+                        lane_best = da;
+                        lane_cnt = 0;
+                    }
+                    if (da == lane_best) lane_cnt++;
+                }
+                if (okb) {
+                    if (db < lane_best) {
+                        lane_best = db;
+                        lane_cnt = 0;
+                    }
+                    if (db == lane_best) lane_cnt++;
+                }
+            } else {
+                const bool hita = oka && da == target, hitb = okb && db == target;
+                const uint64_t m1 = __ballot(hita), m2 = __ballot(hitb);
+                const uint64_t below = (1ull << lane) - 1ull;
+                if (hita) hits[out_base + written + (uint32_t)__popcll(m1 & below)] = (uint32_t)pa;
+                written += (uint32_t)__popcll(m1);
+                if (hitb) hits[out_base + written + (uint32_t)__popcll(m2 & below)] = (uint32_t)pb;
+                written += (uint32_t)__popcll(m2);
+            }
+        }
+        if (!FILL) {
+            const int wb = wave_min(lane_best);
+            const uint32_t total = wave_sum(lane_best == wb ? lane_cnt : 0u);
+            if (lane == 0) {
+                part_best[w] = (uint32_t)wb;
+                part_cnt[w] = total;
+            }
+        }
+    }
+}
+
 // fold the per-slice partial results of k_scan's count pass: one lane per listed segment
 __global__ void __launch_bounds__(256)
 k_scan_reduce(const int32_t *__restrict__ list, int64_t n_list, int n_slices, int max_err,
@@ -1600,9 +1715,14 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     if (n > 0) {
         if (hc[0]) {
             Timer t(c, "k_scan_count");
-            k_scan<false, false><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
-                c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
-                np, bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_scan, pc_scan, nullptr, nullptr);
+            if (bl <= 16)
+                k_scan_pk<false><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
+                    c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
+                    np, bl, max_err, c->min_e.as<uint8_t>(), pb_scan, pc_scan, nullptr, nullptr);
+            else
+                k_scan<false, false><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
+                    c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
+                    np, bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_scan, pc_scan, nullptr, nullptr);
             k_scan_reduce<<<blocks_for(hc[0], 256), 256, 0, st>>>(c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, max_err, pb_scan,
                                                                   pc_scan, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>());
         }
@@ -1638,9 +1758,14 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         }
         if (hc[0]) {
             Timer t(c, "k_scan_fill");
-            k_scan<false, true><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
-                c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
-                np, bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_scan, pc_scan, c->hit_offs.as<int64_t>(), c->hits.as<uint32_t>());
+            if (bl <= 16)
+                k_scan_pk<true><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
+                    c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
+                    np, bl, max_err, c->min_e.as<uint8_t>(), pb_scan, pc_scan, c->hit_offs.as<int64_t>(), c->hits.as<uint32_t>());
+            else
+                k_scan<false, true><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
+                    c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
+                    np, bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_scan, pc_scan, c->hit_offs.as<int64_t>(), c->hits.as<uint32_t>());
         }
         if (hc[1]) {
             Timer t(c, "k_dp_fill");
