@@ -242,9 +242,8 @@ struct FilterLane {
     __device__ __forceinline__ void operator()(int f, uint32_t key) {
         const uint32_t *off = tab_off + (size_t)f * (SCT_KEYS + 1) + key;
         const uint32_t s = off[0], e = off[1];
-        const uint32_t *ent = tab_ent + (size_t)f * np;
-        for (uint32_t k = s; k < e; k++) {
-            const uint32_t pid = ent[k];
+        for (uint32_t k = s; k < e; k++) {  // offsets index the concatenated entry table
+            const uint32_t pid = tab_ent[k];
             const uint2 p = pat[pid];
             res.add(wm_verify<E>(tls, ths, ve, va, p.x, p.y, 16), pid);
         }
@@ -314,10 +313,10 @@ static constexpr int K_RETRY = 32, H_RETRY = 64;  // retry launch
 static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
 static constexpr uint32_t PID_MASK = (1u << 30) - 1u;  // pattern id in a hit-list entry (2 bits of distance above it)
 
-// where each family's offsets and entries start inside the concatenated tables
+// where each family's offsets start inside the concatenated offset table; the offsets themselves index the
+// concatenated entry tables (family f's entries start at f * np)
 struct FamTables {
     uint32_t off_base[SCT_NFAM_ALL];
-    uint32_t ent_base[SCT_NFAM_ALL];
 };
 
 template <typename W, int HM>
@@ -493,7 +492,6 @@ struct FilterWave {
             slen = (int)L.slen[sl];
         }
         const uint32_t *off = tab_off + ft.off_base[fam.INDEX];
-        const uint32_t ebase = ft.ent_base[fam.INDEX];
         uint32_t ps = 0, pe = 0, pmeta = 0;  // the pass whose loads were issued last
         bool pend = false;
         for (int p0 = 0; p0 < P; p0 += G) {
@@ -505,9 +503,13 @@ struct FilterWave {
                 if (sct_valid_of(fam, t2, slen)) {
                     // bucket start and end are neighbouring words: one 8-byte load (4-byte aligned)
                     const OffPair op = *reinterpret_cast<const OffPair *>(off + sct_key_of<W>(fam, slo, shi, t, t2));
-                    s = op.a + ebase;
-                    e = op.b + ebase;
+                    s = op.a;  // absolute entry indices: nothing depends on the load until the range is queued,
+                    e = op.b;  // one pass later
                     meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
+#ifdef SCT_ABLATE_PUSH  // timing-only build: the bucket range is loaded but nothing is queued
+                    asm volatile("" ::"v"(s), "v"(e), "v"(meta));
+                    e = s;
+#endif
                 }
             }
             if (pend) push_range(fam, ps, pe, pmeta);
@@ -1490,7 +1492,6 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             if (off_total + sct_family_nkeys(f) + 1 > 0xFFFFFFFFull || (uint64_t)(f + 1) * (uint64_t)np > 0xFFFFFFFFull)
                 return fail(SCT_E_UNSUPPORTED, "too many barcodes for the seed tables");
             ft.off_base[f] = (uint32_t)off_total;
-            ft.ent_base[f] = (uint32_t)((size_t)f * np);
             off_total += (size_t)sct_family_nkeys(f) + 1;
         }
         std::vector<uint32_t> off(off_total, 0u), ent((size_t)nfam * (np ? np : 1)), code((size_t)nfam * (np ? np : 1));
@@ -1509,14 +1510,13 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
                 return sct_key_of<uint32_t>(fam, pat[p].x, pat[p].y, fam.PA, fam.PB);
             };
             for (int p = 0; p < np; p++) o[key_of(p) + 1]++;
+            o[0] = (uint32_t)((size_t)f * np);
             for (uint32_t k = 0; k < nk; k++) o[k + 1] += o[k];
             std::vector<uint32_t> cur(o, o + nk);
-            uint32_t *e = ent.data() + (size_t)f * np;
-            uint32_t *cd = code.data() + (size_t)f * np;
             for (int p = 0; p < np; p++) {
                 const uint32_t at = cur[key_of(p)]++;
-                e[at] = (uint32_t)p;
-                cd[at] = inter[p];
+                ent[at] = (uint32_t)p;
+                code[at] = inter[p];
             }
         }
         if (c->tab_off.ensure(off.size() * sizeof(uint32_t) + 16)) return SCT_E_HIP;
