@@ -339,20 +339,37 @@ SCT_HD W sct_valid_mask(int len) {
     return len >= (int)(8 * sizeof(W)) - 1 ? ~(W)0 : (((W)1 << (len + 1)) - 1);
 }
 
+// The characters of a barcode OUTSIDE the two pieces of `fam`, in barcode order, 2 bits each from bit 0 (at most 8
+// characters for the quarter families of any length 8..16): all the automaton below needs of a candidate, since the
+// piece characters are the key it was found under.
+SCT_HD uint32_t sct_low_bits(int k) { return k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u); }
+template <typename Fam>
+SCT_HD uint32_t sct_rest_of(const Fam &fam, uint32_t code) {
+    const int n0 = fam.PA, s1 = fam.PA + fam.LA, n1 = fam.PB - s1, s2 = fam.PB + fam.LB, n2 = fam.BL - s2;
+    uint32_t r = code & sct_low_bits(2 * n0);
+    if (n1 > 0) r |= ((code >> (2 * s1)) & sct_low_bits(2 * n1)) << (2 * n0);
+    if (n2 > 0) r |= ((code >> (2 * s2)) & sct_low_bits(2 * n2)) << (2 * (n0 + n1));
+    return r;
+}
+
 template <int E, typename W, typename Fam, typename EmFetch>
-SCT_HD int wm_anchored_of(const Fam &fam, EmFetch &&em, W va, uint32_t code, int t, int t2) {
+SCT_HD int wm_anchored_rest(const Fam &fam, EmFetch &&em, W va, uint32_t rest, int t, int t2) {
     WmState<E, W> s;
     s.set(fam.PA == 0 ? ((W)1 << t) : va);
-    for (int j = 0; j < fam.PA; j++) s.step(em((code >> (2 * j)) & 3u));
+    for (int j = 0; j < fam.PA; j++, rest >>= 2) s.step(em(rest & 3u));
     if (fam.ADJ) {
         s.anchor(t, fam.LA + fam.LB);
     } else {
         s.anchor(t, fam.LA);
-        for (int j = fam.PA + fam.LA; j < fam.PB; j++) s.step(em((code >> (2 * j)) & 3u));
+        for (int j = fam.PA + fam.LA; j < fam.PB; j++, rest >>= 2) s.step(em(rest & 3u));
         s.anchor(t2, fam.LB);
     }
-    for (int j = fam.PB + fam.LB; j < fam.BL; j++) s.step(em((code >> (2 * j)) & 3u));
+    for (int j = fam.PB + fam.LB; j < fam.BL; j++, rest >>= 2) s.step(em(rest & 3u));
     return s.result(va);
+}
+template <int E, typename W, typename Fam, typename EmFetch>
+SCT_HD int wm_anchored_of(const Fam &fam, EmFetch &&em, W va, uint32_t code, int t, int t2) {
+    return wm_anchored_rest<E, W>(fam, em, va, sct_rest_of(fam, code), t, t2);
 }
 template <int E, int F, typename W, typename EmFetch>
 SCT_HD int wm_anchored(EmFetch &&em, W va, uint32_t code, int t, int t2) {

@@ -349,13 +349,24 @@ struct EmLds {
     __device__ __forceinline__ W operator()(uint32_t c) const { return base[c * 64]; }
 };
 
-template <int E, typename W, int HM>
+// Bucket slots (SL = true, the quarter families): one 8-byte word per key that answers most lookups by itself.
+//   bit 15 clear: bits 0..1 = n <= 3 entries in the bucket, bits 16j+16 .. 16j+31 = the REST characters of entry j
+//                 (sct_rest_of: all the verification needs besides the key); no other table is read unless the
+//                 entry verifies, and then its pattern id is tab_ent[off[key] + j]
+//   bit 15 set:   a longer bucket: bits 16..47 = its first entry index, bits 0..14 | bits 48..63 << 15 = its length;
+//                 the entries are queued by index and verified from tab_code as without slots
+// A queued entry is (qk, qm): qm = lane | t << 8 | t2 << 16 | j << 24 | inline << 31; qk = rest characters (inline)
+// or entry index.
+static constexpr uint32_t QM_INLINE = 0x80000000u;
+
+template <int E, typename W, int HM, bool SL>
 struct FilterWave {
     static constexpr int HMAX = HM;
     FilterWaveLds<W, HM> &L;
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
     const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
+    const uint2 *__restrict__ tab_slot;     // bucket slots, indexed like tab_off
     FamTables ft;
     int lane;
     bool active;
@@ -367,17 +378,22 @@ struct FilterWave {
     __device__ __forceinline__ void verify(const Fam &fam, bool take) {
         if (take) {
             const uint32_t idx = (head + lane) & (QCAP - 1);
-            const uint32_t gk = L.qk[idx], meta = L.qm[idx];
+            uint32_t gk = L.qk[idx];
+            const uint32_t meta = L.qm[idx];
             const uint32_t src = meta & 63u;
             const int t = (int)((meta >> 8) & 63u), t2 = (int)((meta >> 16) & 63u);
+            const bool inl = SL && (meta & QM_INLINE) != 0u;
+            uint32_t rest = gk;  // an inline entry carries its rest characters (bits above them are ignored)
+            if (!inl) rest = sct_rest_of(fam, tab_code[gk]);
 #ifdef SCT_ABLATE_VERIFY  // timing-only build: candidates are fetched but never run through the automaton
-            const uint32_t code_ = tab_code[gk];
-            asm volatile("" ::"v"(code_), "v"(t), "v"(t2));
+            asm volatile("" ::"v"(rest), "v"(t), "v"(t2));
             const int d = E + 1;
 #else
-            const int d = wm_anchored_of<E, W>(fam, EmLds<W>{&L.em[0][src]}, L.va[src], tab_code[gk], t, t2);
+            const int d = wm_anchored_rest<E, W>(fam, EmLds<W>{&L.em[0][src]}, L.va[src], rest, t, t2);
 #endif
             if (d <= E) {
+                if (inl)
+                    gk = tab_off[ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.lo[src], L.hi[src], t, t2)] + ((meta >> 24) & 3u);
                 const uint32_t pid = tab_ent[gk];
                 atomicMin(&L.best[src], (uint32_t)d);
                 const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
@@ -394,22 +410,40 @@ struct FilterWave {
         if (active && L.best[lane] <= tier) active = false;
     }
 
-    // Append the entry indices [s, e) of every lane to the queue: up to three entries per lane and pass, placed by
-    // three ballots (entry j of a lane goes after all entries i < j of the wave and after entry j of the lanes
-    // below it); 64-entry batches are verified as they form.  Buckets longer than three entries take more passes.
+    // Append the bucket of every lane to the queue, one entry per lane and pass (position = tail + rank of the lane
+    // among those that still have one); 64-entry batches are verified as they form.  (a, b) are the two words the
+    // lookup loaded: a bucket slot (SL) or the bucket's first and end entry index.
     template <typename Fam>
-    __device__ __forceinline__ void push_range(const Fam &fam, uint32_t s, uint32_t e, uint32_t meta) {
-        uint32_t c = e - s;
-#if SCT_PUSH_PER_PASS == 1
+    __device__ __forceinline__ void push_range(const Fam &fam, uint32_t a, uint32_t b, uint32_t meta) {
+        uint32_t c, A, B = 0, sh = 0, inc = 1, jinc = 0;
+        if constexpr (SL) {
+            const bool inl = (a & 0x8000u) == 0u;
+            A = __builtin_amdgcn_alignbit(b, a, 16);  // slot bits 16..47: two rests, or the first entry index
+            B = inl ? b >> 16 : 0u;                   // slot bits 48..63: the third rest
+            c = inl ? (a & 0xFFFFu) : ((a & 0x7FFFu) | ((b >> 16) << 15));
+            sh = inl ? 16u : 0u;
+            inc = inl ? 0u : 1u;
+            jinc = inl ? (1u << 24) : 0u;
+            if (inl) meta |= QM_INLINE;
+        } else {
+            A = a;
+            c = b - a;
+        }
         for (;;) {
             const bool has = c > 0;
             const uint64_t m = __ballot(has);
             if (m == 0) break;
             if (has) {
                 const uint32_t idx = (tail + lane_rank(m)) & (QCAP - 1);
-                L.qk[idx] = s;
+                L.qk[idx] = A;
                 L.qm[idx] = meta;
-                s++;
+                if constexpr (SL) {
+                    A = __builtin_amdgcn_alignbit(B, A, sh) + inc;  // next rest moves down / next entry index
+                    B >>= sh;
+                    meta += jinc;
+                } else {
+                    A++;
+                }
                 c--;
             }
             tail += (uint32_t)__popcll(m);
@@ -418,39 +452,6 @@ struct FilterWave {
                 verify(fam, true);
                 head += 64;
             }
-        }
-        return;
-#endif
-        for (;;) {
-            const uint64_t m1 = __ballot(c >= 1u);
-            if (m1 == 0) break;
-            const uint64_t m2 = __ballot(c >= 2u), m3 = __ballot(c >= 3u);
-            const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2), n3 = (uint32_t)__popcll(m3);
-            if (c >= 1u) {
-                const uint32_t idx = (tail + lane_rank(m1)) & (QCAP - 1);
-                L.qk[idx] = s;
-                L.qm[idx] = meta;
-            }
-            if (c >= 2u) {
-                const uint32_t idx = (tail + n1 + lane_rank(m2)) & (QCAP - 1);
-                L.qk[idx] = s + 1;
-                L.qm[idx] = meta;
-            }
-            if (c >= 3u) {
-                const uint32_t idx = (tail + n1 + n2 + lane_rank(m3)) & (QCAP - 1);
-                L.qk[idx] = s + 2;
-                L.qm[idx] = meta;
-            }
-            const uint32_t took = c < 3u ? c : 3u;
-            s += took;
-            c -= took;
-            tail += n1 + n2 + n3;
-            __builtin_amdgcn_wave_barrier();
-            while (tail - head >= 64) {
-                verify(fam, true);
-                head += 64;
-            }
-            if (m3 == 0) break;  // nobody had more than two entries: nothing is left
         }
     }
 
@@ -492,6 +493,7 @@ struct FilterWave {
             slen = (int)L.slen[sl];
         }
         const uint32_t *off = tab_off + ft.off_base[fam.INDEX];
+        const uint2 *slot = tab_slot + ft.off_base[fam.INDEX];
         uint32_t ps = 0, pe = 0, pmeta = 0;  // the pass whose loads were issued last
         bool pend = false;
         for (int p0 = 0; p0 < P; p0 += G) {
@@ -501,14 +503,22 @@ struct FilterWave {
                 const uint32_t tt = L.ptab[p];
                 const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
                 if (sct_valid_of(fam, t2, slen)) {
-                    // bucket start and end are neighbouring words: one 8-byte load (4-byte aligned)
-                    const OffPair op = *reinterpret_cast<const OffPair *>(off + sct_key_of<W>(fam, slo, shi, t, t2));
-                    s = op.a;  // absolute entry indices: nothing depends on the load until the range is queued,
-                    e = op.b;  // one pass later
+                    // one 8-byte load: the bucket's slot, or its start and end (neighbouring words, 4-byte aligned;
+                    // absolute entry indices).  Nothing depends on the load until the bucket is queued, one pass later.
+                    const uint32_t key = sct_key_of<W>(fam, slo, shi, t, t2);
+                    if constexpr (SL) {
+                        const uint2 sv = slot[key];
+                        s = sv.x;
+                        e = sv.y;
+                    } else {
+                        const OffPair op = *reinterpret_cast<const OffPair *>(off + key);
+                        s = op.a;
+                        e = op.b;
+                    }
                     meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
 #ifdef SCT_ABLATE_PUSH  // timing-only build: the bucket range is loaded but nothing is queued
                     asm volatile("" ::"v"(s), "v"(e), "v"(meta));
-                    e = s;
+                    s = e = 0;
 #endif
                 }
             }
@@ -543,8 +553,8 @@ template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT>
 __global__ void __launch_bounds__(256)
 k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
          int64_t n, const int32_t *__restrict__ rows, const uint32_t *__restrict__ tab_off,
-         const uint32_t *__restrict__ tab_ent, const uint32_t *__restrict__ tab_code, FamTables ft,
-         uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
+         const uint32_t *__restrict__ tab_ent, const uint32_t *__restrict__ tab_code,
+         const uint2 *__restrict__ tab_slot, FamTables ft, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
          uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer, uint32_t *__restrict__ defer_count,
          unsigned long long *__restrict__ slot_cursor, uint64_t slot_tag, int bl_arg) {
     const int bl = RT ? bl_arg : 16;
@@ -587,7 +597,7 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.best[lane] = E + 1;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    FilterWave<E, W, HM> W_{L, tab_off, tab_ent, tab_code, ft, lane, active, len, lo, hi};
+    FilterWave<E, W, HM, !THIRDS> W_{L, tab_off, tab_ent, tab_code, tab_slot, ft, lane, active, len, lo, hi};
 #define RUN_FAMILY(FID)                                                         \
     do {                                                                        \
         if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \
@@ -1300,7 +1310,7 @@ struct sct_ctx {
     int n_bc = 0, bl = 0, np = 0;
     bool have_bc = false, have_tables = false, have_thirds = false;
     FamTables ft{};
-    DevBuf pat, tab_off, tab_ent, tab_code;
+    DevBuf pat, tab_off, tab_ent, tab_code, tab_slot;
     // segments
     int64_t n_seg = -1, seg_bytes = 0;
     DevBuf segs, offs;
@@ -1395,7 +1405,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
+    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->tab_slot, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
                       &c->cnt, &c->route, &c->slots, &c->slots_retry, &c->list_retry, &c->slot_off, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
                       &c->total, &c->hits, &c->part_best, &c->part_cnt, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip, &c->ad_peq, &c->ad_strand, &c->ad_dist, &c->ad_locs, &c->ad_first, &c->ad_last};
     for (DevBuf *b : bufs) b->release();
@@ -1519,6 +1529,28 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
                 code[at] = inter[p];
             }
         }
+        // bucket slots of the quarter families (layout: FilterWave)
+        size_t slot_total = 0;
+        for (int f = 0; f < SCT_NFAM; f++) slot_total += (size_t)sct_family_nkeys(f) + 1;
+        std::vector<uint64_t> slot(slot_total, 0ull);
+        for (int f = 0; f < SCT_NFAM; f++) {
+            const SctFamilyRT fam = sct_family_rt(f, bl);
+            const uint32_t *o = off.data() + ft.off_base[f];
+            uint64_t *sl = slot.data() + ft.off_base[f];
+            for (uint32_t k = 0; k < sct_family_nkeys(f); k++) {
+                const uint32_t cnt = o[k + 1] - o[k];
+                uint64_t v;
+                if (cnt <= 3) {
+                    v = cnt;
+                    for (uint32_t j = 0; j < cnt; j++) v |= (uint64_t)(sct_rest_of(fam, code[o[k] + j]) & 0xFFFFu) << (16 * (j + 1));
+                } else {
+                    v = 0x8000ull | (cnt & 0x7FFFu) | ((uint64_t)o[k] << 16) | ((uint64_t)(cnt >> 15) << 48);
+                }
+                sl[k] = v;
+            }
+        }
+        if (c->tab_slot.ensure(slot.size() * sizeof(uint64_t))) return SCT_E_HIP;
+        HIPCHK(hipMemcpyAsync(c->tab_slot.p, slot.data(), slot.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         if (c->tab_off.ensure(off.size() * sizeof(uint32_t) + 16)) return SCT_E_HIP;
         if (c->tab_ent.ensure(ent.size() * sizeof(uint32_t))) return SCT_E_HIP;
         if (c->tab_code.ensure(code.size() * sizeof(uint32_t))) return SCT_E_HIP;
@@ -1620,7 +1652,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         c->slots.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_scan.as<int32_t>(), counters
 #define WAVE_ARGS                                                                                                     \
     c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), n, (const int32_t *)nullptr,                   \
-        c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->ft, c->min_e.as<uint8_t>(), \
+        c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->tab_slot.as<uint2>(), c->ft, c->min_e.as<uint8_t>(), \
         c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_retry.as<int32_t>(),       \
         counters + 2, reinterpret_cast<unsigned long long *>(counters + 4), 0ull, bl
 #define LAUNCH_WAVE(E, TH)                                                                                            \
@@ -1662,7 +1694,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         const unsigned g = blocks_for(nr, 64);  // 4 waves x 16 rows per block
 #define RETRY_ARGS                                                                                                    \
     c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), nr, c->list_retry.as<int32_t>(),               \
-        c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->ft, c->min_e.as<uint8_t>(), \
+        c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->tab_slot.as<uint2>(), c->ft, c->min_e.as<uint8_t>(), \
         c->cnt.as<uint32_t>(), c->slots_retry.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_scan.as<int32_t>(),  \
         counters + 0, reinterpret_cast<unsigned long long *>(counters + 6), SLOT_TAG_RETRY, bl
 #define LAUNCH_RETRY(E, TH)                                                                                           \
