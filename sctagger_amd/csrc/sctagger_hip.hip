@@ -301,10 +301,7 @@ k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ h
 // All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
 // needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
 // ------------------------------------------------------------------------------------------------------------
-#ifndef SCT_PUSH_PER_PASS
-#define SCT_PUSH_PER_PASS 1  // entries a lane appends per pass (1 or 3; measured equal, 1 needs half the queue)
-#endif
-static constexpr int QCAP = SCT_PUSH_PER_PASS == 3 ? 256 : 128;  // >= 63 left over + 64 x entries pushed per pass
+static constexpr int QCAP = 256;  // >= 63 left over + 64 lanes x 3 inline entries pushed in one pass
 #ifndef SCT_HMAX
 #define SCT_HMAX 8  // with the tiers a settled segment stops early, so few rows collect more than 8 verified matches
 #endif
@@ -325,8 +322,8 @@ struct FilterWaveLds {
     W em[4][64];         // em[c][lane]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
     W va[64];            // bits 0..len
     W lo[64], hi[64];    // the segments' bit-planes (lookup lanes read the planes of the segment they work for)
-    uint32_t slen[64];   // and lengths
-    uint32_t alist[64];  // lanes whose segment still generates candidates, compacted
+    uint8_t slen[64];    // and lengths
+    uint8_t alist[64];   // lanes whose segment still generates candidates, compacted
     uint16_t ptab[sizeof(W) == 4 ? 128 : 320];  // this family's placements for the longest segment: t | t2 << 8
     uint32_t best[64];   // smallest distance verified so far for the lane's segment
     uint32_t hcnt[64];
@@ -410,47 +407,87 @@ struct FilterWave {
         if (active && L.best[lane] <= tier) active = false;
     }
 
-    // Append the bucket of every lane to the queue, one entry per lane and pass (position = tail + rank of the lane
-    // among those that still have one); 64-entry batches are verified as they form.  (a, b) are the two words the
-    // lookup loaded: a bucket slot (SL) or the bucket's first and end entry index.
+    // Append the bucket of every lane to the queue; 64-entry batches are verified as they form.  (a, b) are the two
+    // words the lookup loaded.
+    //   SL:  a bucket slot.  All inline entries of the wave (<= 3 per lane) are placed in ONE pass: the two bits of
+    //        the lane's count are balloted separately, so the lane's first queue position is
+    //        tail + #(bit 0 below) + 2 #(bit 1 below).  Long buckets (rare while the barcode set is small) follow one
+    //        at a time, spread over the lanes: lane i queues entry first + i.
+    //   !SL: the bucket's first and end entry index; one entry per lane and pass.
     template <typename Fam>
     __device__ __forceinline__ void push_range(const Fam &fam, uint32_t a, uint32_t b, uint32_t meta) {
-        uint32_t c, A, B = 0, sh = 0, inc = 1, jinc = 0;
         if constexpr (SL) {
             const bool inl = (a & 0x8000u) == 0u;
-            A = __builtin_amdgcn_alignbit(b, a, 16);  // slot bits 16..47: two rests, or the first entry index
-            B = inl ? b >> 16 : 0u;                   // slot bits 48..63: the third rest
-            c = inl ? (a & 0xFFFFu) : ((a & 0x7FFFu) | ((b >> 16) << 15));
-            sh = inl ? 16u : 0u;
-            inc = inl ? 0u : 1u;
-            jinc = inl ? (1u << 24) : 0u;
-            if (inl) meta |= QM_INLINE;
-        } else {
-            A = a;
-            c = b - a;
-        }
-        for (;;) {
-            const bool has = c > 0;
-            const uint64_t m = __ballot(has);
-            if (m == 0) break;
-            if (has) {
-                const uint32_t idx = (tail + lane_rank(m)) & (QCAP - 1);
-                L.qk[idx] = A;
-                L.qm[idx] = meta;
-                if constexpr (SL) {
-                    A = __builtin_amdgcn_alignbit(B, A, sh) + inc;  // next rest moves down / next entry index
-                    B >>= sh;
-                    meta += jinc;
-                } else {
-                    A++;
+            const uint32_t c = inl ? (a & 3u) : 0u;
+            const uint64_t m0 = __ballot((c & 1u) != 0u), m1 = __ballot((c & 2u) != 0u);
+            const uint32_t A = __builtin_amdgcn_alignbit(b, a, 16);  // slot bits 16..47: two rests / first entry index
+            const uint32_t B = b >> 16;                              // slot bits 48..63: the third rest / length >> 15
+            if ((m0 | m1) != 0) {
+                const uint32_t pos = tail + lane_rank(m0) + 2u * lane_rank(m1);
+                const uint32_t mi = meta | QM_INLINE;
+                if (c >= 1u) {
+                    const uint32_t idx = pos & (QCAP - 1);
+                    L.qk[idx] = A;
+                    L.qm[idx] = mi;
                 }
-                c--;
+                if (c >= 2u) {
+                    const uint32_t idx = (pos + 1u) & (QCAP - 1);
+                    L.qk[idx] = __builtin_amdgcn_alignbit(B, A, 16);
+                    L.qm[idx] = mi + (1u << 24);
+                }
+                if (c >= 3u) {
+                    const uint32_t idx = (pos + 2u) & (QCAP - 1);
+                    L.qk[idx] = B;
+                    L.qm[idx] = mi + (2u << 24);
+                }
+                tail += (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1);
+                __builtin_amdgcn_wave_barrier();
+                while (tail - head >= 64) {
+                    verify(fam, true);
+                    head += 64;
+                }
             }
-            tail += (uint32_t)__popcll(m);
-            __builtin_amdgcn_wave_barrier();
-            if (tail - head >= 64) {
-                verify(fam, true);
-                head += 64;
+            uint64_t om = __ballot(!inl);
+            while (om != 0) {
+                const int src = __builtin_ctzll(om);
+                om &= om - 1;
+                const uint32_t first = __builtin_amdgcn_readlane(A, src);
+                const uint32_t n = (__builtin_amdgcn_readlane(a, src) & 0x7FFFu) | (__builtin_amdgcn_readlane(B, src) << 15);
+                const uint32_t mt = __builtin_amdgcn_readlane(meta, src);
+                for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+                    const uint32_t take = n - k0 < 64u ? n - k0 : 64u;
+                    if ((uint32_t)lane < take) {
+                        const uint32_t idx = (tail + (uint32_t)lane) & (QCAP - 1);
+                        L.qk[idx] = first + k0 + (uint32_t)lane;
+                        L.qm[idx] = mt;
+                    }
+                    tail += take;
+                    __builtin_amdgcn_wave_barrier();
+                    while (tail - head >= 64) {
+                        verify(fam, true);
+                        head += 64;
+                    }
+                }
+            }
+        } else {
+            uint32_t c = b - a;
+            for (;;) {
+                const bool has = c > 0;
+                const uint64_t m = __ballot(has);
+                if (m == 0) break;
+                if (has) {
+                    const uint32_t idx = (tail + lane_rank(m)) & (QCAP - 1);
+                    L.qk[idx] = a;
+                    L.qm[idx] = meta;
+                    a++;
+                    c--;
+                }
+                tail += (uint32_t)__popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (tail - head >= 64) {
+                    verify(fam, true);
+                    head += 64;
+                }
             }
         }
     }
@@ -466,7 +503,7 @@ struct FilterWave {
         const uint64_t am = __ballot(active);
         if (am == 0) return;
         const int A = (int)__popcll(am);
-        if (active) L.alist[lane_rank(am)] = (uint32_t)lane;
+        if (active) L.alist[lane_rank(am)] = (uint8_t)lane;
         // placement table
         int P = 0;
 #pragma unroll
@@ -593,7 +630,7 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.va[lane] = va;
     L.lo[lane] = lo;
     L.hi[lane] = hi;
-    L.slen[lane] = (uint32_t)len;
+    L.slen[lane] = (uint8_t)len;
     L.best[lane] = E + 1;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
