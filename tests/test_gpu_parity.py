@@ -166,6 +166,47 @@ def test_moderate_ties_are_retried_not_scanned(m):
     assert st["retried"] >= 1 and st["exhaustive"] == 0
 
 
+def _shared_prefix_barcodes(groups, rng):
+    """Barcodes that share their first 8 characters in groups of the given sizes (the H1 seed buckets of the filter)."""
+    out = []
+    for size in groups:
+        pre = rng.integers(0, 4, size=8)
+        for _ in range(size):
+            out.append(np.concatenate([pre, rng.integers(0, 4, size=8)]))
+    return np.frombuffer(b"ACGT", np.uint8)[np.array(out)]
+
+
+@pytest.mark.parametrize("e", [0, 1, 2])
+def test_bucket_slot_shapes(m, e):
+    """Seed buckets of 1..6 entries (3 inline entries per slot, longer buckets by index), with exact duplicates whose
+    inline entries differ only in their position inside the bucket."""
+    rng = np.random.default_rng(70 + e)
+    bc = _shared_prefix_barcodes([1 + i % 6 for i in range(400)], rng)
+    bc = np.concatenate([bc, bc[5:8], bc[5:6], bc[100:104]])      # duplicates are distinct bids (SURVEY 8(a)-Q4)
+    segs, offs = synth.make_segments(4000, bc, seed=71 + e, frac_background=0.05)
+    want = trie_oracle.match(bc, segs, offs, e, threads=1, workers=8)
+    a, b = run_both(m, bc, segs, offs, e)
+    util.assert_same(a, want, "filter path")
+    util.assert_same(b, want, "exhaustive path")
+
+
+@pytest.mark.parametrize("e", [0, 1])
+def test_bucket_longer_than_the_slot_length_field(m, e):
+    """40 000 barcodes under ONE 8-character prefix: the bucket length no longer fits the 15 low bits of the slot."""
+    rng = np.random.default_rng(80 + e)
+    rests = rng.choice(65536, size=40000, replace=False)
+    rest = np.stack([(rests >> (2 * j)) & 3 for j in range(8)], axis=1)
+    pre = np.broadcast_to(rng.integers(0, 4, size=8), (40000, 8))
+    bc = np.frombuffer(b"ACGT", np.uint8)[np.concatenate([pre, rest], axis=1)]
+    bc = np.concatenate([bc, synth.make_barcodes(500, seed=81)])
+    segs, offs = synth.make_segments(600, bc, seed=82 + e)
+    want = trie_oracle.match(bc, segs, offs, e, threads=1, workers=8)
+    m.set_barcodes(bc)
+    a = m.match(segs, offs, e, 1)
+    util.assert_same(a, want, "filter path")
+    assert m.last_stats()["filter"] > 0
+
+
 def test_empty_and_degenerate_inputs(m):
     bc = synth.make_barcodes(50, seed=7)
     m.set_barcodes(bc)
