@@ -319,7 +319,7 @@ struct FamTables {
 template <typename W, int HM>
 struct FilterWaveLds {
     static constexpr int HMAX = HM;
-    W em[4][64];         // em[c][lane]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
+    alignas(32) W em[64][4];  // em[lane][c]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
     W va[64];            // bits 0..len
     W lo[64], hi[64];    // the segments' bit-planes (lookup lanes read the planes of the segment they work for)
     uint8_t slen[64];    // and lengths
@@ -342,8 +342,12 @@ struct __attribute__((packed, aligned(4))) OffPair {
 
 template <typename W>
 struct EmLds {
-    const W *base;  // &em[0][segment lane]
-    __device__ __forceinline__ W operator()(uint32_t c) const { return base[c * 64]; }
+    uint32_t base;  // LDS byte address of em[segment lane][0]; aligned to 4 sizeof(W), so the mask's offset is OR-ed in
+    __device__ __forceinline__ explicit EmLds(const W *p)
+        : base((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) W *)p) {}
+    __device__ __forceinline__ W operator()(uint32_t c) const {
+        return *(const __attribute__((address_space(3))) W *)(uintptr_t)(base | (c * (uint32_t)sizeof(W)));
+    }
 };
 
 // Bucket slots (SL = true, the quarter families): one 8-byte word per key that answers most lookups by itself.
@@ -386,7 +390,7 @@ struct FilterWave {
             asm volatile("" ::"v"(rest), "v"(t), "v"(t2));
             const int d = E + 1;
 #else
-            const int d = wm_anchored_rest<E, W>(fam, EmLds<W>{&L.em[0][src]}, L.va[src], rest, t, t2);
+            const int d = wm_anchored_rest<E, W>(fam, EmLds<W>(&L.em[src][0]), L.va[src], rest, t, t2);
 #endif
             if (d <= E) {
                 if (inl)
@@ -623,10 +627,10 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     }
     const W va = sct_valid_mask<W>(len);
     const W ve = va & ~(W)1, l1 = lo << 1, h1 = hi << 1;
-    L.em[0][lane] = ~l1 & ~h1 & ve;
-    L.em[1][lane] = l1 & ~h1 & ve;
-    L.em[2][lane] = ~l1 & h1 & ve;
-    L.em[3][lane] = l1 & h1 & ve;
+    L.em[lane][0] = ~l1 & ~h1 & ve;
+    L.em[lane][1] = l1 & ~h1 & ve;
+    L.em[lane][2] = ~l1 & h1 & ve;
+    L.em[lane][3] = l1 & h1 & ve;
     L.va[lane] = va;
     L.lo[lane] = lo;
     L.hi[lane] = hi;
