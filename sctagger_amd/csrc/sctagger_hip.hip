@@ -308,7 +308,8 @@ static constexpr int QCAP = 256;  // >= 63 left over + 64 lanes x 3 inline entri
 static constexpr int HMAX = SCT_HMAX;  // main launch
 static constexpr int K_RETRY = 32, H_RETRY = 64;  // retry launch
 static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
-static constexpr uint32_t PID_MASK = (1u << 30) - 1u;  // pattern id in a hit-list entry (2 bits of distance above it)
+static constexpr uint32_t LOC_MASK = (1u << 30) - 1u;    // locator in a hit-list entry (2 bits of distance above it)
+static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline slot entry (entry indices stay below it)
 
 // where each family's offsets start inside the concatenated offset table; the offsets themselves index the
 // concatenated entry tables (family f's entries start at f * np)
@@ -385,7 +386,11 @@ struct FilterWave {
             const int t = (int)((meta >> 8) & 63u), t2 = (int)((meta >> 16) & 63u);
             const bool inl = SL && (meta & QM_INLINE) != 0u;
             uint32_t rest = gk;  // an inline entry carries its rest characters (bits above them are ignored)
+#ifdef SCT_ABLATE_MISS  // timing-only build: no table is read after the slot (results are wrong)
+            if (!inl) rest = gk * 2654435761u;
+#else
             if (!inl) rest = sct_rest_of(fam, tab_code[gk]);
+#endif
 #ifdef SCT_ABLATE_VERIFY  // timing-only build: candidates are fetched but never run through the automaton
             asm volatile("" ::"v"(rest), "v"(t), "v"(t2));
             const int d = E + 1;
@@ -393,15 +398,23 @@ struct FilterWave {
             const int d = wm_anchored_rest<E, W>(fam, EmLds<W>(&L.em[src][0]), L.va[src], rest, t, t2);
 #endif
             if (d <= E) {
+                // what is kept is the entry's LOCATOR; the pattern ids are read once, when the segment is finished
+                // (resolve), so that no table read sits between two batches
                 if (inl)
-                    gk = tab_off[ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.lo[src], L.hi[src], t, t2)] + ((meta >> 24) & 3u);
-                const uint32_t pid = tab_ent[gk];
+                    gk = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.lo[src], L.hi[src], t, t2)) << 2) |
+                         ((meta >> 24) & 3u);
                 atomicMin(&L.best[src], (uint32_t)d);
                 const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
-                if (k < HMAX) L.hlist[k][src] = ((uint32_t)d << 30) | pid;
+                if (k < HMAX) L.hlist[k][src] = ((uint32_t)d << 30) | gk;
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+
+    // pattern id of a verified entry: locator = entry index, or LOC_INLINE | (index into tab_off) << 2 | j
+    __device__ __forceinline__ uint32_t resolve(uint32_t loc) const {
+        if (SL && (loc & LOC_INLINE)) loc = tab_off[(loc & (LOC_INLINE - 1u)) >> 2] + (loc & 3u);
+        return tab_ent[loc];
     }
 
     // Tiering: the families are ordered so that after H1 every barcode at distance 0 has been verified, and after
@@ -609,11 +622,12 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     int64_t r = gid;
     int len = 0;
     if (active) {
+        // per-row data is read once: non-temporal, so that it does not push the seed tables out of the L2
         if (rows) r = rows[gid];                       // a retried row: listed explicitly
-        else active = cnt[r] != CNT_DEFER;             // routed to a scan path by k_pack
+        else active = __builtin_nontemporal_load(&cnt[r]) != CNT_DEFER;  // routed to a scan path by k_pack
     }
     if (active) {
-        len = (int)(meta_in[r] & 0xFF);
+        len = (int)(__builtin_nontemporal_load(&meta_in[r]) & 0xFF);
         active = len >= bl - E;  // shorter rows were finished by k_pack
     }
     if (!active) len = 0;
@@ -622,8 +636,8 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     if ((maxlen <= 31) != (sizeof(W) == 4)) return;  // the other instantiation's wave
     W lo = 0, hi = 0;
     if (active) {
-        lo = (W)lo_in[r];
-        hi = (W)hi_in[r];
+        lo = (W)__builtin_nontemporal_load(&lo_in[r]);
+        hi = (W)__builtin_nontemporal_load(&hi_in[r]);
     }
     const W va = sct_valid_mask<W>(len);
     const W ve = va & ~(W)1, l1 = lo << 1, h1 = hi << 1;
@@ -672,7 +686,7 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     const uint32_t lim = nc < (uint32_t)HM ? nc : (uint32_t)HM;
     for (uint32_t k = 0; k < lim; k++) {
         const uint32_t v = L.hlist[k][lane];
-        res.add((int)(v >> 30), v & PID_MASK);
+        res.add((int)(v >> 30), W_.resolve(v & LOC_MASK));
     }
     res.store(active, r, nc > (uint32_t)HM, min_e, cnt, slots, slot_off, list_defer, defer_count, slot_cursor, slot_tag);
 }
@@ -1658,7 +1672,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     const int64_t n = c->n_seg;
     const int np = c->np, bl = c->bl;
     const int prefix_len = sct_prefix_len(threads);
-    const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && np <= (int)PID_MASK;
+    const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && (uint64_t)SCT_NFAM_ALL * (uint64_t)np < LOC_INLINE;
     const bool use_thirds = filter_ok && c->have_thirds && max_err <= 1 && c->filter_mode != 1 && !c->no_thirds;
     const bool rt_families = bl != 16;  // quarter families with run-time piece boundaries
     const size_t n1 = (size_t)(n ? n : 1);
