@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Non-packed 32-bit integer VALU ops issue one wave64 instruction per 4 cycles per SIMD (SQ_ACTIVE_INST_VALU counts
 # one quad-cycle per instruction; SURVEY.md §7: 256 CU x 64 lanes x 2.4 GHz = 3.9e13 lane-ops/s):
 VALU_PEAK_WINST_S = 256 * 4 * 2.4e9 / 4
+L2_PEAK_REQ_S = 8 * 16 * 2.4e9   # L2: 16 channels per XCD, one 128-byte request per channel and clock (MI355X_MICROARCH.md: 34.5 TB/s)
 
 
 def baseline_metric():
@@ -180,7 +181,17 @@ def main():
             # (calibrated for 16-byte-per-lane streams) does not apply to it
             rd = q.get("hbm_read_bytes_raw") or 0
             roof["traffic"] = int(rd + (q.get("hbm_write_bytes") or 0))
-            roof["traffic_source"] = q["source"] + "; FETCH_SIZE + WRITE_SIZE as read (FETCH_SIZE matches the kernel's 24 B/segment input)"
+            roof["traffic_source"] = q["source"] + (
+                "; FETCH_SIZE + WRITE_SIZE as read.  Reads = 24 B/segment of packed input streamed once + the L2 misses of "
+                "the pattern-id resolution (offset/entry tables, ~7 MB of tables against a 4 MB L2; FETCH_SIZE counts "
+                "Infinity-Cache hits too); writes = the result arrays")
+            if q.get("l2_requests_per_launch"):
+                # the seed lookups are random 8-byte reads: one 128-byte L2 request each, whatever the bytes used
+                r = q["l2_requests_per_launch"] / (avg[dominant] * 1e-3)
+                roof["l2"] = {"requests_per_segment": round(q["l2_requests_per_launch"] / q["segments_per_launch"], 1),
+                              "achieved_requests_per_s": r, "peak_requests_per_s": L2_PEAK_REQ_S,
+                              "frac": round(r / L2_PEAK_REQ_S, 3), "hit_rate": q.get("l2_hit_rate"),
+                              "note": "peak = 16 channels x 8 XCDs x 1 request/clk at 2.4 GHz (34.5 TB/s / 128 B lines)"}
             if q.get("valu_insts_per_launch"):
                 w = q["valu_insts_per_launch"] / (avg[dominant] * 1e-3)
                 roof["valu"] = {"insts_per_segment": round(q["valu_insts_per_launch"] / q["segments_per_launch"], 1),

@@ -53,6 +53,7 @@ def main():
                  "kernel": dom[0], "workload": b["config"]["workload"], "segments_per_launch": b["config"]["segments_per_gpu"],
                  "hbm_read_bytes_raw": d.get("hbm_read_bytes_raw"), "hbm_read_bytes_x2_gfx950": d.get("hbm_read_bytes_x2_gfx950"),
                  "hbm_write_bytes": d.get("hbm_write_bytes"), "l2_hit_rate": d.get("l2_hit_rate"),
+                 "l2_requests_per_launch": (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) or None,
                  "kernel_ms_at_profile": b.get("kernels_ms", {}).get("k_filter"),
                  "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
                  "lds_insts_per_launch": c.get("SQ_INSTS_LDS"), "vmem_rd_insts_per_launch": c.get("SQ_INSTS_VMEM_RD")}
