@@ -1,0 +1,559 @@
+// k_filter.hip.h — the seed filter: LaneResult, k_filter_lane (A/B), k_filter (wave-cooperative, bucket slots).
+// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, pack, filter, scan,
+// offsets, whitelist, adapter, validate).  gfx950 only.
+#pragma once
+// ------------------------------------------------------------------------------------------------------------
+// Per-lane result of the filter kernels: running minimum distance and up to K_SLOTS distinct pattern ids at
+// that minimum, in registers (static indexing only).  More than K_SLOTS ties defer the segment to the scan path.
+// ------------------------------------------------------------------------------------------------------------
+template <int E, int KS = K_SLOTS>
+struct LaneResult {
+    static constexpr int K_SLOTS = KS;  // shadows the global default inside this struct
+    int best = E + 1;
+    int nh = 0;
+    uint32_t h[KS];
+
+    __device__ __forceinline__ void init() {
+        best = E + 1;
+        nh = 0;
+#pragma unroll
+        for (int i = 0; i < K_SLOTS; i++) h[i] = 0;
+    }
+    __device__ __forceinline__ void add(int d, uint32_t pid) {
+        if (d > E) return;
+        if (d < best) {
+            best = d;
+            nh = 0;
+        }
+        if (d != best) return;
+        bool dup = false;
+#pragma unroll
+        for (int i = 0; i < K_SLOTS; i++) dup |= (i < nh) && (h[i] == pid);
+        if (dup) return;
+#pragma unroll
+        for (int i = 0; i < K_SLOTS; i++)
+            if (i == nh) h[i] = pid;
+        nh++;  // may run past K_SLOTS: that is the defer signal
+    }
+    // Wave-cooperative store (every lane of the wave must call it; `row` says whether the lane owns a row).
+    // The hit lists of the wave are written back to back into the dense `slots` array: one wave-wide prefix sum
+    // of the list lengths and one 64-bit atomic per wave reserve the space, slot_off[r] remembers where row r's
+    // list starts.  Rows with too many ties are pushed to the scan list instead.
+    __device__ __forceinline__ void store(bool row, int64_t r, bool overflow, uint8_t *__restrict__ min_e,
+                                          uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
+                                          uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer,
+                                          uint32_t *__restrict__ defer_count, unsigned long long *__restrict__ slot_cursor,
+                                          uint64_t slot_tag) {
+        const int lane = threadIdx.x & 63;
+        const bool defer = row && (overflow || nh > K_SLOTS);
+        const uint32_t mine = (row && !defer) ? (uint32_t)nh : 0u;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        const uint32_t total = __shfl(inc, 63, 64);
+        unsigned long long base = 0;
+        if (lane == 0 && total) base = atomicAdd(slot_cursor, (unsigned long long)total);
+        base = __shfl(base, 0, 64);
+        if (!row) return;
+        if (defer) {
+            const uint32_t k = atomicAdd(defer_count, 1u);
+            list_defer[k] = (int32_t)r;
+            cnt[r] = CNT_DEFER;
+            return;
+        }
+        cnt[r] = mine;
+        if (mine == 0) {
+            min_e[r] = SCT_NO_HIT;
+            return;
+        }
+        if (nh > 1) {  // sort ascending: odd-even transposition network on registers
+#pragma unroll
+            for (int i = 0; i < K_SLOTS; i++)
+                if (i >= nh) h[i] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int round = 0; round < K_SLOTS; round++) {
+#pragma unroll
+                for (int i = round & 1; i + 1 < K_SLOTS; i += 2) {
+                    const uint32_t a = h[i], b = h[i + 1];
+                    h[i] = a < b ? a : b;
+                    h[i + 1] = a < b ? b : a;
+                }
+            }
+        }
+        min_e[r] = (uint8_t)best;
+        const uint64_t start = base + inc - mine;
+        slot_off[r] = start | slot_tag;
+#pragma unroll
+        for (int i = 0; i < K_SLOTS; i++)
+            if (i < nh) slots[start + i] = h[i];
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// k_filter_lane<E> (first version, kept for A/B: option "filter_mode" = 1): one lane per segment, each lane walks
+// its own buckets and verifies its own candidates; lanes idle while the longest bucket of the wave is walked.
+// ------------------------------------------------------------------------------------------------------------
+template <int E>
+struct FilterLane {
+    const uint32_t *__restrict__ tab_off;
+    const uint32_t *__restrict__ tab_ent;
+    const uint2 *__restrict__ pat;
+    int np;
+    uint32_t tls, ths, ve, va;
+    LaneResult<E> res;
+
+    __device__ __forceinline__ void operator()(int f, uint32_t key) {
+        const uint32_t *off = tab_off + (size_t)f * (SCT_KEYS + 1) + key;
+        const uint32_t s = off[0], e = off[1];
+        for (uint32_t k = s; k < e; k++) {  // offsets index the concatenated entry table
+            const uint32_t pid = tab_ent[k];
+            const uint2 p = pat[pid];
+            res.add(wm_verify<E>(tls, ths, ve, va, p.x, p.y, 16), pid);
+        }
+    }
+};
+
+template <int E>
+__global__ void __launch_bounds__(256)
+k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
+              int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
+              const uint2 *__restrict__ pat, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
+              uint32_t *__restrict__ slots, uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_scan,
+              uint32_t *__restrict__ counters) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = r < n;
+    if (active) active = cnt[r] != CNT_DEFER;  // routed to a scan path by k_pack
+    int len = 0;
+    if (active) {
+        len = (int)(meta_in[r] & 0xFF);
+        active = len >= 16 - E;  // shorter rows were finished by k_pack
+    }
+    FilterLane<E> L;
+    L.res.init();
+    if (active) {
+        const uint32_t lo = (uint32_t)lo_in[r], hi = (uint32_t)hi_in[r];
+        L.tab_off = tab_off;
+        L.tab_ent = tab_ent;
+        L.pat = pat;
+        L.np = np;
+        L.tls = lo << 1;
+        L.ths = hi << 1;
+        L.va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
+        L.ve = L.va & ~1u;
+        sct_for_each_seed<E, uint32_t>(lo, hi, len, L);
+    }
+    L.res.store(active, r, false, min_e, cnt, slots, slot_off, list_scan, counters + 0,
+                reinterpret_cast<unsigned long long *>(counters + 4), 0ull);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_filter<E> (default): one WAVE per 64 segments, cooperating through LDS so that verification always runs on
+// full waves.  The seed families are processed one after the other; within a family
+//   lookup   every lane computes the seed key of its own segment for the current placement (t, t2) — the
+//            placements are walked wave-uniformly up to the longest segment of the wave — and reads its bucket
+//            range; the loads are issued one placement ahead of the queue work that consumes them;
+//   push     round by round, every lane that still has a candidate appends (table entry, lane, t, t2) to the
+//            wave's queue in LDS (position = tail + mbcnt(ballot));
+//   drain    whenever 64 candidates are queued, lane i takes entry head+i: reads the barcode's 2-bit codes from
+//            the table (L2), runs the ANCHORED Wu-Manber automaton of this family (8 of the 16 barcode
+//            characters, sct_core.h) against the owning segment's match masks in LDS, and on d <= E appends
+//            (d, pattern id) to that segment's list in LDS (LDS atomic counter);
+//   finish   (after the last family) every lane folds its own list into (minimum, distinct pattern ids), sorts
+//            and stores.
+// A segment with more than HMAX verified matches (duplicates included) or more than K_SLOTS ties is deferred.
+// All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
+// needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
+// ------------------------------------------------------------------------------------------------------------
+static constexpr int QCAP = 256;  // >= 63 left over + 64 lanes x 3 inline entries pushed in one pass
+#ifndef SCT_HMAX
+#define SCT_HMAX 8  // with the tiers a settled segment stops early, so few rows collect more than 8 verified matches
+#endif
+static constexpr int HMAX = SCT_HMAX;  // main launch
+static constexpr int K_RETRY = 32, H_RETRY = 64;  // retry launch
+static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
+static constexpr uint32_t LOC_MASK = (1u << 30) - 1u;    // locator in a hit-list entry (2 bits of distance above it)
+static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline slot entry (entry indices stay below it)
+
+// where each family's offsets start inside the concatenated offset table; the offsets themselves index the
+// concatenated entry tables (family f's entries start at f * np)
+struct FamTables {
+    uint32_t off_base[SCT_NFAM_ALL];
+};
+
+template <typename W, int HM>
+struct FilterWaveLds {
+    static constexpr int HMAX = HM;
+    alignas(32) W em[64][4];  // em[lane][c]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
+    W va[64];            // bits 0..len
+    W lo[64], hi[64];    // the segments' bit-planes (lookup lanes read the planes of the segment they work for)
+    uint8_t slen[64];    // and lengths
+    uint8_t alist[64];   // lanes whose segment still generates candidates, compacted
+    uint16_t ptab[sizeof(W) == 4 ? 128 : 320];  // this family's placements for the longest segment: t | t2 << 8
+    uint32_t best[64];   // smallest distance verified so far for the lane's segment
+    uint32_t hcnt[64];
+    uint32_t hlist[HM][64];
+    uint32_t qk[QCAP];   // queue: global table entry index f*np + k
+    uint32_t qm[QCAP];   //        lane | t << 8 | t2 << 16
+};
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t m) {  // number of set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+struct __attribute__((packed, aligned(4))) OffPair {
+    uint32_t a, b;
+};
+
+template <typename W>
+struct EmLds {
+    uint32_t base;  // LDS byte address of em[segment lane][0]; aligned to 4 sizeof(W), so the mask's offset is OR-ed in
+    __device__ __forceinline__ explicit EmLds(const W *p)
+        : base((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) W *)p) {}
+    __device__ __forceinline__ W operator()(uint32_t c) const {
+        return *(const __attribute__((address_space(3))) W *)(uintptr_t)(base | (c * (uint32_t)sizeof(W)));
+    }
+};
+
+// Bucket slots (SL = true, the quarter families): one 8-byte word per key that answers most lookups by itself.
+//   bit 15 clear: bits 0..1 = n <= 3 entries in the bucket, bits 16j+16 .. 16j+31 = the REST characters of entry j
+//                 (sct_rest_of: all the verification needs besides the key); no other table is read unless the
+//                 entry verifies, and then its pattern id is tab_ent[off[key] + j]
+//   bit 15 set:   a longer bucket: bits 16..47 = its first entry index, bits 0..14 | bits 48..63 << 15 = its length;
+//                 the entries are queued by index and verified from tab_code as without slots
+// A queued entry is (qk, qm): qm = lane | t << 8 | t2 << 16 | j << 24 | inline << 31; qk = rest characters (inline)
+// or entry index.
+static constexpr uint32_t QM_INLINE = 0x80000000u;
+
+template <int E, typename W, int HM, bool SL>
+struct FilterWave {
+    static constexpr int HMAX = HM;
+    FilterWaveLds<W, HM> &L;
+    const uint32_t *__restrict__ tab_off;
+    const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
+    const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
+    const uint2 *__restrict__ tab_slot;     // bucket slots, indexed like tab_off
+    FamTables ft;
+    int lane;
+    bool active;
+    int len;
+    W lo, hi;
+    uint32_t head = 0, tail = 0;  // wave-uniform
+
+    template <typename Fam>
+    __device__ __forceinline__ void verify(const Fam &fam, bool take) {
+        if (take) {
+            const uint32_t idx = (head + lane) & (QCAP - 1);
+            uint32_t gk = L.qk[idx];
+            const uint32_t meta = L.qm[idx];
+            const uint32_t src = meta & 63u;
+            const int t = (int)((meta >> 8) & 63u), t2 = (int)((meta >> 16) & 63u);
+            const bool inl = SL && (meta & QM_INLINE) != 0u;
+            uint32_t rest = gk;  // an inline entry carries its rest characters (bits above them are ignored)
+#ifdef SCT_ABLATE_MISS  // timing-only build: no table is read after the slot (results are wrong)
+            if (!inl) rest = gk * 2654435761u;
+#else
+            if (!inl) rest = sct_rest_of(fam, tab_code[gk]);
+#endif
+#ifdef SCT_ABLATE_VERIFY  // timing-only build: candidates are fetched but never run through the automaton
+            asm volatile("" ::"v"(rest), "v"(t), "v"(t2));
+            const int d = E + 1;
+#else
+            const int d = wm_anchored_rest<E, W>(fam, EmLds<W>(&L.em[src][0]), L.va[src], rest, t, t2);
+#endif
+            if (d <= E) {
+                // what is kept is the entry's LOCATOR; the pattern ids are read once, when the segment is finished
+                // (resolve), so that no table read sits between two batches
+                if (inl)
+                    gk = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.lo[src], L.hi[src], t, t2)) << 2) |
+                         ((meta >> 24) & 3u);
+                atomicMin(&L.best[src], (uint32_t)d);
+                const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
+                if (k < HMAX) L.hlist[k][src] = ((uint32_t)d << 30) | gk;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // pattern id of a verified entry: locator = entry index, or LOC_INLINE | (index into tab_off) << 2 | j
+    __device__ __forceinline__ uint32_t resolve(uint32_t loc) const {
+        if (SL && (loc & LOC_INLINE)) loc = tab_off[(loc & (LOC_INLINE - 1u)) >> 2] + (loc & 3u);
+        return tab_ent[loc];
+    }
+
+    // Tiering: the families are ordered so that after H1 every barcode at distance 0 has been verified, and after
+    // H1 + H2 every barcode at distance <= 1 (one half is untouched).  A segment whose minimum is already settled
+    // stops generating candidates for the later families — only the minimum tier is reported.
+    __device__ __forceinline__ void settle(uint32_t tier) {
+        if (active && L.best[lane] <= tier) active = false;
+    }
+
+    // Append the bucket of every lane to the queue; 64-entry batches are verified as they form.  (a, b) are the two
+    // words the lookup loaded.
+    //   SL:  a bucket slot.  All inline entries of the wave (<= 3 per lane) are placed in ONE pass: the two bits of
+    //        the lane's count are balloted separately, so the lane's first queue position is
+    //        tail + #(bit 0 below) + 2 #(bit 1 below).  Long buckets (rare while the barcode set is small) follow one
+    //        at a time, spread over the lanes: lane i queues entry first + i.
+    //   !SL: the bucket's first and end entry index; one entry per lane and pass.
+    template <typename Fam>
+    __device__ __forceinline__ void push_range(const Fam &fam, uint32_t a, uint32_t b, uint32_t meta) {
+        if constexpr (SL) {
+            const bool inl = (a & 0x8000u) == 0u;
+            const uint32_t c = inl ? (a & 3u) : 0u;
+            const uint64_t m0 = __ballot((c & 1u) != 0u), m1 = __ballot((c & 2u) != 0u);
+            const uint32_t A = __builtin_amdgcn_alignbit(b, a, 16);  // slot bits 16..47: two rests / first entry index
+            const uint32_t B = b >> 16;                              // slot bits 48..63: the third rest / length >> 15
+            if ((m0 | m1) != 0) {
+                const uint32_t pos = tail + lane_rank(m0) + 2u * lane_rank(m1);
+                const uint32_t mi = meta | QM_INLINE;
+                if (c >= 1u) {
+                    const uint32_t idx = pos & (QCAP - 1);
+                    L.qk[idx] = A;
+                    L.qm[idx] = mi;
+                }
+                if (c >= 2u) {
+                    const uint32_t idx = (pos + 1u) & (QCAP - 1);
+                    L.qk[idx] = __builtin_amdgcn_alignbit(B, A, 16);
+                    L.qm[idx] = mi + (1u << 24);
+                }
+                if (c >= 3u) {
+                    const uint32_t idx = (pos + 2u) & (QCAP - 1);
+                    L.qk[idx] = B;
+                    L.qm[idx] = mi + (2u << 24);
+                }
+                tail += (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1);
+                __builtin_amdgcn_wave_barrier();
+                while (tail - head >= 64) {
+                    verify(fam, true);
+                    head += 64;
+                }
+            }
+            uint64_t om = __ballot(!inl);
+            while (om != 0) {
+                const int src = __builtin_ctzll(om);
+                om &= om - 1;
+                const uint32_t first = __builtin_amdgcn_readlane(A, src);
+                const uint32_t n = (__builtin_amdgcn_readlane(a, src) & 0x7FFFu) | (__builtin_amdgcn_readlane(B, src) << 15);
+                const uint32_t mt = __builtin_amdgcn_readlane(meta, src);
+                for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+                    const uint32_t take = n - k0 < 64u ? n - k0 : 64u;
+                    if ((uint32_t)lane < take) {
+                        const uint32_t idx = (tail + (uint32_t)lane) & (QCAP - 1);
+                        L.qk[idx] = first + k0 + (uint32_t)lane;
+                        L.qm[idx] = mt;
+                    }
+                    tail += take;
+                    __builtin_amdgcn_wave_barrier();
+                    while (tail - head >= 64) {
+                        verify(fam, true);
+                        head += 64;
+                    }
+                }
+            }
+        } else {
+            uint32_t c = b - a;
+            for (;;) {
+                const bool has = c > 0;
+                const uint64_t m = __ballot(has);
+                if (m == 0) break;
+                if (has) {
+                    const uint32_t idx = (tail + lane_rank(m)) & (QCAP - 1);
+                    L.qk[idx] = a;
+                    L.qm[idx] = meta;
+                    a++;
+                    c--;
+                }
+                tail += (uint32_t)__popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (tail - head >= 64) {
+                    verify(fam, true);
+                    head += 64;
+                }
+            }
+        }
+    }
+
+    // One family.  The lookups are spread over the lanes as (active segment, placement) PAIRS: with A segments of
+    // the wave still generating candidates, G = 64 / A placements are looked up per pass (lane = g * A + a works on
+    // placement p0 + g for the a-th active segment), so the wave-uniform cost of a pass is shared by 64 lookups
+    // even when most segments have settled.  The placements of the family for the longest segment of the wave are
+    // tabulated in LDS once; a lane skips those its own segment is too short for.  The bucket range of a pass is
+    // queued while the loads of the next pass are in flight.
+    template <typename Fam>
+    __device__ __forceinline__ void run_family(const Fam &fam, int maxlen) {
+        const uint64_t am = __ballot(active);
+        if (am == 0) return;
+        const int A = (int)__popcll(am);
+        if (active) L.alist[lane_rank(am)] = (uint8_t)lane;
+        // placement table
+        int P = 0;
+#pragma unroll
+        for (int d = -fam.SLACK; d <= fam.SLACK; d++) {
+            const int c = maxlen - fam.GAP - d - fam.LB + 1;
+            if (c > 0) {
+                for (int t = lane; t < c; t += 64) L.ptab[P + t] = (uint16_t)(t | ((t + fam.GAP + d) << 8));
+                P += c;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (P == 0) return;
+        const int G = 64 / A;
+        const uint32_t inv = 65536u / (uint32_t)A + 1u;           // lane / A for lane < 64 (checked for every A <= 64)
+        const int g = (int)(((uint32_t)lane * inv) >> 16), a = lane - g * A;
+        const bool worker = g < G;
+        uint32_t sl = 0;
+        W slo = 0, shi = 0;
+        int slen = 0;
+        if (worker) {
+            sl = L.alist[a];
+            slo = L.lo[sl];
+            shi = L.hi[sl];
+            slen = (int)L.slen[sl];
+        }
+        const uint32_t *off = tab_off + ft.off_base[fam.INDEX];
+        const uint2 *slot = tab_slot + ft.off_base[fam.INDEX];
+        uint32_t ps = 0, pe = 0, pmeta = 0;  // the pass whose loads were issued last
+        bool pend = false;
+        for (int p0 = 0; p0 < P; p0 += G) {
+            const int p = p0 + g;
+            uint32_t s = 0, e = 0, meta = 0;
+            if (worker && p < P) {
+                const uint32_t tt = L.ptab[p];
+                const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
+                if (sct_valid_of(fam, t2, slen)) {
+                    // one 8-byte load: the bucket's slot, or its start and end (neighbouring words, 4-byte aligned;
+                    // absolute entry indices).  Nothing depends on the load until the bucket is queued, one pass later.
+                    const uint32_t key = sct_key_of<W>(fam, slo, shi, t, t2);
+                    if constexpr (SL) {
+                        const uint2 sv = slot[key];
+                        s = sv.x;
+                        e = sv.y;
+                    } else {
+                        const OffPair op = *reinterpret_cast<const OffPair *>(off + key);
+                        s = op.a;
+                        e = op.b;
+                    }
+                    meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
+#ifdef SCT_ABLATE_PUSH  // timing-only build: the bucket range is loaded but nothing is queued
+                    asm volatile("" ::"v"(s), "v"(e), "v"(meta));
+                    s = e = 0;
+#endif
+                }
+            }
+            if (pend) push_range(fam, ps, pe, pmeta);
+            pend = true;
+            ps = s;
+            pe = e;
+            pmeta = meta;
+        }
+        if (pend) push_range(fam, ps, pe, pmeta);
+        if (tail != head) {  // the family's last, partial batch
+            verify(fam, (uint32_t)lane < tail - head);
+            head = tail;
+        }
+    }
+};
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// W = uint32_t handles the waves whose longest segment has at most 31 characters, W = uint64_t the others
+// (up to 63); both instantiations are launched over all rows and a wave leaves at once if it is not its kind.
+// THIRDS = true (max_err <= 1 only) walks the 20/22-bit families of the thirds scheme instead of the quarters.
+// KS / HM: ties kept per segment / verified matches kept per segment before the row is deferred.  The main launch
+// (KS 8, HM 16) covers all rows; rows it defers are retried by a launch with KS 32, HM 64 over the list `rows`
+// (16 listed rows per wave), and only what that launch defers again goes to the exhaustive scan.
+// RT = true: barcode length `bl` (8..16) other than 16, piece boundaries computed at run time (sct_family_rt).
+template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT>
+__global__ void __launch_bounds__(256)
+k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
+         int64_t n, const int32_t *__restrict__ rows, const uint32_t *__restrict__ tab_off,
+         const uint32_t *__restrict__ tab_ent, const uint32_t *__restrict__ tab_code,
+         const uint2 *__restrict__ tab_slot, FamTables ft, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
+         uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer, uint32_t *__restrict__ defer_count,
+         unsigned long long *__restrict__ slot_cursor, uint64_t slot_tag, int bl_arg) {
+    const int bl = RT ? bl_arg : 16;
+    __shared__ FilterWaveLds<W, HM> lds[4];
+    FilterWaveLds<W, HM> &L = lds[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    // RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows, so that the pair
+    // compaction of run_family spreads each row's lookups over four lanes and the few retried rows finish sooner
+    const int64_t gid = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * RPW + lane;
+    bool active = lane < RPW && gid < n;
+    int64_t r = gid;
+    int len = 0;
+    if (active) {
+        // per-row data is read once: non-temporal, so that it does not push the seed tables out of the L2
+        if (rows) r = rows[gid];                       // a retried row: listed explicitly
+        else active = __builtin_nontemporal_load(&cnt[r]) != CNT_DEFER;  // routed to a scan path by k_pack
+    }
+    if (active) {
+        len = (int)(__builtin_nontemporal_load(&meta_in[r]) & 0xFF);
+        active = len >= bl - E;  // shorter rows were finished by k_pack
+    }
+    if (!active) len = 0;
+    const int maxlen = wave_max_i(len);
+    if (maxlen == 0) return;  // the whole wave has nothing to do
+    if ((maxlen <= 31) != (sizeof(W) == 4)) return;  // the other instantiation's wave
+    W lo = 0, hi = 0;
+    if (active) {
+        lo = (W)__builtin_nontemporal_load(&lo_in[r]);
+        hi = (W)__builtin_nontemporal_load(&hi_in[r]);
+    }
+    const W va = sct_valid_mask<W>(len);
+    const W ve = va & ~(W)1, l1 = lo << 1, h1 = hi << 1;
+    L.em[lane][0] = ~l1 & ~h1 & ve;
+    L.em[lane][1] = l1 & ~h1 & ve;
+    L.em[lane][2] = ~l1 & h1 & ve;
+    L.em[lane][3] = l1 & h1 & ve;
+    L.va[lane] = va;
+    L.lo[lane] = lo;
+    L.hi[lane] = hi;
+    L.slen[lane] = (uint8_t)len;
+    L.best[lane] = E + 1;
+    L.hcnt[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    FilterWave<E, W, HM, !THIRDS> W_{L, tab_off, tab_ent, tab_code, tab_slot, ft, lane, active, len, lo, hi};
+#define RUN_FAMILY(FID)                                                         \
+    do {                                                                        \
+        if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \
+        else W_.run_family(SctFamily<FID>{}, maxlen);                           \
+    } while (0)
+    if (THIRDS) {
+        RUN_FAMILY(SCT_F_T01);
+        if (E >= 1) {
+            W_.settle(0);
+            RUN_FAMILY(SCT_F_T12);
+            RUN_FAMILY(SCT_F_T02);
+        }
+    } else {
+        RUN_FAMILY(SCT_F_H1);
+        if (E >= 1) {
+            W_.settle(0);
+            RUN_FAMILY(SCT_F_H2);
+        }
+        if (E >= 2) {
+            W_.settle(1);
+            RUN_FAMILY(SCT_F_MID);
+            RUN_FAMILY(SCT_F_02);
+            RUN_FAMILY(SCT_F_13);
+            RUN_FAMILY(SCT_F_03);
+        }
+    }
+#undef RUN_FAMILY
+    const uint32_t nc = active ? L.hcnt[lane] : 0u;
+    LaneResult<E, KS> res;
+    res.init();
+    const uint32_t lim = nc < (uint32_t)HM ? nc : (uint32_t)HM;
+    for (uint32_t k = 0; k < lim; k++) {
+        const uint32_t v = L.hlist[k][lane];
+        res.add((int)(v >> 30), W_.resolve(v & LOC_MASK));
+    }
+    res.store(active, r, nc > (uint32_t)HM, min_e, cnt, slots, slot_off, list_defer, defer_count, slot_cursor, slot_tag);
+}
+

@@ -1,4 +1,5 @@
-// sctagger_hip.hip — gfx950 kernels and the C-ABI (include/sctagger_hip.h).
+// sctagger_hip.hip — contexts, seed-table construction, kernel launches and the C-ABI (include/sctagger_hip.h);
+// the gfx950 kernels themselves are in the k_*.hip.h headers included below.
 //
 // match_trie (reference scTagger.py:643-716, observable semantics in SURVEY.md §8(a)-Q): for every long-read
 // segment the minimum infix edit distance (<= max_err) to any barcode on either strand, and the sorted list of
@@ -8,8 +9,9 @@
 // Device data (all in HBM, resident for the life of the context / upload):
 //   patterns   np = 2*n_bc entries, index p = bid*2 + strand (strand 1 = forward, 0 = reverse complement, so
 //              ascending p is the reference's sorted(bids) order), stored as bit-planes uint2{lo, hi}
-//   seed tables (bl == 16): per family an offsets array (65537 entries; 2^20+1 / 2^22+1 for the thirds scheme of
-//              large barcode sets) and np entries as pattern ids and as 2-bit codes, see sct_core.h
+//   seed tables (bl 8..16): per family 8-byte bucket slots and an offsets array (65537 entries; 2^20+1 / 2^22+1
+//              offsets, no slots, for the thirds scheme of large barcode sets) and np entries as pattern ids and as
+//              2-bit codes, see sct_core.h and k_filter.hip.h
 //   segments   the caller's CSR bytes + int64 offsets, plus per segment the packed bit-planes {lo, hi, meta}
 //   results    min_e u8[n], cnt u32[n], slot_off u64[n] + dense slots u32[] (filter path), hit_offs i64[n+1],
 //              hits u32[total]
@@ -59,1271 +61,16 @@ static int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(SCT_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-static constexpr int K_SLOTS = 8;          // hits kept per segment by the filter kernel before it defers
-static constexpr uint32_t CNT_DEFER = 0xFFFFFFFFu;
-static constexpr int THIRDS_MIN_PATTERNS = 1 << 19;  // from here on (8 barcodes per 16-bit bucket) the thirds scheme pays
-static constexpr int META_NONACGT = 1 << 8;
-static constexpr int META_LONG = 1 << 9;   // more than 63 characters: not representable in the filter's planes
-static constexpr int PLANE_MAX = 63;       // characters kept in the packed bit-planes
 
-// ------------------------------------------------------------------------------------------------------------
-// k_pack: one lane per segment. ASCII -> bit-planes of the first 63 characters, flags, and routing.
-//   route 0: filter path; route 1: exhaustive Myers scan; route 2: restricted-start DP scan
-// Segments shorter than bl - max_err cannot match anything (every window the reference inserts is at least
-// that long, scTagger.py:681) and are finished here.
-// ------------------------------------------------------------------------------------------------------------
-__global__ void k_pack(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, int64_t n, int bl,
-                       int max_err, int prefix_len, int filter_maxlen, uint64_t *__restrict__ lo_out,
-                       uint64_t *__restrict__ hi_out, uint32_t *__restrict__ meta_out, uint8_t *__restrict__ min_e,
-                       uint32_t *__restrict__ cnt, int32_t *__restrict__ list_scan, int32_t *__restrict__ list_dp,
-                       uint32_t *__restrict__ counters) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int64_t b0 = offs[r];
-    const int64_t len = offs[r + 1] - b0;
-    // The segment's bytes are fetched as the aligned 32-bit words that cover them (neighbouring lanes read
-    // neighbouring words, so the loads coalesce; the buffer is padded past its end).  Per byte: valid = one of
-    // A C G T (bit test on b & 31 for b in 0x40..0x5F), code = ((b >> 1) ^ (b >> 2)) & 3 for those, else 0.
-    uint32_t lo0 = 0, lo1 = 0, hi0 = 0, hi1 = 0;  // planes of characters 0..31 and 32..62
-    bool nonacgt = false;
-    const uint32_t *wp = reinterpret_cast<const uint32_t *>(segs) + (b0 >> 2);
-    const int skip = (int)(b0 & 3);
-    const int nbytes = (int)(len < (1 << 20) ? len : (1 << 20)) + skip;  // bytes from the first word's start
-    constexpr uint32_t ACGT_SET = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20);
-    for (int k = 0; k * 4 < nbytes; k++) {
-        const uint32_t w = wp[k];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i = k * 4 + j - skip;  // character index
-            if (i >= 0 && i < (int)len) {
-                const uint32_t b = (w >> (8 * j)) & 0xFFu;
-                const bool ok = (b >> 5) == 2u && ((ACGT_SET >> (b & 31u)) & 1u);
-                const uint32_t c = ok ? ((b >> 1) ^ (b >> 2)) & 3u : 0u;
-                nonacgt |= !ok;
-                if (i < 32) {
-                    lo0 |= (c & 1u) << i;
-                    hi0 |= (c >> 1) << i;
-                } else if (i < PLANE_MAX) {
-                    lo1 |= (c & 1u) << (i - 32);
-                    hi1 |= (c >> 1) << (i - 32);
-                }
-            }
-        }
-    }
-    for (int64_t i = (1 << 20); i < len; i++) nonacgt |= !sct_is_acgt(segs[b0 + i]);  // absurdly long rows
-    const uint64_t lo = lo0 | ((uint64_t)lo1 << 32), hi = hi0 | ((uint64_t)hi1 << 32);
-    uint32_t meta = (uint32_t)(len < 255 ? len : 255);
-    if (nonacgt) meta |= META_NONACGT;
-    if (len > PLANE_MAX) meta |= META_LONG;
-    lo_out[r] = lo;
-    hi_out[r] = hi;
-    meta_out[r] = meta;
-    if (len < bl - max_err) {
-        min_e[r] = SCT_NO_HIT;
-        cnt[r] = 0;
-        return;
-    }
-    if (nonacgt && prefix_len > 0) {
-        const uint32_t k = atomicAdd(&counters[1], 1u);
-        list_dp[k] = (int32_t)r;
-        cnt[r] = CNT_DEFER;
-    } else if (len > filter_maxlen) {  // filter_maxlen: 0 = no filter path, 31 = lane variant, 63 = wave kernels
-        const uint32_t k = atomicAdd(&counters[0], 1u);
-        list_scan[k] = (int32_t)r;
-        cnt[r] = CNT_DEFER;
-    } else {
-        cnt[r] = 0;  // filter path fills it in
-    }
-}
+#include "sct_kernels_common.h"
+#include "k_pack.hip.h"
+#include "k_filter.hip.h"
+#include "k_scan.hip.h"
+#include "k_offsets.hip.h"
+#include "k_whitelist.hip.h"
+#include "k_adapter.hip.h"
+#include "k_validate.hip.h"
 
-// ------------------------------------------------------------------------------------------------------------
-// Per-lane result of the filter kernels: running minimum distance and up to K_SLOTS distinct pattern ids at
-// that minimum, in registers (static indexing only).  More than K_SLOTS ties defer the segment to the scan path.
-// ------------------------------------------------------------------------------------------------------------
-template <int E, int KS = K_SLOTS>
-struct LaneResult {
-    static constexpr int K_SLOTS = KS;  // shadows the global default inside this struct
-    int best = E + 1;
-    int nh = 0;
-    uint32_t h[KS];
-
-    __device__ __forceinline__ void init() {
-        best = E + 1;
-        nh = 0;
-#pragma unroll
-        for (int i = 0; i < K_SLOTS; i++) h[i] = 0;
-    }
-    __device__ __forceinline__ void add(int d, uint32_t pid) {
-        if (d > E) return;
-        if (d < best) {
-            best = d;
-            nh = 0;
-        }
-        if (d != best) return;
-        bool dup = false;
-#pragma unroll
-        for (int i = 0; i < K_SLOTS; i++) dup |= (i < nh) && (h[i] == pid);
-        if (dup) return;
-#pragma unroll
-        for (int i = 0; i < K_SLOTS; i++)
-            if (i == nh) h[i] = pid;
-        nh++;  // may run past K_SLOTS: that is the defer signal
-    }
-    // Wave-cooperative store (every lane of the wave must call it; `row` says whether the lane owns a row).
-    // The hit lists of the wave are written back to back into the dense `slots` array: one wave-wide prefix sum
-    // of the list lengths and one 64-bit atomic per wave reserve the space, slot_off[r] remembers where row r's
-    // list starts.  Rows with too many ties are pushed to the scan list instead.
-    __device__ __forceinline__ void store(bool row, int64_t r, bool overflow, uint8_t *__restrict__ min_e,
-                                          uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
-                                          uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer,
-                                          uint32_t *__restrict__ defer_count, unsigned long long *__restrict__ slot_cursor,
-                                          uint64_t slot_tag) {
-        const int lane = threadIdx.x & 63;
-        const bool defer = row && (overflow || nh > K_SLOTS);
-        const uint32_t mine = (row && !defer) ? (uint32_t)nh : 0u;
-        uint32_t inc = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        const uint32_t total = __shfl(inc, 63, 64);
-        unsigned long long base = 0;
-        if (lane == 0 && total) base = atomicAdd(slot_cursor, (unsigned long long)total);
-        base = __shfl(base, 0, 64);
-        if (!row) return;
-        if (defer) {
-            const uint32_t k = atomicAdd(defer_count, 1u);
-            list_defer[k] = (int32_t)r;
-            cnt[r] = CNT_DEFER;
-            return;
-        }
-        cnt[r] = mine;
-        if (mine == 0) {
-            min_e[r] = SCT_NO_HIT;
-            return;
-        }
-        if (nh > 1) {  // sort ascending: odd-even transposition network on registers
-#pragma unroll
-            for (int i = 0; i < K_SLOTS; i++)
-                if (i >= nh) h[i] = 0xFFFFFFFFu;
-#pragma unroll
-            for (int round = 0; round < K_SLOTS; round++) {
-#pragma unroll
-                for (int i = round & 1; i + 1 < K_SLOTS; i += 2) {
-                    const uint32_t a = h[i], b = h[i + 1];
-                    h[i] = a < b ? a : b;
-                    h[i + 1] = a < b ? b : a;
-                }
-            }
-        }
-        min_e[r] = (uint8_t)best;
-        const uint64_t start = base + inc - mine;
-        slot_off[r] = start | slot_tag;
-#pragma unroll
-        for (int i = 0; i < K_SLOTS; i++)
-            if (i < nh) slots[start + i] = h[i];
-    }
-};
-
-// ------------------------------------------------------------------------------------------------------------
-// k_filter_lane<E> (first version, kept for A/B: option "filter_mode" = 1): one lane per segment, each lane walks
-// its own buckets and verifies its own candidates; lanes idle while the longest bucket of the wave is walked.
-// ------------------------------------------------------------------------------------------------------------
-template <int E>
-struct FilterLane {
-    const uint32_t *__restrict__ tab_off;
-    const uint32_t *__restrict__ tab_ent;
-    const uint2 *__restrict__ pat;
-    int np;
-    uint32_t tls, ths, ve, va;
-    LaneResult<E> res;
-
-    __device__ __forceinline__ void operator()(int f, uint32_t key) {
-        const uint32_t *off = tab_off + (size_t)f * (SCT_KEYS + 1) + key;
-        const uint32_t s = off[0], e = off[1];
-        for (uint32_t k = s; k < e; k++) {  // offsets index the concatenated entry table
-            const uint32_t pid = tab_ent[k];
-            const uint2 p = pat[pid];
-            res.add(wm_verify<E>(tls, ths, ve, va, p.x, p.y, 16), pid);
-        }
-    }
-};
-
-template <int E>
-__global__ void __launch_bounds__(256)
-k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
-              int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
-              const uint2 *__restrict__ pat, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
-              uint32_t *__restrict__ slots, uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_scan,
-              uint32_t *__restrict__ counters) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = r < n;
-    if (active) active = cnt[r] != CNT_DEFER;  // routed to a scan path by k_pack
-    int len = 0;
-    if (active) {
-        len = (int)(meta_in[r] & 0xFF);
-        active = len >= 16 - E;  // shorter rows were finished by k_pack
-    }
-    FilterLane<E> L;
-    L.res.init();
-    if (active) {
-        const uint32_t lo = (uint32_t)lo_in[r], hi = (uint32_t)hi_in[r];
-        L.tab_off = tab_off;
-        L.tab_ent = tab_ent;
-        L.pat = pat;
-        L.np = np;
-        L.tls = lo << 1;
-        L.ths = hi << 1;
-        L.va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
-        L.ve = L.va & ~1u;
-        sct_for_each_seed<E, uint32_t>(lo, hi, len, L);
-    }
-    L.res.store(active, r, false, min_e, cnt, slots, slot_off, list_scan, counters + 0,
-                reinterpret_cast<unsigned long long *>(counters + 4), 0ull);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// k_filter<E> (default): one WAVE per 64 segments, cooperating through LDS so that verification always runs on
-// full waves.  The seed families are processed one after the other; within a family
-//   lookup   every lane computes the seed key of its own segment for the current placement (t, t2) — the
-//            placements are walked wave-uniformly up to the longest segment of the wave — and reads its bucket
-//            range; the loads are issued one placement ahead of the queue work that consumes them;
-//   push     round by round, every lane that still has a candidate appends (table entry, lane, t, t2) to the
-//            wave's queue in LDS (position = tail + mbcnt(ballot));
-//   drain    whenever 64 candidates are queued, lane i takes entry head+i: reads the barcode's 2-bit codes from
-//            the table (L2), runs the ANCHORED Wu-Manber automaton of this family (8 of the 16 barcode
-//            characters, sct_core.h) against the owning segment's match masks in LDS, and on d <= E appends
-//            (d, pattern id) to that segment's list in LDS (LDS atomic counter);
-//   finish   (after the last family) every lane folds its own list into (minimum, distinct pattern ids), sorts
-//            and stores.
-// A segment with more than HMAX verified matches (duplicates included) or more than K_SLOTS ties is deferred.
-// All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
-// needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
-// ------------------------------------------------------------------------------------------------------------
-static constexpr int QCAP = 256;  // >= 63 left over + 64 lanes x 3 inline entries pushed in one pass
-#ifndef SCT_HMAX
-#define SCT_HMAX 8  // with the tiers a settled segment stops early, so few rows collect more than 8 verified matches
-#endif
-static constexpr int HMAX = SCT_HMAX;  // main launch
-static constexpr int K_RETRY = 32, H_RETRY = 64;  // retry launch
-static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
-static constexpr uint32_t LOC_MASK = (1u << 30) - 1u;    // locator in a hit-list entry (2 bits of distance above it)
-static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline slot entry (entry indices stay below it)
-
-// where each family's offsets start inside the concatenated offset table; the offsets themselves index the
-// concatenated entry tables (family f's entries start at f * np)
-struct FamTables {
-    uint32_t off_base[SCT_NFAM_ALL];
-};
-
-template <typename W, int HM>
-struct FilterWaveLds {
-    static constexpr int HMAX = HM;
-    alignas(32) W em[64][4];  // em[lane][c]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
-    W va[64];            // bits 0..len
-    W lo[64], hi[64];    // the segments' bit-planes (lookup lanes read the planes of the segment they work for)
-    uint8_t slen[64];    // and lengths
-    uint8_t alist[64];   // lanes whose segment still generates candidates, compacted
-    uint16_t ptab[sizeof(W) == 4 ? 128 : 320];  // this family's placements for the longest segment: t | t2 << 8
-    uint32_t best[64];   // smallest distance verified so far for the lane's segment
-    uint32_t hcnt[64];
-    uint32_t hlist[HM][64];
-    uint32_t qk[QCAP];   // queue: global table entry index f*np + k
-    uint32_t qm[QCAP];   //        lane | t << 8 | t2 << 16
-};
-
-__device__ __forceinline__ uint32_t lane_rank(uint64_t m) {  // number of set bits of m below this lane
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-struct __attribute__((packed, aligned(4))) OffPair {
-    uint32_t a, b;
-};
-
-template <typename W>
-struct EmLds {
-    uint32_t base;  // LDS byte address of em[segment lane][0]; aligned to 4 sizeof(W), so the mask's offset is OR-ed in
-    __device__ __forceinline__ explicit EmLds(const W *p)
-        : base((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) W *)p) {}
-    __device__ __forceinline__ W operator()(uint32_t c) const {
-        return *(const __attribute__((address_space(3))) W *)(uintptr_t)(base | (c * (uint32_t)sizeof(W)));
-    }
-};
-
-// Bucket slots (SL = true, the quarter families): one 8-byte word per key that answers most lookups by itself.
-//   bit 15 clear: bits 0..1 = n <= 3 entries in the bucket, bits 16j+16 .. 16j+31 = the REST characters of entry j
-//                 (sct_rest_of: all the verification needs besides the key); no other table is read unless the
-//                 entry verifies, and then its pattern id is tab_ent[off[key] + j]
-//   bit 15 set:   a longer bucket: bits 16..47 = its first entry index, bits 0..14 | bits 48..63 << 15 = its length;
-//                 the entries are queued by index and verified from tab_code as without slots
-// A queued entry is (qk, qm): qm = lane | t << 8 | t2 << 16 | j << 24 | inline << 31; qk = rest characters (inline)
-// or entry index.
-static constexpr uint32_t QM_INLINE = 0x80000000u;
-
-template <int E, typename W, int HM, bool SL>
-struct FilterWave {
-    static constexpr int HMAX = HM;
-    FilterWaveLds<W, HM> &L;
-    const uint32_t *__restrict__ tab_off;
-    const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
-    const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
-    const uint2 *__restrict__ tab_slot;     // bucket slots, indexed like tab_off
-    FamTables ft;
-    int lane;
-    bool active;
-    int len;
-    W lo, hi;
-    uint32_t head = 0, tail = 0;  // wave-uniform
-
-    template <typename Fam>
-    __device__ __forceinline__ void verify(const Fam &fam, bool take) {
-        if (take) {
-            const uint32_t idx = (head + lane) & (QCAP - 1);
-            uint32_t gk = L.qk[idx];
-            const uint32_t meta = L.qm[idx];
-            const uint32_t src = meta & 63u;
-            const int t = (int)((meta >> 8) & 63u), t2 = (int)((meta >> 16) & 63u);
-            const bool inl = SL && (meta & QM_INLINE) != 0u;
-            uint32_t rest = gk;  // an inline entry carries its rest characters (bits above them are ignored)
-#ifdef SCT_ABLATE_MISS  // timing-only build: no table is read after the slot (results are wrong)
-            if (!inl) rest = gk * 2654435761u;
-#else
-            if (!inl) rest = sct_rest_of(fam, tab_code[gk]);
-#endif
-#ifdef SCT_ABLATE_VERIFY  // timing-only build: candidates are fetched but never run through the automaton
-            asm volatile("" ::"v"(rest), "v"(t), "v"(t2));
-            const int d = E + 1;
-#else
-            const int d = wm_anchored_rest<E, W>(fam, EmLds<W>(&L.em[src][0]), L.va[src], rest, t, t2);
-#endif
-            if (d <= E) {
-                // what is kept is the entry's LOCATOR; the pattern ids are read once, when the segment is finished
-                // (resolve), so that no table read sits between two batches
-                if (inl)
-                    gk = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.lo[src], L.hi[src], t, t2)) << 2) |
-                         ((meta >> 24) & 3u);
-                atomicMin(&L.best[src], (uint32_t)d);
-                const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
-                if (k < HMAX) L.hlist[k][src] = ((uint32_t)d << 30) | gk;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    // pattern id of a verified entry: locator = entry index, or LOC_INLINE | (index into tab_off) << 2 | j
-    __device__ __forceinline__ uint32_t resolve(uint32_t loc) const {
-        if (SL && (loc & LOC_INLINE)) loc = tab_off[(loc & (LOC_INLINE - 1u)) >> 2] + (loc & 3u);
-        return tab_ent[loc];
-    }
-
-    // Tiering: the families are ordered so that after H1 every barcode at distance 0 has been verified, and after
-    // H1 + H2 every barcode at distance <= 1 (one half is untouched).  A segment whose minimum is already settled
-    // stops generating candidates for the later families — only the minimum tier is reported.
-    __device__ __forceinline__ void settle(uint32_t tier) {
-        if (active && L.best[lane] <= tier) active = false;
-    }
-
-    // Append the bucket of every lane to the queue; 64-entry batches are verified as they form.  (a, b) are the two
-    // words the lookup loaded.
-    //   SL:  a bucket slot.  All inline entries of the wave (<= 3 per lane) are placed in ONE pass: the two bits of
-    //        the lane's count are balloted separately, so the lane's first queue position is
-    //        tail + #(bit 0 below) + 2 #(bit 1 below).  Long buckets (rare while the barcode set is small) follow one
-    //        at a time, spread over the lanes: lane i queues entry first + i.
-    //   !SL: the bucket's first and end entry index; one entry per lane and pass.
-    template <typename Fam>
-    __device__ __forceinline__ void push_range(const Fam &fam, uint32_t a, uint32_t b, uint32_t meta) {
-        if constexpr (SL) {
-            const bool inl = (a & 0x8000u) == 0u;
-            const uint32_t c = inl ? (a & 3u) : 0u;
-            const uint64_t m0 = __ballot((c & 1u) != 0u), m1 = __ballot((c & 2u) != 0u);
-            const uint32_t A = __builtin_amdgcn_alignbit(b, a, 16);  // slot bits 16..47: two rests / first entry index
-            const uint32_t B = b >> 16;                              // slot bits 48..63: the third rest / length >> 15
-            if ((m0 | m1) != 0) {
-                const uint32_t pos = tail + lane_rank(m0) + 2u * lane_rank(m1);
-                const uint32_t mi = meta | QM_INLINE;
-                if (c >= 1u) {
-                    const uint32_t idx = pos & (QCAP - 1);
-                    L.qk[idx] = A;
-                    L.qm[idx] = mi;
-                }
-                if (c >= 2u) {
-                    const uint32_t idx = (pos + 1u) & (QCAP - 1);
-                    L.qk[idx] = __builtin_amdgcn_alignbit(B, A, 16);
-                    L.qm[idx] = mi + (1u << 24);
-                }
-                if (c >= 3u) {
-                    const uint32_t idx = (pos + 2u) & (QCAP - 1);
-                    L.qk[idx] = B;
-                    L.qm[idx] = mi + (2u << 24);
-                }
-                tail += (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1);
-                __builtin_amdgcn_wave_barrier();
-                while (tail - head >= 64) {
-                    verify(fam, true);
-                    head += 64;
-                }
-            }
-            uint64_t om = __ballot(!inl);
-            while (om != 0) {
-                const int src = __builtin_ctzll(om);
-                om &= om - 1;
-                const uint32_t first = __builtin_amdgcn_readlane(A, src);
-                const uint32_t n = (__builtin_amdgcn_readlane(a, src) & 0x7FFFu) | (__builtin_amdgcn_readlane(B, src) << 15);
-                const uint32_t mt = __builtin_amdgcn_readlane(meta, src);
-                for (uint32_t k0 = 0; k0 < n; k0 += 64) {
-                    const uint32_t take = n - k0 < 64u ? n - k0 : 64u;
-                    if ((uint32_t)lane < take) {
-                        const uint32_t idx = (tail + (uint32_t)lane) & (QCAP - 1);
-                        L.qk[idx] = first + k0 + (uint32_t)lane;
-                        L.qm[idx] = mt;
-                    }
-                    tail += take;
-                    __builtin_amdgcn_wave_barrier();
-                    while (tail - head >= 64) {
-                        verify(fam, true);
-                        head += 64;
-                    }
-                }
-            }
-        } else {
-            uint32_t c = b - a;
-            for (;;) {
-                const bool has = c > 0;
-                const uint64_t m = __ballot(has);
-                if (m == 0) break;
-                if (has) {
-                    const uint32_t idx = (tail + lane_rank(m)) & (QCAP - 1);
-                    L.qk[idx] = a;
-                    L.qm[idx] = meta;
-                    a++;
-                    c--;
-                }
-                tail += (uint32_t)__popcll(m);
-                __builtin_amdgcn_wave_barrier();
-                if (tail - head >= 64) {
-                    verify(fam, true);
-                    head += 64;
-                }
-            }
-        }
-    }
-
-    // One family.  The lookups are spread over the lanes as (active segment, placement) PAIRS: with A segments of
-    // the wave still generating candidates, G = 64 / A placements are looked up per pass (lane = g * A + a works on
-    // placement p0 + g for the a-th active segment), so the wave-uniform cost of a pass is shared by 64 lookups
-    // even when most segments have settled.  The placements of the family for the longest segment of the wave are
-    // tabulated in LDS once; a lane skips those its own segment is too short for.  The bucket range of a pass is
-    // queued while the loads of the next pass are in flight.
-    template <typename Fam>
-    __device__ __forceinline__ void run_family(const Fam &fam, int maxlen) {
-        const uint64_t am = __ballot(active);
-        if (am == 0) return;
-        const int A = (int)__popcll(am);
-        if (active) L.alist[lane_rank(am)] = (uint8_t)lane;
-        // placement table
-        int P = 0;
-#pragma unroll
-        for (int d = -fam.SLACK; d <= fam.SLACK; d++) {
-            const int c = maxlen - fam.GAP - d - fam.LB + 1;
-            if (c > 0) {
-                for (int t = lane; t < c; t += 64) L.ptab[P + t] = (uint16_t)(t | ((t + fam.GAP + d) << 8));
-                P += c;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (P == 0) return;
-        const int G = 64 / A;
-        const uint32_t inv = 65536u / (uint32_t)A + 1u;           // lane / A for lane < 64 (checked for every A <= 64)
-        const int g = (int)(((uint32_t)lane * inv) >> 16), a = lane - g * A;
-        const bool worker = g < G;
-        uint32_t sl = 0;
-        W slo = 0, shi = 0;
-        int slen = 0;
-        if (worker) {
-            sl = L.alist[a];
-            slo = L.lo[sl];
-            shi = L.hi[sl];
-            slen = (int)L.slen[sl];
-        }
-        const uint32_t *off = tab_off + ft.off_base[fam.INDEX];
-        const uint2 *slot = tab_slot + ft.off_base[fam.INDEX];
-        uint32_t ps = 0, pe = 0, pmeta = 0;  // the pass whose loads were issued last
-        bool pend = false;
-        for (int p0 = 0; p0 < P; p0 += G) {
-            const int p = p0 + g;
-            uint32_t s = 0, e = 0, meta = 0;
-            if (worker && p < P) {
-                const uint32_t tt = L.ptab[p];
-                const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
-                if (sct_valid_of(fam, t2, slen)) {
-                    // one 8-byte load: the bucket's slot, or its start and end (neighbouring words, 4-byte aligned;
-                    // absolute entry indices).  Nothing depends on the load until the bucket is queued, one pass later.
-                    const uint32_t key = sct_key_of<W>(fam, slo, shi, t, t2);
-                    if constexpr (SL) {
-                        const uint2 sv = slot[key];
-                        s = sv.x;
-                        e = sv.y;
-                    } else {
-                        const OffPair op = *reinterpret_cast<const OffPair *>(off + key);
-                        s = op.a;
-                        e = op.b;
-                    }
-                    meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
-#ifdef SCT_ABLATE_PUSH  // timing-only build: the bucket range is loaded but nothing is queued
-                    asm volatile("" ::"v"(s), "v"(e), "v"(meta));
-                    s = e = 0;
-#endif
-                }
-            }
-            if (pend) push_range(fam, ps, pe, pmeta);
-            pend = true;
-            ps = s;
-            pe = e;
-            pmeta = meta;
-        }
-        if (pend) push_range(fam, ps, pe, pmeta);
-        if (tail != head) {  // the family's last, partial batch
-            verify(fam, (uint32_t)lane < tail - head);
-            head = tail;
-        }
-    }
-};
-
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-// W = uint32_t handles the waves whose longest segment has at most 31 characters, W = uint64_t the others
-// (up to 63); both instantiations are launched over all rows and a wave leaves at once if it is not its kind.
-// THIRDS = true (max_err <= 1 only) walks the 20/22-bit families of the thirds scheme instead of the quarters.
-// KS / HM: ties kept per segment / verified matches kept per segment before the row is deferred.  The main launch
-// (KS 8, HM 16) covers all rows; rows it defers are retried by a launch with KS 32, HM 64 over the list `rows`
-// (16 listed rows per wave), and only what that launch defers again goes to the exhaustive scan.
-// RT = true: barcode length `bl` (8..16) other than 16, piece boundaries computed at run time (sct_family_rt).
-template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT>
-__global__ void __launch_bounds__(256)
-k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
-         int64_t n, const int32_t *__restrict__ rows, const uint32_t *__restrict__ tab_off,
-         const uint32_t *__restrict__ tab_ent, const uint32_t *__restrict__ tab_code,
-         const uint2 *__restrict__ tab_slot, FamTables ft, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
-         uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer, uint32_t *__restrict__ defer_count,
-         unsigned long long *__restrict__ slot_cursor, uint64_t slot_tag, int bl_arg) {
-    const int bl = RT ? bl_arg : 16;
-    __shared__ FilterWaveLds<W, HM> lds[4];
-    FilterWaveLds<W, HM> &L = lds[threadIdx.x >> 6];
-    const int lane = threadIdx.x & 63;
-    // RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows, so that the pair
-    // compaction of run_family spreads each row's lookups over four lanes and the few retried rows finish sooner
-    const int64_t gid = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * RPW + lane;
-    bool active = lane < RPW && gid < n;
-    int64_t r = gid;
-    int len = 0;
-    if (active) {
-        // per-row data is read once: non-temporal, so that it does not push the seed tables out of the L2
-        if (rows) r = rows[gid];                       // a retried row: listed explicitly
-        else active = __builtin_nontemporal_load(&cnt[r]) != CNT_DEFER;  // routed to a scan path by k_pack
-    }
-    if (active) {
-        len = (int)(__builtin_nontemporal_load(&meta_in[r]) & 0xFF);
-        active = len >= bl - E;  // shorter rows were finished by k_pack
-    }
-    if (!active) len = 0;
-    const int maxlen = wave_max_i(len);
-    if (maxlen == 0) return;  // the whole wave has nothing to do
-    if ((maxlen <= 31) != (sizeof(W) == 4)) return;  // the other instantiation's wave
-    W lo = 0, hi = 0;
-    if (active) {
-        lo = (W)__builtin_nontemporal_load(&lo_in[r]);
-        hi = (W)__builtin_nontemporal_load(&hi_in[r]);
-    }
-    const W va = sct_valid_mask<W>(len);
-    const W ve = va & ~(W)1, l1 = lo << 1, h1 = hi << 1;
-    L.em[lane][0] = ~l1 & ~h1 & ve;
-    L.em[lane][1] = l1 & ~h1 & ve;
-    L.em[lane][2] = ~l1 & h1 & ve;
-    L.em[lane][3] = l1 & h1 & ve;
-    L.va[lane] = va;
-    L.lo[lane] = lo;
-    L.hi[lane] = hi;
-    L.slen[lane] = (uint8_t)len;
-    L.best[lane] = E + 1;
-    L.hcnt[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    FilterWave<E, W, HM, !THIRDS> W_{L, tab_off, tab_ent, tab_code, tab_slot, ft, lane, active, len, lo, hi};
-#define RUN_FAMILY(FID)                                                         \
-    do {                                                                        \
-        if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \
-        else W_.run_family(SctFamily<FID>{}, maxlen);                           \
-    } while (0)
-    if (THIRDS) {
-        RUN_FAMILY(SCT_F_T01);
-        if (E >= 1) {
-            W_.settle(0);
-            RUN_FAMILY(SCT_F_T12);
-            RUN_FAMILY(SCT_F_T02);
-        }
-    } else {
-        RUN_FAMILY(SCT_F_H1);
-        if (E >= 1) {
-            W_.settle(0);
-            RUN_FAMILY(SCT_F_H2);
-        }
-        if (E >= 2) {
-            W_.settle(1);
-            RUN_FAMILY(SCT_F_MID);
-            RUN_FAMILY(SCT_F_02);
-            RUN_FAMILY(SCT_F_13);
-            RUN_FAMILY(SCT_F_03);
-        }
-    }
-#undef RUN_FAMILY
-    const uint32_t nc = active ? L.hcnt[lane] : 0u;
-    LaneResult<E, KS> res;
-    res.init();
-    const uint32_t lim = nc < (uint32_t)HM ? nc : (uint32_t)HM;
-    for (uint32_t k = 0; k < lim; k++) {
-        const uint32_t v = L.hlist[k][lane];
-        res.add((int)(v >> 30), W_.resolve(v & LOC_MASK));
-    }
-    res.store(active, r, nc > (uint32_t)HM, min_e, cnt, slots, slot_off, list_defer, defer_count, slot_cursor, slot_tag);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// k_scan<DP, FILL>: one wave per listed segment, lanes = patterns (64 per step), text wave-uniform.
-//   DP = false: Myers bit-vector (free start anywhere);  DP = true: plain DP, row 0 carries the allowed starts
-//   FILL = false: writes min_e / cnt;  FILL = true: writes the pattern ids at the minimum, ascending
-// The text is loaded 64 characters at a time, one per lane, and broadcast column by column with readlane.
-// ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-static constexpr int DP_BIG = 100;
-
-template <bool DP, bool FILL>
-__global__ void __launch_bounds__(256)
-k_scan(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const int32_t *__restrict__ list,
-       int64_t n_list, int n_slices, const uint2 *__restrict__ pat, int np, int bl, int max_err, int prefix_len,
-       const uint8_t *__restrict__ min_e, uint32_t *__restrict__ part_best, uint32_t *__restrict__ part_cnt,
-       const int64_t *__restrict__ hit_offs, uint32_t *__restrict__ hits) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int tiles = (np + 63) / 64;
-    const int tiles_per_slice = (tiles + n_slices - 1) / n_slices;
-    for (int64_t w = wave; w < n_list * n_slices; w += n_waves) {
-        const int64_t li = w / n_slices;
-        const int slice = (int)(w - li * n_slices);
-        const int64_t r = (int64_t)list[li];
-        const int64_t b0 = offs[r];
-        const int64_t len = offs[r + 1] - b0;
-        const int p_begin = slice * tiles_per_slice * 64;
-        const int p_end = min(np, p_begin + tiles_per_slice * 64);
-        int target = 0;
-        int64_t out_base = 0;
-        if (FILL) {
-            target = min_e[r];
-            if (target == SCT_NO_HIT) continue;
-            // a slice whose own minimum is worse than the row's holds no hit: nothing to recompute
-            if (part_best[w] != (uint32_t)target) continue;
-            // hits of the earlier slices at the same minimum come first
-            uint32_t mine = 0;
-            for (int sl = lane; sl < slice; sl += 64)
-                if (part_best[li * n_slices + sl] == (uint32_t)target) mine += part_cnt[li * n_slices + sl];
-            out_base = hit_offs[r] + wave_sum(mine);
-        }
-        int lane_best = max_err + 1;
-        uint32_t lane_cnt = 0;
-        uint32_t written = 0;  // wave-uniform
-        for (int p0 = p_begin; p0 < p_end; p0 += 64) {
-            const int p = p0 + lane;
-            const bool pvalid = p < p_end;
-            const uint2 pp = pvalid ? pat[p] : make_uint2(0, 0);
-            int d;
-            if (!DP) {
-                MyersState<uint32_t> s;
-                myers_init(s, bl);
-                int best = bl;
-                for (int64_t c0 = 0; c0 < len; c0 += 64) {
-                    const int64_t ci = c0 + lane;
-                    const uint32_t my = ci < len ? sct_code(segs[b0 + ci]) : 0u;
-                    const int ncol = (int)(len - c0 < 64 ? len - c0 : 64);
-                    for (int j = 0; j < ncol; j++) {
-                        const uint32_t c = __builtin_amdgcn_readlane(my, j);
-                        myers_step<uint32_t>(s, pp.x, pp.y, c, bl);
-                        best = min(best, s.score);
-                    }
-                }
-                d = best;
-            } else {
-                // col[i] = D[i][j] for i = 0..bl, in registers.  Row 0 is the distance back to the nearest text
-                // position at which the reference would start a window (scTagger.py:679-682): a window may start at
-                // position s iff s + k <= len and its first k raw bytes are all in "ACGT" (k = prefix_len).  Letting a
-                // window start at s lowers D[0][s] to 0, and through vertical moves D[i][s] to at most i.
-                int col[SCT_MAX_BL + 1];
-#pragma unroll
-                for (int i = 0; i <= SCT_MAX_BL; i++) col[i] = DP_BIG;
-                int best = DP_BIG;
-                for (int64_t c0 = 0; c0 < len; c0 += 64) {
-                    const int64_t ci = c0 + lane;
-                    uint32_t my = 0;
-                    bool al = false;
-                    if (ci < len) {
-                        my = sct_code(segs[b0 + ci]);
-                        al = ci + prefix_len <= len;
-                        for (int q = 0; q < prefix_len && al; q++) al = sct_is_acgt(segs[b0 + ci + q]);
-                    }
-                    const uint64_t almask = __ballot(al);
-                    const int ncol = (int)(len - c0 < 64 ? len - c0 : 64);
-                    for (int j = 0; j < ncol; j++) {
-                        const uint32_t c = __builtin_amdgcn_readlane(my, j);
-                        if ((almask >> j) & 1) {
-#pragma unroll
-                            for (int i = 0; i <= SCT_MAX_BL; i++) col[i] = min(col[i], i);
-                        }
-                        int diag = col[0];
-                        col[0] = min(col[0] + 1, DP_BIG);
-#pragma unroll
-                        for (int i = 1; i <= SCT_MAX_BL; i++) {
-                            if (i <= bl) {
-                                const uint32_t pc = ((pp.x >> (i - 1)) & 1u) | (((pp.y >> (i - 1)) & 1u) << 1);
-                                const int up = col[i];
-                                const int v = min(min(diag + (pc != c ? 1 : 0), up + 1), col[i - 1] + 1);
-                                diag = up;
-                                col[i] = min(v, DP_BIG);
-                                if (i == bl) best = min(best, col[i]);
-                            }
-                        }
-                    }
-                }
-                d = best;
-            }
-            const bool ok = pvalid && d <= max_err;
-            if (!FILL) {
-                if (ok) {
-                    if (d < lane_best) {
-                        lane_best = d;
-                        lane_cnt = 0;
-                    }
-                    if (d == lane_best) lane_cnt++;
-                }
-            } else {
-                const bool hit = ok && d == target;
-                const uint64_t m = __ballot(hit);
-                if (hit) {
-                    const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    hits[out_base + written + before] = (uint32_t)p;
-                }
-                written += (uint32_t)__popcll(m);
-            }
-        }
-        if (!FILL) {
-            const int wb = wave_min(lane_best);
-            const uint32_t total = wave_sum(lane_best == wb ? lane_cnt : 0u);
-            if (lane == 0) {
-                part_best[w] = (uint32_t)wb;
-                part_cnt[w] = total;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// k_scan_pk<FILL>: the Myers scan of k_scan for barcodes of at most 16 characters with TWO barcodes per lane, one in
-// each 16-bit half of the 32-bit state words (128 barcodes per wave step).  Bitwise operations and the +-1 score
-// updates act on both halves at once; only the addition of the carry chain needs the packed 16-bit add
-// (v_pk_add_u16) and the running minimum the packed min; the shifted words are masked so that nothing crosses from
-// the low half into the high one.  Same task decomposition, partial results and output order as k_scan.
-// ------------------------------------------------------------------------------------------------------------
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b));
-}
-__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
-}
-
-template <bool FILL>
-__global__ void __launch_bounds__(256)
-k_scan_pk(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const int32_t *__restrict__ list,
-          int64_t n_list, int n_slices, const uint2 *__restrict__ pat, int np, int bl, int max_err,
-          const uint8_t *__restrict__ min_e, uint32_t *__restrict__ part_best, uint32_t *__restrict__ part_cnt,
-          const int64_t *__restrict__ hit_offs, uint32_t *__restrict__ hits) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int tiles = (np + 63) / 64;
-    const int tiles_per_slice = (tiles + n_slices - 1) / n_slices;
-    const uint32_t one = 0x00010001u;
-    for (int64_t w = wave; w < n_list * n_slices; w += n_waves) {
-        const int64_t li = w / n_slices;
-        const int slice = (int)(w - li * n_slices);
-        const int64_t r = (int64_t)list[li];
-        const int64_t b0 = offs[r];
-        const int64_t len = offs[r + 1] - b0;
-        const int p_begin = slice * tiles_per_slice * 64;
-        const int p_end = min(np, p_begin + tiles_per_slice * 64);
-        int target = 0;
-        int64_t out_base = 0;
-        if (FILL) {
-            target = min_e[r];
-            if (target == SCT_NO_HIT) continue;
-            if (part_best[w] != (uint32_t)target) continue;  // a slice whose own minimum is worse holds no hit
-            uint32_t mine = 0;
-            for (int sl = lane; sl < slice; sl += 64)
-                if (part_best[li * n_slices + sl] == (uint32_t)target) mine += part_cnt[li * n_slices + sl];
-            out_base = hit_offs[r] + wave_sum(mine);
-        }
-        int lane_best = max_err + 1;
-        uint32_t lane_cnt = 0;
-        uint32_t written = 0;  // wave-uniform
-        for (int p0 = p_begin; p0 < p_end; p0 += 128) {
-            const int pa = p0 + lane, pb = p0 + 64 + lane;
-            const bool va = pa < p_end, vb = pb < p_end;
-            const uint2 qa = va ? pat[pa] : make_uint2(0, 0);
-            const uint2 qb = vb ? pat[pb] : make_uint2(0, 0);
-            const uint32_t LO = (qa.x & 0xFFFFu) | (qb.x << 16), HI = (qa.y & 0xFFFFu) | (qb.y << 16);
-            uint32_t Pv = 0xFFFFFFFFu, Mv = 0u;
-            uint32_t score = (uint32_t)bl * one, best = score;
-            for (int64_t c0 = 0; c0 < len; c0 += 64) {
-                const int64_t ci = c0 + lane;
-                const uint32_t my = ci < len ? sct_code(segs[b0 + ci]) : 0u;
-                const int ncol = (int)(len - c0 < 64 ? len - c0 : 64);
-                for (int j = 0; j < ncol; j++) {
-                    const uint32_t c = __builtin_amdgcn_readlane(my, j);
-                    const uint32_t ml = 0u - (c & 1u), mh = 0u - (c >> 1);
-                    const uint32_t Eq = ~(LO ^ ml) & ~(HI ^ mh);
-                    const uint32_t Xv = Eq | Mv;
-                    const uint32_t Xh = (pk_add16(Eq & Pv, Pv) ^ Pv) | Eq;
-                    uint32_t Ph = Mv | ~(Xh | Pv);
-                    uint32_t Mh = Pv & Xh;
-                    score = score + ((Ph >> (bl - 1)) & one) - ((Mh >> (bl - 1)) & one);
-                    Ph = (Ph << 1) & 0xFFFEFFFEu;
-                    Mh = (Mh << 1) & 0xFFFEFFFEu;
-                    Pv = Mh | ~(Xv | Ph);
-                    Mv = Ph & Xv;
-                    best = pk_min16(best, score);
-                }
-            }
-            const int da = (int)(best & 0xFFFFu), db = (int)(best >> 16);
-            const bool oka = va && da <= max_err, okb = vb && db <= max_err;
-            if (!FILL) {
-                if (oka) {
-                    if (da < lane_best) {
-                        lane_best = da;
-                        lane_cnt = 0;
-                    }
-                    if (da == lane_best) lane_cnt++;
-                }
-                if (okb) {
-                    if (db < lane_best) {
-                        lane_best = db;
-                        lane_cnt = 0;
-                    }
-                    if (db == lane_best) lane_cnt++;
-                }
-            } else {
-                const bool hita = oka && da == target, hitb = okb && db == target;
-                const uint64_t m1 = __ballot(hita), m2 = __ballot(hitb);
-                const uint64_t below = (1ull << lane) - 1ull;
-                if (hita) hits[out_base + written + (uint32_t)__popcll(m1 & below)] = (uint32_t)pa;
-                written += (uint32_t)__popcll(m1);
-                if (hitb) hits[out_base + written + (uint32_t)__popcll(m2 & below)] = (uint32_t)pb;
-                written += (uint32_t)__popcll(m2);
-            }
-        }
-        if (!FILL) {
-            const int wb = wave_min(lane_best);
-            const uint32_t total = wave_sum(lane_best == wb ? lane_cnt : 0u);
-            if (lane == 0) {
-                part_best[w] = (uint32_t)wb;
-                part_cnt[w] = total;
-            }
-        }
-    }
-}
-
-// fold the per-slice partial results of k_scan's count pass: one lane per listed segment
-__global__ void __launch_bounds__(256)
-k_scan_reduce(const int32_t *__restrict__ list, int64_t n_list, int n_slices, int max_err,
-              const uint32_t *__restrict__ part_best, const uint32_t *__restrict__ part_cnt,
-              uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt) {
-    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= n_list) return;
-    uint32_t best = (uint32_t)max_err + 1u, total = 0;
-    for (int sl = 0; sl < n_slices; sl++) {
-        const uint32_t b = part_best[li * n_slices + sl], c = part_cnt[li * n_slices + sl];
-        if (b < best) {
-            best = b;
-            total = 0;
-        }
-        if (b == best) total += c;
-    }
-    const int64_t r = list[li];
-    if (best <= (uint32_t)max_err) {
-        min_e[r] = (uint8_t)best;
-        cnt[r] = total;
-    } else {
-        min_e[r] = SCT_NO_HIT;
-        cnt[r] = 0;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// exclusive scan of cnt[n] (u32) into hit_offs[n+1] (i64): per-block sums, one-block scan of the sums, offsets
-// ------------------------------------------------------------------------------------------------------------
-static constexpr int SCAN_ITEMS = 8;                       // per thread
-static constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;        // elements per block
-
-__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *total, uint64_t *lds /* >= 5 */) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint64_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) lds[w] = inc;
-    __syncthreads();
-    uint64_t base = 0;
-    for (int i = 0; i < w; i++) base += lds[i];
-    if (threadIdx.x == blockDim.x - 1) lds[4] = base + inc;
-    __syncthreads();
-    *total = lds[4];
-    const uint64_t r = base + inc - v;
-    __syncthreads();
-    return r;
-}
-
-__global__ void __launch_bounds__(256) k_sum_blocks(const uint32_t *__restrict__ cnt, int64_t n, uint64_t *__restrict__ sums) {
-    __shared__ uint64_t lds[8];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
-    uint64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++)
-        if (base + i < n) s += cnt[base + i];
-    uint64_t total;
-    block_exclusive_scan(s, &total, lds);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-
-__global__ void __launch_bounds__(256) k_scan_sums(uint64_t *__restrict__ sums, int64_t nb, uint64_t *__restrict__ total_out) {
-    __shared__ uint64_t lds[8];
-    uint64_t carry = 0;
-    for (int64_t c0 = 0; c0 < nb; c0 += 256) {
-        const int64_t i = c0 + threadIdx.x;
-        const uint64_t v = i < nb ? sums[i] : 0;
-        uint64_t total;
-        const uint64_t ex = block_exclusive_scan(v, &total, lds);
-        if (i < nb) sums[i] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) *total_out = carry;
-}
-
-__global__ void __launch_bounds__(256) k_offsets(const uint32_t *__restrict__ cnt, int64_t n, const uint64_t *__restrict__ sums,
-                                                  const uint64_t *__restrict__ total, int64_t *__restrict__ hit_offs) {
-    __shared__ uint64_t lds[8];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        v[i] = base + i < n ? cnt[base + i] : 0u;
-        s += v[i];
-    }
-    uint64_t tot;
-    uint64_t run = sums[blockIdx.x] + block_exclusive_scan(s, &tot, lds);
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        if (base + i < n) hit_offs[base + i] = (int64_t)run;
-        run += v[i];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) hit_offs[n] = (int64_t)*total;
-}
-
-// filter path: slots -> CSR
-__global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ slots,
-                                               const uint32_t *__restrict__ slots_retry,
-                                               const uint64_t *__restrict__ slot_off, const int64_t *__restrict__ hit_offs,
-                                               const uint32_t *__restrict__ route_cnt, int64_t n, uint32_t *__restrict__ hits) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    if (route_cnt[r] == CNT_DEFER) return;  // written by the scan path's fill pass
-    const uint32_t c = cnt[r];
-    const int64_t o = hit_offs[r];
-    if (c == 0) return;
-    const uint64_t so = slot_off[r];
-    const uint32_t *src = (so & SLOT_TAG_RETRY) ? slots_retry : slots;
-    const uint64_t at = so & ~SLOT_TAG_RETRY;
-    for (uint32_t i = 0; i < c; i++) hits[o + i] = src[at + i];
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// k_wl_count: the matching loop of extract_sr_bc_from_lr (reference scTagger.py:818-826).  One lane per row.
-// Every occurrence of every dictionary key in the segment counts as a hit (Automaton.iter); rows with exactly one
-// hit add 1 to that barcode's counter (index |value|) and lower its first-seen row (the Counter's insertion order
-// breaks ties in the reference's sort).  Genuinely memory-bound: ~7 random 24-byte table probes per row.
-// ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_wl_count(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const uint8_t *__restrict__ skip, int64_t n,
-           const SctWlSlot *__restrict__ table, uint32_t mask, uint32_t len_set, uint32_t *__restrict__ counts,
-           uint32_t *__restrict__ first_seen) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    if (skip[r]) return;
-    const int64_t b0 = offs[r];
-    const int64_t len = offs[r + 1] - b0;
-    const uint32_t *wp = reinterpret_cast<const uint32_t *>(segs) + (b0 >> 2);
-    const int sk = (int)(b0 & 3);
-    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // the last 16 bytes read, newest in the top byte of w3
-    uint32_t hits = 0;
-    int32_t value = 0;
-    uint32_t word = 0;
-    for (int64_t i = 0; i < len; i++) {
-        const int64_t g = i + sk;
-        if ((g & 3) == 0 || i == 0) word = wp[g >> 2];
-        const uint32_t b = (word >> (8 * (g & 3))) & 0xFFu;
-        w0 = (w0 >> 8) | (w1 << 24);
-        w1 = (w1 >> 8) | (w2 << 24);
-        w2 = (w2 >> 8) | (w3 << 24);
-        w3 = (w3 >> 8) | (b << 24);
-        for (uint32_t ls = len_set; ls; ls &= ls - 1) {
-            const int L = __ffs(ls) - 1;  // key length, 1..16
-            if (i + 1 < L) continue;
-            // the last L bytes, zero padded: shift the 128-bit window right by 16-L bytes
-            const int sb = 16 - L, dw = sb >> 2, bs = (sb & 3) * 8;
-            uint32_t a0 = dw == 0 ? w0 : dw == 1 ? w1 : dw == 2 ? w2 : w3;
-            uint32_t a1 = dw == 0 ? w1 : dw == 1 ? w2 : dw == 2 ? w3 : 0u;
-            uint32_t a2 = dw == 0 ? w2 : dw == 1 ? w3 : 0u;
-            uint32_t a3 = dw == 0 ? w3 : 0u;
-            if (bs) {
-                a0 = (a0 >> bs) | (a1 << (32 - bs));
-                a1 = (a1 >> bs) | (a2 << (32 - bs));
-                a2 = (a2 >> bs) | (a3 << (32 - bs));
-                a3 = a3 >> bs;
-            }
-            uint32_t idx = sct_wl_hash(a0, a1, a2, a3, (uint32_t)L) & mask;
-            for (;;) {
-                const SctWlSlot s = table[idx];
-                if (s.len == 0) break;
-                if (s.len == (uint32_t)L && s.k[0] == a0 && s.k[1] == a1 && s.k[2] == a2 && s.k[3] == a3) {
-                    hits++;
-                    value = s.value;
-                    break;
-                }
-                idx = (idx + 1) & mask;
-            }
-        }
-    }
-    if (hits == 1) {
-        const uint32_t b = (uint32_t)(value < 0 ? -value : value);
-        atomicAdd(&counts[b], 1u);
-        atomicMin(&first_seen[b], (uint32_t)r);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// extract_lr_bc (reference scTagger.py:176-196): the adapter and its reverse complement are aligned to every whole
-// read in edlib's HW (infix) mode.  One lane per read, Myers bit-vector over the read's bytes (fetched as aligned
-// 32-bit words), match masks from a 256-entry table in LDS (symbols are raw bytes, as in edlib).
-//   k_adapter_count   both patterns in one pass: minimum distance of each and the number of end positions at
-//                     which it is reached; decides the strand ('+' if the adapter is strictly better, '-' if its
-//                     reverse complement is, none on a tie) and how many locations the read will report
-//   k_adapter_fill    second pass with the winning pattern only: writes the locations — end positions for '+';
-//                     for '-' the start of the longest optimal alignment ending there (edlib: reverse alignment in
-//                     prefix mode, last position with the same score), stored as start - len - 1 like the reference
-// ------------------------------------------------------------------------------------------------------------
-// one text byte through both automata, tracking for each the minimum, how often it is reached and where first / last
-struct AdapterTrack {
-    MyersState<uint32_t> s1, s2;
-    int best1, best2;
-    uint32_t c1 = 0, c2 = 0;
-    int64_t first1 = 0, last1 = 0, first2 = 0, last2 = 0;
-    __device__ __forceinline__ void step(uint32_t e1, uint32_t e2, int m, int64_t i) {
-        myers_step_eq<uint32_t, false>(s1, e1, m);
-        myers_step_eq<uint32_t, false>(s2, e2, m);
-        if (s1.score <= best1) {
-            if (s1.score < best1) {
-                c1 = 0;
-                first1 = i;
-            }
-            c1++;
-            last1 = i;
-            best1 = s1.score;
-        }
-        if (s2.score <= best2) {
-            if (s2.score < best2) {
-                c2 = 0;
-                first2 = i;
-            }
-            c2++;
-            last2 = i;
-            best2 = s2.score;
-        }
-    }
-};
-
-// The read is streamed in 64-byte aligned chunks held in registers (four 16-byte loads per lane and chunk: every
-// cache line is fetched exactly once, although neighbouring lanes walk different reads); bytes of the first and
-// last chunk that lie outside the read are skipped.  (Fetching word by word made every lane revisit its line 16
-// times with 64 different lines per wave instruction in between: 8.5 ms instead of 2.5 ms per 2 GB.)
-__global__ void __launch_bounds__(256)
-k_adapter_count(const uint8_t *__restrict__ reads, const int64_t *__restrict__ offs, int64_t n, const uint32_t *__restrict__ peq,
-                int m, int8_t *__restrict__ strand, int32_t *__restrict__ dist, uint32_t *__restrict__ cnt,
-                int64_t *__restrict__ win_first, int64_t *__restrict__ win_last) {
-    __shared__ uint32_t P1[256], P2[256];
-    P1[threadIdx.x] = peq[threadIdx.x];
-    P2[threadIdx.x] = peq[256 + threadIdx.x];
-    __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int64_t b0 = offs[r], b1 = offs[r + 1], len = b1 - b0;
-    AdapterTrack T;
-    myers_init(T.s1, m);
-    myers_init(T.s2, m);
-    T.best1 = T.best2 = m + 1;
-    const uint4 *base = reinterpret_cast<const uint4 *>(reads);
-    for (int64_t c = b0 >> 6; (c << 6) < b1; c++) {
-        uint4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = base[c * 4 + q];
-        const int64_t p0 = c << 6;
-        const bool whole = p0 >= b0 && p0 + 64 <= b1;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int64_t pos = p0 + q * 16 + k * 4 + j;
-                    if (whole || (pos >= b0 && pos < b1)) {
-                        const uint32_t b = (w[k] >> (8 * j)) & 0xFFu;
-                        T.step(P1[b], P2[b], m, pos - b0);
-                    }
-                }
-            }
-        }
-    }
-    int8_t st = 0;
-    int32_t d = -1;
-    uint32_t cc = 0;
-    int64_t wf = 0, wl = -1;
-    if (len > 0 && T.best1 != T.best2) {
-        if (T.best1 < T.best2) {
-            st = 1;
-            d = T.best1;
-            cc = T.c1;
-            wf = T.first1;
-            wl = T.last1;
-        } else {
-            st = 2;
-            d = T.best2;
-            cc = T.c2;
-            wf = T.first2;
-            wl = T.last2;
-        }
-    }
-    strand[r] = st;
-    dist[r] = d;
-    cnt[r] = cc;
-    win_first[r] = wf;
-    win_last[r] = wl;
-}
-
-// Second pass, winning pattern only, over the window [first end - 2m, last end] of the read: D[m][j] depends on at
-// most the 2m characters before j (an alignment of an m-character pattern with <= m edits is at most 2m long and the
-// start is free), so an automaton started 2m characters before the first reported end gives the same scores there.
-__global__ void __launch_bounds__(256)
-k_adapter_fill(const uint8_t *__restrict__ reads, const int64_t *__restrict__ offs, int64_t n, const uint32_t *__restrict__ peq,
-               int m, const int8_t *__restrict__ strand, const int32_t *__restrict__ dist, const int64_t *__restrict__ win_first,
-               const int64_t *__restrict__ win_last, const int64_t *__restrict__ loc_offs, int32_t *__restrict__ locs) {
-    __shared__ uint32_t P1[256], P2[256], P2R[256];
-    P1[threadIdx.x] = peq[threadIdx.x];
-    P2[threadIdx.x] = peq[256 + threadIdx.x];
-    P2R[threadIdx.x] = peq[512 + threadIdx.x];
-    __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int st = strand[r];
-    if (st == 0) return;
-    const int64_t b0 = offs[r], len = offs[r + 1] - b0;
-    const int d = dist[r];
-    const uint32_t *P = st == 1 ? P1 : P2;
-    int64_t out = loc_offs[r];
-    const int64_t first = win_first[r], last = win_last[r];
-    const int64_t from = first - 2 * m > 0 ? first - 2 * m : 0;
-    MyersState<uint32_t> s;
-    myers_init(s, m);
-    // bytes through a one-word cache: the forward walk and the short backward walks touch each word once
-    const uint32_t *wp = reinterpret_cast<const uint32_t *>(reads);
-    int64_t wi = -1;
-    uint32_t word = 0;
-    auto byte_at = [&](int64_t i) {
-        const int64_t g = b0 + i;
-        if ((g >> 2) != wi) {
-            wi = g >> 2;
-            word = wp[wi];
-        }
-        return (word >> (8 * (g & 3))) & 0xFFu;
-    };
-    for (int64_t i = from; i <= last; i++) {
-        myers_step_eq<uint32_t, false>(s, P[byte_at(i)], m);
-        if (i >= first && s.score == d) {
-            if (st == 1) {
-                locs[out++] = (int32_t)i;
-            } else {
-                // reverse alignment in prefix mode from this end; a position further back than m + d characters
-                // cannot reach score d (the characters before the match are charged)
-                MyersState<uint32_t> q;
-                myers_init(q, m);
-                int lastpos = 0;
-                const int lim = (int)((int64_t)(m + d) < i + 1 ? (int64_t)(m + d) : i + 1);
-                for (int t = 0; t < lim; t++) {
-                    myers_step_eq<uint32_t, true>(q, P2R[byte_at(i - t)], m);
-                    if (q.score == d) lastpos = t;
-                }
-                locs[out++] = (int32_t)((i - lastpos) - len - 1);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// k_validate: input checks of sct_upload_segments on the device.  bad[0] = smallest row whose offsets are not
-// non-decreasing (or n if offs[n] != bytes), bad[1] = smallest byte offset holding a value >= 128; ~0 = none.
-// ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_validate(const uint8_t *__restrict__ segs, int64_t bytes, const int64_t *__restrict__ offs, int64_t n,
-           unsigned long long *__restrict__ bad) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const int64_t a = offs[i], b = offs[i + 1];
-        if (b < a || a < 0 || b > bytes) atomicMin(&bad[0], (unsigned long long)i);
-    }
-    const int64_t p = i * 16;
-    if (p < bytes) {  // the buffer is padded by 64 bytes, so the 16-byte load may run past `bytes`
-        const uint4 v = *reinterpret_cast<const uint4 *>(segs + p);
-        if ((v.x | v.y | v.z | v.w) & 0x80808080u) {
-            for (int k = 0; k < 16 && p + k < bytes; k++)
-                if (segs[p + k] >= 128) {
-                    atomicMin(&bad[1], (unsigned long long)(p + k));
-                    break;
-                }
-        }
-    }
-}
 
 static inline unsigned blocks_for_n(int64_t n, int per) { return (unsigned)((n + per - 1) / per > 0 ? (n + per - 1) / per : 1); }
 
