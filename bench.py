@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--segments", type=int, default=None, help="override segments per GPU")
     ap.add_argument("--barcode-length", type=int, default=None, help="override the workload's barcode length (exploration)")
+    ap.add_argument("--barcodes", type=int, default=None, help="override the workload's barcode count (exploration)")
+    ap.add_argument("--max-err", type=int, default=None, help="override the workload's max_err (exploration)")
+    ap.add_argument("--slots", type=int, default=-1, help="bucket slots of the seed tables: -1 = library default, 0 = off, 1 = on (exploration)")
     ap.add_argument("--seg-len", type=int, default=22, help="segment length of the synthetic rows (22 = the reference's nominal length)")
     ap.add_argument("--cpu-sample", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,6 +113,10 @@ def main():
         n_seg = args.segments
     if args.barcode_length:
         bl = args.barcode_length
+    if args.barcodes:
+        n_bc = args.barcodes
+    if args.max_err is not None:
+        max_err = args.max_err
     bc = synth.make_barcodes(n_bc, bl=bl, seed=3)
     seed = 3 if world == 1 else 40 + rank
     segs, offs = make_batch(n_seg, bc, seed, seg_len=args.seg_len)
@@ -121,6 +128,8 @@ def main():
     if args.force_exhaustive:
         m.set_option("force_exhaustive", 1)
     m.set_option("filter_mode", args.filter_mode)
+    if args.slots >= 0:
+        m.set_option("slots", args.slots)
     m.upload_segments(segs, offs)
 
     def barrier():

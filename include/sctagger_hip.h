@@ -112,6 +112,8 @@ int sct_sync(sct_ctx *ctx);
  *   "timing"           0|1   record HIP events around each kernel of sct_run (default 1)
  *   "filter_mode"      0|1   0 = wave-cooperative seed-filter kernel (default), 1 = lane-per-segment variant
  *   "no_thirds"        0|1   1 = never use the 20/22-bit seed families chosen for >= 2^19 patterns at max_err <= 1
+ *   "slots"           -1|0|1 8-byte bucket slots of the 16-character seed tables: -1 = used while few keys hold more
+ *                            than three barcodes (3.5 % at max_err 2, 10 % below; default), 0 = never, 1 = always
  */
 int sct_set_option(sct_ctx *ctx, const char *key, int64_t value);
 

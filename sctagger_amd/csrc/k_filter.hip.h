@@ -469,7 +469,8 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // (KS 8, HM 16) covers all rows; rows it defers are retried by a launch with KS 32, HM 64 over the list `rows`
 // (16 listed rows per wave), and only what that launch defers again goes to the exhaustive scan.
 // RT = true: barcode length `bl` (8..16) other than 16, piece boundaries computed at run time (sct_family_rt).
-template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT>
+// SL = true: lookups read bucket slots (FilterWave); chosen by the host while few buckets are longer than a slot.
+template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT, bool SL>
 __global__ void __launch_bounds__(256)
 k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
          int64_t n, const int32_t *__restrict__ rows, const uint32_t *__restrict__ tab_off,
@@ -518,7 +519,8 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.best[lane] = E + 1;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    FilterWave<E, W, HM, !THIRDS> W_{L, tab_off, tab_ent, tab_code, tab_slot, ft, lane, active, len, lo, hi};
+    static_assert(!(SL && (THIRDS || RT)), "bucket slots exist for the 16-character quarter families only");
+    FilterWave<E, W, HM, SL> W_{L, tab_off, tab_ent, tab_code, tab_slot, ft, lane, active, len, lo, hi};
 #define RUN_FAMILY(FID)                                                         \
     do {                                                                        \
         if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \

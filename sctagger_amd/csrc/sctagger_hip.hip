@@ -127,6 +127,8 @@ struct sct_ctx {
     int32_t wl_n = -1;
     // options
     bool force_exhaustive = false, timing = true, no_thirds = false;
+    int slots_mode = -1;       // -1 = by the share of long buckets, 0 = never, 1 = whenever the tables hold them
+    double long_share = 1.0;   // share of the seed keys whose bucket does not fit a slot (sct_set_barcodes)
     int filter_mode = 0;  // 0 = wave-cooperative k_filter, 1 = k_filter_lane
     // timing
     std::vector<TimedKernel> timed;
@@ -248,6 +250,7 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "timing")) c->timing = value != 0;
     else if (!strcmp(key, "filter_mode")) c->filter_mode = (int)value;
     else if (!strcmp(key, "no_thirds")) c->no_thirds = value != 0;
+    else if (!strcmp(key, "slots")) c->slots_mode = value < 0 ? -1 : (value != 0);
     else return fail(SCT_E_ARG, "unknown option '%s'", key);
     return SCT_OK;
 }
@@ -335,6 +338,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
         size_t slot_total = 0;
         for (int f = 0; f < SCT_NFAM; f++) slot_total += (size_t)sct_family_nkeys(f) + 1;
         std::vector<uint64_t> slot(slot_total, 0ull);
+        size_t long_keys = 0;  // keys whose bucket does not fit a slot
         for (int f = 0; f < SCT_NFAM; f++) {
             const SctFamilyRT fam = sct_family_rt(f, bl);
             const uint32_t *o = off.data() + ft.off_base[f];
@@ -342,6 +346,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             for (uint32_t k = 0; k < sct_family_nkeys(f); k++) {
                 const uint32_t cnt = o[k + 1] - o[k];
                 uint64_t v;
+                if (cnt > 3) long_keys++;
                 if (cnt <= 3) {
                     v = cnt;
                     for (uint32_t j = 0; j < cnt; j++) v |= (uint64_t)(sct_rest_of(fam, code[o[k] + j]) & 0xFFFFu) << (16 * (j + 1));
@@ -351,6 +356,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
                 sl[k] = v;
             }
         }
+        c->long_share = (double)long_keys / (double)slot_total;
         if (c->tab_slot.ensure(slot.size() * sizeof(uint64_t))) return SCT_E_HIP;
         HIPCHK(hipMemcpyAsync(c->tab_slot.p, slot.data(), slot.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         if (c->tab_off.ensure(off.size() * sizeof(uint32_t) + 16)) return SCT_E_HIP;
@@ -420,6 +426,8 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     const int np = c->np, bl = c->bl;
     const int prefix_len = sct_prefix_len(threads);
     const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && (uint64_t)SCT_NFAM_ALL * (uint64_t)np < LOC_INLINE;
+    const bool use_slots = bl == 16 && (c->slots_mode < 0 ? c->long_share <= (max_err <= 1 ? SLOTS_MAX_LONG_SHARE_E1 : SLOTS_MAX_LONG_SHARE_E2)
+                                                          : c->slots_mode == 1);
     const bool use_thirds = filter_ok && c->have_thirds && max_err <= 1 && c->filter_mode != 1 && !c->no_thirds;
     const bool rt_families = bl != 16;  // quarter families with run-time piece boundaries
     const size_t n1 = (size_t)(n ? n : 1);
@@ -460,11 +468,14 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
 #define LAUNCH_WAVE(E, TH)                                                                                            \
     do {                                                                                                              \
         if (rt_families) {                                                                                            \
-            k_filter<E, uint32_t, false, K_SLOTS, HMAX, 64, true><<<g, 256, 0, st>>>(WAVE_ARGS);                       \
-            k_filter<E, uint64_t, false, K_SLOTS, HMAX, 64, true><<<g, 256, 0, st>>>(WAVE_ARGS);                       \
+            k_filter<E, uint32_t, false, K_SLOTS, HMAX, 64, true, false><<<g, 256, 0, st>>>(WAVE_ARGS);                \
+            k_filter<E, uint64_t, false, K_SLOTS, HMAX, 64, true, false><<<g, 256, 0, st>>>(WAVE_ARGS);                \
+        } else if (use_slots && !TH) {                                                                                \
+            k_filter<E, uint32_t, false, K_SLOTS, HMAX, 64, false, true><<<g, 256, 0, st>>>(WAVE_ARGS);                \
+            k_filter<E, uint64_t, false, K_SLOTS, HMAX, 64, false, true><<<g, 256, 0, st>>>(WAVE_ARGS);                \
         } else {                                                                                                      \
-            k_filter<E, uint32_t, TH, K_SLOTS, HMAX, 64, false><<<g, 256, 0, st>>>(WAVE_ARGS);                         \
-            k_filter<E, uint64_t, TH, K_SLOTS, HMAX, 64, false><<<g, 256, 0, st>>>(WAVE_ARGS);                         \
+            k_filter<E, uint32_t, TH, K_SLOTS, HMAX, 64, false, false><<<g, 256, 0, st>>>(WAVE_ARGS);                  \
+            k_filter<E, uint64_t, TH, K_SLOTS, HMAX, 64, false, false><<<g, 256, 0, st>>>(WAVE_ARGS);                  \
         }                                                                                                             \
     } while (0)
 #define LAUNCH_FILTER(E)                                                                                              \
@@ -502,11 +513,14 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
 #define LAUNCH_RETRY(E, TH)                                                                                           \
     do {                                                                                                              \
         if (rt_families) {                                                                                            \
-            k_filter<E, uint32_t, false, K_RETRY, H_RETRY, 16, true><<<g, 256, 0, st>>>(RETRY_ARGS);                   \
-            k_filter<E, uint64_t, false, K_RETRY, H_RETRY, 16, true><<<g, 256, 0, st>>>(RETRY_ARGS);                   \
+            k_filter<E, uint32_t, false, K_RETRY, H_RETRY, 16, true, false><<<g, 256, 0, st>>>(RETRY_ARGS);            \
+            k_filter<E, uint64_t, false, K_RETRY, H_RETRY, 16, true, false><<<g, 256, 0, st>>>(RETRY_ARGS);            \
+        } else if (use_slots && !TH) {                                                                                \
+            k_filter<E, uint32_t, false, K_RETRY, H_RETRY, 16, false, true><<<g, 256, 0, st>>>(RETRY_ARGS);            \
+            k_filter<E, uint64_t, false, K_RETRY, H_RETRY, 16, false, true><<<g, 256, 0, st>>>(RETRY_ARGS);            \
         } else {                                                                                                      \
-            k_filter<E, uint32_t, TH, K_RETRY, H_RETRY, 16, false><<<g, 256, 0, st>>>(RETRY_ARGS);                     \
-            k_filter<E, uint64_t, TH, K_RETRY, H_RETRY, 16, false><<<g, 256, 0, st>>>(RETRY_ARGS);                     \
+            k_filter<E, uint32_t, TH, K_RETRY, H_RETRY, 16, false, false><<<g, 256, 0, st>>>(RETRY_ARGS);              \
+            k_filter<E, uint64_t, TH, K_RETRY, H_RETRY, 16, false, false><<<g, 256, 0, st>>>(RETRY_ARGS);              \
         }                                                                                                             \
     } while (0)
         if (use_thirds && max_err == 0) LAUNCH_RETRY(0, true);

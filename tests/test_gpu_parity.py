@@ -30,6 +30,10 @@ def run_both(m, bc, segs, offs, e, t=1):
     m.set_option("force_exhaustive", 0)
     m.set_option("filter_mode", 0)
     a = m.match(segs, offs, e, t)
+    for sl in (0, 1):                       # with and without the bucket slots, whatever the library would pick
+        m.set_option("slots", sl)
+        util.assert_same(m.match(segs, offs, e, t), a, "slots=%d vs default" % sl)
+    m.set_option("slots", -1)
     m.set_option("filter_mode", 1)          # the one-lane-per-segment variant must agree bit for bit
     util.assert_same(m.match(segs, offs, e, t), a, "filter_mode 1 vs 0")
     m.set_option("filter_mode", 0)
@@ -202,9 +206,12 @@ def test_bucket_longer_than_the_slot_length_field(m, e):
     segs, offs = synth.make_segments(600, bc, seed=82 + e)
     want = trie_oracle.match(bc, segs, offs, e, threads=1, workers=8)
     m.set_barcodes(bc)
-    a = m.match(segs, offs, e, 1)
-    util.assert_same(a, want, "filter path")
-    assert m.last_stats()["filter"] > 0
+    for sl in (1, 0):
+        m.set_option("slots", sl)
+        a = m.match(segs, offs, e, 1)
+        util.assert_same(a, want, "filter path, slots=%d" % sl)
+        assert m.last_stats()["filter"] > 0
+    m.set_option("slots", -1)
 
 
 def test_empty_and_degenerate_inputs(m):
