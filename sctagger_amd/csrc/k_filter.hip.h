@@ -167,12 +167,20 @@ k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ h
 // All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
 // needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
 // ------------------------------------------------------------------------------------------------------------
-static constexpr int QCAP = 256;  // >= 63 left over + 64 lanes x 3 inline entries pushed in one pass
+// queue capacity: >= 63 left over + what one pass appends — 64 lanes x 3 inline slot entries, or one entry per lane.
+// The retry launch (long hit lists) takes the small queue where it can, to keep two 80 KB blocks per CU; the main
+// launch keeps 256 either way: its LDS footprint then allows 6 blocks per CU, and with seed tables far beyond the L2
+// a seventh only adds misses (1 M barcodes, e <= 2: 11.9 ms with 7 blocks per CU, 8.6 ms with 6).
+template <bool SL, int HM>
+struct QueueCap {
+    static constexpr int value = (SL || HM <= 16) ? 256 : 128;
+};
 #ifndef SCT_HMAX
 #define SCT_HMAX 8  // with the tiers a settled segment stops early, so few rows collect more than 8 verified matches
 #endif
 static constexpr int HMAX = SCT_HMAX;  // main launch
 static constexpr int K_RETRY = 32, H_RETRY = 64;  // retry launch
+static constexpr int H_RETRY_SL = 60;              // with bucket slots (larger queue): still two blocks of 80 KB per CU
 static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
 static constexpr uint32_t LOC_MASK = (1u << 30) - 1u;    // locator in a hit-list entry (2 bits of distance above it)
 static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline slot entry (entry indices stay below it)
@@ -183,8 +191,9 @@ struct FamTables {
     uint32_t off_base[SCT_NFAM_ALL];
 };
 
-template <typename W, int HM>
+template <typename W, int HM, int QC>
 struct FilterWaveLds {
+    static constexpr int QCAP = QC;
     static constexpr int HMAX = HM;
     alignas(32) W em[64][4];  // em[lane][c]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
     W va[64];            // bits 0..len
@@ -230,7 +239,8 @@ static constexpr uint32_t QM_INLINE = 0x80000000u;
 template <int E, typename W, int HM, bool SL>
 struct FilterWave {
     static constexpr int HMAX = HM;
-    FilterWaveLds<W, HM> &L;
+    static constexpr int QCAP = QueueCap<SL, HM>::value;
+    FilterWaveLds<W, HM, QCAP> &L;
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
     const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
@@ -479,8 +489,8 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
          uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer, uint32_t *__restrict__ defer_count,
          unsigned long long *__restrict__ slot_cursor, uint64_t slot_tag, int bl_arg) {
     const int bl = RT ? bl_arg : 16;
-    __shared__ FilterWaveLds<W, HM> lds[4];
-    FilterWaveLds<W, HM> &L = lds[threadIdx.x >> 6];
+    __shared__ FilterWaveLds<W, HM, QueueCap<SL, HM>::value> lds[4];
+    FilterWaveLds<W, HM, QueueCap<SL, HM>::value> &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     // RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows, so that the pair
     // compaction of run_family spreads each row's lookups over four lanes and the few retried rows finish sooner
@@ -548,13 +558,31 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
         }
     }
 #undef RUN_FAMILY
+    // Locators -> pattern ids, in place, by all lanes of the wave: with RPW rows per wave, 64 / RPW lanes share a row's
+    // list (the retry launch keeps up to 64 hits for each of its 16 rows), up to four table reads in flight per lane.
+    {
+        constexpr int PARTS = 64 / RPW;
+        const int row = lane % RPW, part = lane / RPW;
+        const uint32_t n_row = L.hcnt[row] < (uint32_t)HM ? L.hcnt[row] : (uint32_t)HM;  // 0 for rows without work
+        for (uint32_t k0 = (uint32_t)part; k0 < n_row; k0 += 4 * PARTS) {
+            uint32_t v[4], pid[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = k0 + i * PARTS < n_row ? L.hlist[k0 + i * PARTS][row] : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) pid[i] = k0 + i * PARTS < n_row ? W_.resolve(v[i] & LOC_MASK) : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (k0 + i * PARTS < n_row) L.hlist[k0 + i * PARTS][row] = (v[i] & ~LOC_MASK) | pid[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     const uint32_t nc = active ? L.hcnt[lane] : 0u;
     LaneResult<E, KS> res;
     res.init();
     const uint32_t lim = nc < (uint32_t)HM ? nc : (uint32_t)HM;
     for (uint32_t k = 0; k < lim; k++) {
         const uint32_t v = L.hlist[k][lane];
-        res.add((int)(v >> 30), W_.resolve(v & LOC_MASK));
+        res.add((int)(v >> 30), v & LOC_MASK);
     }
     res.store(active, r, nc > (uint32_t)HM, min_e, cnt, slots, slot_off, list_defer, defer_count, slot_cursor, slot_tag);
 }
