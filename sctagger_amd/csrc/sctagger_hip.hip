@@ -531,16 +531,15 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
 #undef LAUNCH_RETRY
 #undef RETRY_ARGS
     }
-    if (n > 0) {
-        // remember which rows are (still) deferred: cnt is about to be overwritten by the scan path's count pass
-        HIPCHK(hipMemcpyAsync(c->route.p, c->cnt.p, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
-        if (hc[2] > 0) {  // the retry may have deferred rows to the scan list
-            HIPCHK(hipMemcpyAsync(hc, c->counters.p, 16, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-        }
-    }
-    // a short list is cut into pattern slices so that the whole chip works on it; a long one needs no slicing
-    auto slices_for = [&](uint32_t rows) {
+    // The rows of the scan lists are those k_pack routed there (known since sync #1) and, rarely, rows the retry launch
+    // could not hold either.  The tail below — scan-path count passes, offsets, sync #2 — first runs with the lists as
+    // known; sync #2 also brings the counters back, and only if the retry launch did add rows is the tail run again
+    // with them (the count passes rewrite the same values for the rows they had already seen).
+    uint32_t *pb_scan = nullptr, *pc_scan = nullptr, *pb_dp = nullptr, *pc_dp = nullptr;
+    int sl_scan = 1, sl_dp = 1;
+    const uint32_t *route = c->cnt.as<uint32_t>();  // which rows are deferred (CNT_DEFER), as k_fill sees it
+    uint64_t total = 0;
+    auto slices_for = [&](uint32_t rows) {  // a short list is cut into pattern slices so that the whole chip works on it
         if (rows == 0) return 1;
         const int tiles = (np + 63) / 64;
         int64_t sl = (16384 + rows - 1) / rows;   // aim at 16 k waves in flight
@@ -549,60 +548,81 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         if (sl > tiles) sl = tiles;
         return (int)(sl < 1 ? 1 : sl);
     };
-    const int sl_scan = slices_for(hc[0]), sl_dp = slices_for(hc[1]);
     auto grid_for = [&](uint32_t rows, int sl) {
         const int64_t waves = (int64_t)rows * sl;
         const int64_t blocks = (waves + 3) / 4;
         return (unsigned)(blocks < 2048 ? (blocks < 1 ? 1 : blocks) : 2048);
     };
-    if (c->part_best.ensure(4 * ((size_t)hc[0] * sl_scan + (size_t)hc[1] * sl_dp + 1)) ||
-        c->part_cnt.ensure(4 * ((size_t)hc[0] * sl_scan + (size_t)hc[1] * sl_dp + 1)))
-        return SCT_E_HIP;
-    uint32_t *pb_scan = c->part_best.as<uint32_t>(), *pc_scan = c->part_cnt.as<uint32_t>();
-    uint32_t *pb_dp = pb_scan + (size_t)hc[0] * sl_scan, *pc_dp = pc_scan + (size_t)hc[0] * sl_scan;
-    if (n > 0) {
-        if (hc[0]) {
-            Timer t(c, "k_scan_count");
-            if (bl <= 16)
-                k_scan_pk<false><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
-                    c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
-                    np, bl, max_err, c->min_e.as<uint8_t>(), pb_scan, pc_scan, nullptr, nullptr);
-            else
-                k_scan<false, false><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
-                    c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
-                    np, bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_scan, pc_scan, nullptr, nullptr);
-            k_scan_reduce<<<blocks_for(hc[0], 256), 256, 0, st>>>(c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, max_err, pb_scan,
-                                                                  pc_scan, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>());
+    auto tail = [&]() -> int {
+        if (n > 0 && (hc[0] || hc[1]) && route == c->cnt.as<uint32_t>()) {
+            // remember which rows are deferred: their cnt is about to be overwritten by the count passes (taken once:
+            // the marks of the retry launch's rows are already in place when the tail first runs)
+            HIPCHK(hipMemcpyAsync(c->route.p, c->cnt.p, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
+            route = c->route.as<uint32_t>();
         }
-        if (hc[1]) {
-            Timer t(c, "k_dp_count");
-            k_scan<true, false><<<grid_for(hc[1], sl_dp), 256, 0, st>>>(
-                c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_dp.as<int32_t>(), (int64_t)hc[1], sl_dp, c->pat.as<uint2>(), np,
-                bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_dp, pc_dp, nullptr, nullptr);
-            k_scan_reduce<<<blocks_for(hc[1], 256), 256, 0, st>>>(c->list_dp.as<int32_t>(), (int64_t)hc[1], sl_dp, max_err, pb_dp, pc_dp,
-                                                                  c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>());
+        sl_scan = slices_for(hc[0]);
+        sl_dp = slices_for(hc[1]);
+        if (c->part_best.ensure(4 * ((size_t)hc[0] * sl_scan + (size_t)hc[1] * sl_dp + 1)) ||
+            c->part_cnt.ensure(4 * ((size_t)hc[0] * sl_scan + (size_t)hc[1] * sl_dp + 1)))
+            return SCT_E_HIP;
+        pb_scan = c->part_best.as<uint32_t>();
+        pc_scan = c->part_cnt.as<uint32_t>();
+        pb_dp = pb_scan + (size_t)hc[0] * sl_scan;
+        pc_dp = pc_scan + (size_t)hc[0] * sl_scan;
+        if (n > 0) {
+            if (hc[0]) {
+                Timer t(c, "k_scan_count");
+                if (bl <= 16)
+                    k_scan_pk<false><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
+                        c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
+                        np, bl, max_err, c->min_e.as<uint8_t>(), pb_scan, pc_scan, nullptr, nullptr);
+                else
+                    k_scan<false, false><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
+                        c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
+                        np, bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_scan, pc_scan, nullptr, nullptr);
+                k_scan_reduce<<<blocks_for(hc[0], 256), 256, 0, st>>>(c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, max_err, pb_scan,
+                                                                      pc_scan, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>());
+            }
+            if (hc[1]) {
+                Timer t(c, "k_dp_count");
+                k_scan<true, false><<<grid_for(hc[1], sl_dp), 256, 0, st>>>(
+                    c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_dp.as<int32_t>(), (int64_t)hc[1], sl_dp, c->pat.as<uint2>(), np,
+                    bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_dp, pc_dp, nullptr, nullptr);
+                k_scan_reduce<<<blocks_for(hc[1], 256), 256, 0, st>>>(c->list_dp.as<int32_t>(), (int64_t)hc[1], sl_dp, max_err, pb_dp, pc_dp,
+                                                                      c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>());
+            }
+            {
+                Timer t(c, "k_offsets");
+                k_sum_blocks<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>());
+                k_scan_sums<<<1, 256, 0, st>>>(c->sums.as<uint64_t>(), nb, c->total.as<uint64_t>());
+                k_offsets<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>(), c->total.as<uint64_t>(),
+                                                        c->hit_offs.as<int64_t>());
+            }
+        } else {
+            HIPCHK(hipMemsetAsync(c->hit_offs.p, 0, 8, st));
+            HIPCHK(hipMemsetAsync(c->total.p, 0, 8, st));
         }
-        {
-            Timer t(c, "k_offsets");
-            k_sum_blocks<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>());
-            k_scan_sums<<<1, 256, 0, st>>>(c->sums.as<uint64_t>(), nb, c->total.as<uint64_t>());
-            k_offsets<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>(), c->total.as<uint64_t>(),
-                                                    c->hit_offs.as<int64_t>());
-        }
-    } else {
-        HIPCHK(hipMemsetAsync(c->hit_offs.p, 0, 8, st));
-        HIPCHK(hipMemsetAsync(c->total.p, 0, 8, st));
-    }
-    // host sync #2: the total hit count sizes the CSR hit array
-    uint64_t total = 0;
+        return SCT_OK;
+    };
+    const uint32_t listed0 = hc[0];
+    if (int rc = tail()) return rc;
+    // host sync #2: the total hit count sizes the CSR hit array; the counters say whether the retry launch deferred rows
+    uint32_t hc2[4] = {hc[0], hc[1], hc[2], 0};
     HIPCHK(hipMemcpyAsync(&total, c->total.p, 8, hipMemcpyDeviceToHost, st));
+    if (n > 0) HIPCHK(hipMemcpyAsync(hc2, c->counters.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (hc2[0] != listed0) {
+        hc[0] = hc2[0];
+        if (int rc = tail()) return rc;
+        HIPCHK(hipMemcpyAsync(&total, c->total.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
     if (c->hits.ensure(4 * (size_t)(total ? total : 1))) return SCT_E_HIP;
     if (n > 0 && total > 0) {
         if (filter_ok) {
             Timer t(c, "k_fill");
             k_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->slots_retry.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->hit_offs.as<int64_t>(),
-                                                       c->route.as<uint32_t>(), n, c->hits.as<uint32_t>());
+                                                       route, n, c->hits.as<uint32_t>());
         }
         if (hc[0]) {
             Timer t(c, "k_scan_fill");
