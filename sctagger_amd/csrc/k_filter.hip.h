@@ -429,7 +429,21 @@ struct FilterWave {
         for (int p0 = 0; p0 < P; p0 += G) {
             const int p = p0 + g;
             uint32_t s = 0, e = 0, meta = 0;
-            if (worker && p < P) {
+            if constexpr (SL) {
+                // branch-free: a lane without a lookup of its own reads the spare all-zero slot behind the family's keys
+                const uint32_t tt = L.ptab[p < P ? p : P - 1];
+                const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
+                const bool ok = worker && p < P && sct_valid_of(fam, t2, slen);
+                const uint32_t key = sct_key_of<W>(fam, slo, shi, t, t2);
+                const uint2 sv = slot[ok ? key : (uint32_t)fam.NKEYS];
+                s = sv.x;
+                e = sv.y;
+                meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
+#ifdef SCT_ABLATE_PUSH  // timing-only build: the slot is loaded but nothing is queued
+                asm volatile("" ::"v"(s), "v"(e), "v"(meta));
+                s = e = 0;
+#endif
+            } else if (worker && p < P) {
                 const uint32_t tt = L.ptab[p];
                 const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
                 if (sct_valid_of(fam, t2, slen)) {
