@@ -310,11 +310,11 @@ struct FilterWave {
     template <typename Fam>
     __device__ __forceinline__ void push_range(const Fam &fam, uint32_t a, uint32_t b, uint32_t meta) {
         if constexpr (SL) {
-            const bool inl = (a & 0x8000u) == 0u;
-            const uint32_t c = inl ? (a & 3u) : 0u;
+            const bool inl = sct_slot_is_inline(a);
+            const uint32_t c = inl ? sct_slot_inline_count(a) : 0u;
             const uint64_t m0 = __ballot((c & 1u) != 0u), m1 = __ballot((c & 2u) != 0u);
-            const uint32_t A = __builtin_amdgcn_alignbit(b, a, 16);  // slot bits 16..47: two rests / first entry index
-            const uint32_t B = b >> 16;                              // slot bits 48..63: the third rest / length >> 15
+            const uint32_t A = sct_slot_mid(a, b);  // slot bits 16..47: two rests / first entry index
+            const uint32_t B = sct_slot_top(b);     // slot bits 48..63: the third rest / length >> 15
             if ((m0 | m1) != 0) {
                 const uint32_t pos = tail + lane_rank(m0) + 2u * lane_rank(m1);
                 const uint32_t mi = meta | QM_INLINE;
@@ -325,7 +325,7 @@ struct FilterWave {
                 }
                 if (c >= 2u) {
                     const uint32_t idx = (pos + 1u) & (QCAP - 1);
-                    L.qk[idx] = __builtin_amdgcn_alignbit(B, A, 16);
+                    L.qk[idx] = sct_slot_next(A, B);
                     L.qm[idx] = mi + (1u << 24);
                 }
                 if (c >= 3u) {
@@ -345,7 +345,7 @@ struct FilterWave {
                 const int src = __builtin_ctzll(om);
                 om &= om - 1;
                 const uint32_t first = __builtin_amdgcn_readlane(A, src);
-                const uint32_t n = (__builtin_amdgcn_readlane(a, src) & 0x7FFFu) | (__builtin_amdgcn_readlane(B, src) << 15);
+                const uint32_t n = sct_slot_long_count(__builtin_amdgcn_readlane(a, src), __builtin_amdgcn_readlane(B, src));
                 const uint32_t mt = __builtin_amdgcn_readlane(meta, src);
                 for (uint32_t k0 = 0; k0 < n; k0 += 64) {
                     const uint32_t take = n - k0 < 64u ? n - k0 : 64u;

@@ -377,6 +377,30 @@ SCT_HD int wm_anchored(EmFetch &&em, W va, uint32_t code, int t, int t2) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Bucket slots of the quarter families (k_filter.hip.h): one 8-byte word per seed key, read as two 32-bit words
+// (a = bits 0..31, b = bits 32..63), that answers most lookups by itself.
+//   bit 15 clear  inline bucket: bits 0..1 = n <= 3 entries, bits 16(j+1) .. 16(j+1)+15 = rest characters of entry j
+//                 (sct_rest_of) — all a verification needs besides the key
+//   bit 15 set    long bucket: bits 16..47 = index of its first entry, bits 0..14 | bits 48..63 << 15 = its length
+// The kernel queues entry 0 as `mid`, entry 1 as the funnel shift {top, mid} >> 16 and entry 2 as `top`: the low 16
+// bits of each are that entry's rest (the automaton ignores what lies above them).
+// ---------------------------------------------------------------------------------------------------
+SCT_HD uint64_t sct_slot_inline(uint32_t n, const uint32_t *rest) {
+    uint64_t v = n;
+    for (uint32_t j = 0; j < n; j++) v |= (uint64_t)(rest[j] & 0xFFFFu) << (16 * (j + 1));
+    return v;
+}
+SCT_HD uint64_t sct_slot_long(uint32_t first, uint32_t n) {
+    return 0x8000ull | (n & 0x7FFFu) | ((uint64_t)first << 16) | ((uint64_t)(n >> 15) << 48);
+}
+SCT_HD bool sct_slot_is_inline(uint32_t a) { return (a & 0x8000u) == 0u; }
+SCT_HD uint32_t sct_slot_inline_count(uint32_t a) { return a & 3u; }
+SCT_HD uint32_t sct_slot_mid(uint32_t a, uint32_t b) { return (uint32_t)((((uint64_t)b << 32) | a) >> 16); }  // bits 16..47
+SCT_HD uint32_t sct_slot_top(uint32_t b) { return b >> 16; }                                                    // bits 48..63
+SCT_HD uint32_t sct_slot_long_count(uint32_t a, uint32_t top) { return (a & 0x7FFFu) | (top << 15); }
+SCT_HD uint32_t sct_slot_next(uint32_t mid, uint32_t top) { return (uint32_t)((((uint64_t)top << 32) | mid) >> 16); }
+
+// ---------------------------------------------------------------------------------------------------
 // Whitelist dictionary of the extract_sr_bc_from_lr stage (reference scTagger.py:801-809): keys are whole
 // barcodes of 1..16 raw bytes, zero-padded into four little-endian words.  One open-addressing table holds
 // all keys (the length is part of the key); host build and device lookup share hash and slot layout.

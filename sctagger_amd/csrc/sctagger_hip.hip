@@ -345,15 +345,14 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             uint64_t *sl = slot.data() + ft.off_base[f];
             for (uint32_t k = 0; k < sct_family_nkeys(f); k++) {
                 const uint32_t cnt = o[k + 1] - o[k];
-                uint64_t v;
-                if (cnt > 3) long_keys++;
                 if (cnt <= 3) {
-                    v = cnt;
-                    for (uint32_t j = 0; j < cnt; j++) v |= (uint64_t)(sct_rest_of(fam, code[o[k] + j]) & 0xFFFFu) << (16 * (j + 1));
+                    uint32_t rest[3] = {0, 0, 0};
+                    for (uint32_t j = 0; j < cnt; j++) rest[j] = sct_rest_of(fam, code[o[k] + j]);
+                    sl[k] = sct_slot_inline(cnt, rest);
                 } else {
-                    v = 0x8000ull | (cnt & 0x7FFFu) | ((uint64_t)o[k] << 16) | ((uint64_t)(cnt >> 15) << 48);
+                    long_keys++;
+                    sl[k] = sct_slot_long(o[k], cnt);
                 }
-                sl[k] = v;
             }
         }
         c->long_share = (double)long_keys / (double)slot_total;

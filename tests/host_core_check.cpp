@@ -262,6 +262,24 @@ int main() {
         if (!check_adapter(q, t)) { printf("FAIL adapter m=%d n=%d\n", m, n); return 1; }
         checked++;
     }
+    // 1c. bucket slots: what the kernel decodes (and queues) is what the table builder packed
+    for (int it = 0; it < 200000; it++) {
+        const uint32_t n = (uint32_t)rnd(4);
+        uint32_t rest[3] = {(uint32_t)rng(), (uint32_t)rng(), (uint32_t)rng()};
+        const uint64_t v = sct_slot_inline(n, rest);
+        const uint32_t a = (uint32_t)v, b = (uint32_t)(v >> 32);
+        const uint32_t mid = sct_slot_mid(a, b), top = sct_slot_top(b);
+        const uint32_t q[3] = {mid, sct_slot_next(mid, top), top};  // entries 0, 1, 2 as queued
+        bool ok = sct_slot_is_inline(a) && sct_slot_inline_count(a) == n;
+        for (uint32_t j = 0; j < n; j++) ok = ok && (q[j] & 0xFFFFu) == (rest[j] & 0xFFFFu);
+        const uint32_t first = (uint32_t)rng();
+        const uint32_t len = it % 3 == 0 ? 4u + (uint32_t)rnd(70000) : 4u + (uint32_t)(rng() % 0x7FFFFFFCull);
+        const uint64_t w = sct_slot_long(first, len);
+        const uint32_t wa = (uint32_t)w, wb = (uint32_t)(w >> 32);
+        ok = ok && !sct_slot_is_inline(wa) && sct_slot_mid(wa, wb) == first && sct_slot_long_count(wa, sct_slot_top(wb)) == len;
+        if (!ok) { printf("FAIL slot n=%u\n", n); return 1; }
+        checked++;
+    }
     // 2. transposed Wu-Manber + seed completeness, bl = 16, texts 0..31, planted copies with 0..3 edits
     for (int it = 0; it < 300000; it++) {
         const int m = 16, alpha = (it % 7 == 0) ? 2 : 4;
