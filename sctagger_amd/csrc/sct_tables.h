@@ -1,0 +1,83 @@
+// sct_tables.h — host-side construction of the seed tables of the filter kernel (plain C++, no HIP): used by
+// sct_set_barcodes and, in tests/host_core_check.cpp, by a CPU emulation of the filter path over the same tables.
+//
+// Per family f (sct_core.h): an offsets array of nkeys(f) + 1 entries holding ABSOLUTE indices into the entry tables
+// (family f's entries start at f * np), the entries as pattern ids (ascending inside a bucket) and as 2-bit codes, and
+// — for the six quarter families — one 8-byte bucket slot per key (sct_slot_*), indexed like the offsets.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "sct_core.h"
+
+struct SctSeedTables {
+    int nfam = 0;
+    uint32_t off_base[SCT_NFAM_ALL] = {};  // where family f's offsets (and slots) start
+    std::vector<uint32_t> off, ent, code;
+    std::vector<uint64_t> slot;
+    double long_share = 1.0;               // share of the quarter families' keys whose bucket does not fit a slot
+};
+
+// pat[p].x / .y: bit-planes of pattern p (np patterns of bl characters, 8 <= bl <= 16); thirds: also build the
+// 20/22-bit families (bl == 16 only).  Returns false if the tables would not be addressable with 32-bit indices.
+template <typename Pat>
+static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds, SctSeedTables &T) {
+    T.nfam = thirds ? SCT_NFAM_ALL : SCT_NFAM;
+    size_t off_total = 0;
+    for (int f = 0; f < T.nfam; f++) {
+        if (off_total + sct_family_nkeys(f) + 1 > 0xFFFFFFFFull || (uint64_t)(f + 1) * (uint64_t)np > 0xFFFFFFFFull) return false;
+        T.off_base[f] = (uint32_t)off_total;
+        off_total += (size_t)sct_family_nkeys(f) + 1;
+    }
+    const size_t npn = np ? (size_t)np : 1;
+    T.off.assign(off_total, 0u);
+    T.ent.assign((size_t)T.nfam * npn, 0u);
+    T.code.assign((size_t)T.nfam * npn, 0u);
+    std::vector<uint32_t> inter(npn);
+    for (int p = 0; p < np; p++) {
+        uint32_t v = 0;
+        for (int j = 0; j < bl; j++) v |= (((pat[p].x >> j) & 1u) | (((pat[p].y >> j) & 1u) << 1)) << (2 * j);
+        inter[p] = v;
+    }
+    for (int f = 0; f < T.nfam; f++) {
+        const uint32_t nk = sct_family_nkeys(f);
+        uint32_t *o = T.off.data() + T.off_base[f];
+        auto key_of = [&](int p) {  // quarter families: piece boundaries from the barcode length
+            if (f >= SCT_NFAM) return sct_pattern_key(f, pat[p].x, pat[p].y);
+            const SctFamilyRT fam = sct_family_rt(f, bl);
+            return sct_key_of<uint32_t>(fam, pat[p].x, pat[p].y, fam.PA, fam.PB);
+        };
+        for (int p = 0; p < np; p++) o[key_of(p) + 1]++;
+        o[0] = (uint32_t)((size_t)f * np);
+        for (uint32_t k = 0; k < nk; k++) o[k + 1] += o[k];
+        std::vector<uint32_t> cur(o, o + nk);
+        for (int p = 0; p < np; p++) {
+            const uint32_t at = cur[key_of(p)]++;
+            T.ent[at] = (uint32_t)p;
+            T.code[at] = inter[p];
+        }
+    }
+    size_t slot_total = 0;
+    for (int f = 0; f < SCT_NFAM; f++) slot_total += (size_t)sct_family_nkeys(f) + 1;
+    T.slot.assign(slot_total, 0ull);
+    size_t long_keys = 0;
+    for (int f = 0; f < SCT_NFAM; f++) {
+        const SctFamilyRT fam = sct_family_rt(f, bl);
+        const uint32_t *o = T.off.data() + T.off_base[f];
+        uint64_t *sl = T.slot.data() + T.off_base[f];
+        for (uint32_t k = 0; k < sct_family_nkeys(f); k++) {
+            const uint32_t cnt = o[k + 1] - o[k];
+            if (cnt <= 3) {
+                uint32_t rest[3] = {0, 0, 0};
+                for (uint32_t j = 0; j < cnt; j++) rest[j] = sct_rest_of(fam, T.code[o[k] + j]);
+                sl[k] = sct_slot_inline(cnt, rest);
+            } else {
+                long_keys++;
+                sl[k] = sct_slot_long(o[k], cnt);
+            }
+        }
+    }
+    T.long_share = (double)long_keys / (double)slot_total;
+    return true;
+}

@@ -41,6 +41,7 @@
 
 #include "../../include/sctagger_hip.h"
 #include "sct_core.h"
+#include "sct_tables.h"
 
 // ------------------------------------------------------------------------------------------------------------
 // error plumbing
@@ -297,65 +298,16 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
     c->have_tables = false;
     c->have_thirds = false;
     if (bl >= 8 && bl <= 16) {
-        // seed tables: counting sort of the pattern ids by key, per family (ids ascending inside a bucket).
+        // seed tables (sct_tables.h): counting sort of the pattern ids by key, per family, plus the bucket slots.
         // The thirds families (20/22-bit keys) are only worth their 38 MB of offsets for very large barcode sets.
         const bool thirds = bl == 16 && np >= THIRDS_MIN_PATTERNS;
-        const int nfam = thirds ? SCT_NFAM_ALL : SCT_NFAM;
+        SctSeedTables tb;
+        if (!sct_build_tables(pat.data(), np, bl, thirds, tb)) return fail(SCT_E_UNSUPPORTED, "too many barcodes for the seed tables");
         FamTables ft{};
-        size_t off_total = 0;
-        for (int f = 0; f < nfam; f++) {
-            if (off_total + sct_family_nkeys(f) + 1 > 0xFFFFFFFFull || (uint64_t)(f + 1) * (uint64_t)np > 0xFFFFFFFFull)
-                return fail(SCT_E_UNSUPPORTED, "too many barcodes for the seed tables");
-            ft.off_base[f] = (uint32_t)off_total;
-            off_total += (size_t)sct_family_nkeys(f) + 1;
-        }
-        std::vector<uint32_t> off(off_total, 0u), ent((size_t)nfam * (np ? np : 1)), code((size_t)nfam * (np ? np : 1));
-        std::vector<uint32_t> inter((size_t)(np ? np : 1));
-        for (int p = 0; p < np; p++) {
-            uint32_t v = 0;
-            for (int j = 0; j < bl; j++) v |= (((pat[p].x >> j) & 1u) | (((pat[p].y >> j) & 1u) << 1)) << (2 * j);
-            inter[p] = v;
-        }
-        for (int f = 0; f < nfam; f++) {
-            const uint32_t nk = sct_family_nkeys(f);
-            uint32_t *o = off.data() + ft.off_base[f];
-            auto key_of = [&](int p) {  // quarter families: piece boundaries from the barcode length
-                if (f >= SCT_NFAM) return sct_pattern_key(f, pat[p].x, pat[p].y);
-                const SctFamilyRT fam = sct_family_rt(f, bl);
-                return sct_key_of<uint32_t>(fam, pat[p].x, pat[p].y, fam.PA, fam.PB);
-            };
-            for (int p = 0; p < np; p++) o[key_of(p) + 1]++;
-            o[0] = (uint32_t)((size_t)f * np);
-            for (uint32_t k = 0; k < nk; k++) o[k + 1] += o[k];
-            std::vector<uint32_t> cur(o, o + nk);
-            for (int p = 0; p < np; p++) {
-                const uint32_t at = cur[key_of(p)]++;
-                ent[at] = (uint32_t)p;
-                code[at] = inter[p];
-            }
-        }
-        // bucket slots of the quarter families (layout: FilterWave)
-        size_t slot_total = 0;
-        for (int f = 0; f < SCT_NFAM; f++) slot_total += (size_t)sct_family_nkeys(f) + 1;
-        std::vector<uint64_t> slot(slot_total, 0ull);
-        size_t long_keys = 0;  // keys whose bucket does not fit a slot
-        for (int f = 0; f < SCT_NFAM; f++) {
-            const SctFamilyRT fam = sct_family_rt(f, bl);
-            const uint32_t *o = off.data() + ft.off_base[f];
-            uint64_t *sl = slot.data() + ft.off_base[f];
-            for (uint32_t k = 0; k < sct_family_nkeys(f); k++) {
-                const uint32_t cnt = o[k + 1] - o[k];
-                if (cnt <= 3) {
-                    uint32_t rest[3] = {0, 0, 0};
-                    for (uint32_t j = 0; j < cnt; j++) rest[j] = sct_rest_of(fam, code[o[k] + j]);
-                    sl[k] = sct_slot_inline(cnt, rest);
-                } else {
-                    long_keys++;
-                    sl[k] = sct_slot_long(o[k], cnt);
-                }
-            }
-        }
-        c->long_share = (double)long_keys / (double)slot_total;
+        for (int f = 0; f < tb.nfam; f++) ft.off_base[f] = tb.off_base[f];
+        const std::vector<uint32_t> &off = tb.off, &ent = tb.ent, &code = tb.code;
+        const std::vector<uint64_t> &slot = tb.slot;
+        c->long_share = tb.long_share;
         if (c->tab_slot.ensure(slot.size() * sizeof(uint64_t))) return SCT_E_HIP;
         HIPCHK(hipMemcpyAsync(c->tab_slot.p, slot.data(), slot.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         if (c->tab_off.ensure(off.size() * sizeof(uint32_t) + 16)) return SCT_E_HIP;

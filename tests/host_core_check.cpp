@@ -8,7 +8,10 @@
 #include <random>
 #include <vector>
 
+#include <set>
+
 #include "../sctagger_amd/csrc/sct_core.h"
+#include "../sctagger_amd/csrc/sct_tables.h"
 
 static int brute_infix(const std::vector<int> &p, const std::vector<int> &t) {
     const int m = (int)p.size(), n = (int)t.size();
@@ -228,6 +231,64 @@ static bool check_adapter(const std::vector<int> &q, const std::vector<int> &t) 
     return true;
 }
 
+// ---- the filter path over the seed tables, emulated on the host: every (family, placement) lookup of a text goes
+// through the bucket slots (and, second run, through the plain offsets), every candidate through the anchored
+// automaton on its rest characters, pattern ids are resolved as the kernel does (inline entry j -> ent[off[key] + j]).
+// Result = (minimum distance, set of pattern ids at it); must equal the plain DP over all patterns.
+struct PatPlanes {
+    uint32_t x, y;
+};
+template <int E>
+static bool emulate_filter(const SctSeedTables &T, const std::vector<std::vector<int>> &pats, int bl, const std::vector<int> &t,
+                           bool use_slots) {
+    const int L = (int)t.size();
+    uint64_t tlo, thi;
+    planes(t, tlo, thi);
+    EmArray<uint32_t> em;
+    const uint32_t va = sct_valid_mask<uint32_t>(L), ve = va & ~1u, l1 = (uint32_t)tlo << 1, h1 = (uint32_t)thi << 1;
+    em.m[0] = ~l1 & ~h1 & ve; em.m[1] = l1 & ~h1 & ve; em.m[2] = ~l1 & h1 & ve; em.m[3] = l1 & h1 & ve;
+    int best = E + 1;
+    std::set<uint32_t> hits;
+    auto add = [&](int d, uint32_t pid) {
+        if (d > E) return;
+        if (d < best) { best = d; hits.clear(); }
+        if (d == best) hits.insert(pid);
+    };
+    const int nf = E == 0 ? 1 : E == 1 ? 2 : 6;
+    for (int f = 0; f < nf; f++) {
+        const SctFamilyRT fam = sct_family_rt(f, bl);
+        const uint32_t *off = T.off.data() + T.off_base[f];
+        sct_for_each_placement_of(fam, L, [&](int a, int b) {
+            const uint32_t key = sct_key_of<uint32_t>(fam, (uint32_t)tlo, (uint32_t)thi, a, b);
+            if (use_slots) {
+                const uint64_t v = T.slot[T.off_base[f] + key];
+                const uint32_t sa = (uint32_t)v, sb = (uint32_t)(v >> 32), mid = sct_slot_mid(sa, sb), top = sct_slot_top(sb);
+                if (sct_slot_is_inline(sa)) {
+                    const uint32_t q[3] = {mid, sct_slot_next(mid, top), top};
+                    for (uint32_t j = 0; j < sct_slot_inline_count(sa); j++)
+                        add(wm_anchored_rest<E, uint32_t>(fam, em, va, q[j], a, b), T.ent[off[key] + j]);
+                } else {
+                    for (uint32_t k = 0; k < sct_slot_long_count(sa, top); k++)
+                        add(wm_anchored_rest<E, uint32_t>(fam, em, va, sct_rest_of(fam, T.code[mid + k]), a, b), T.ent[mid + k]);
+                }
+            } else {
+                for (uint32_t gk = off[key]; gk < off[key + 1]; gk++)
+                    add(wm_anchored_of<E, uint32_t>(fam, em, va, T.code[gk], a, b), T.ent[gk]);
+            }
+        });
+    }
+    int want = E + 1;
+    std::set<uint32_t> want_hits;
+    for (size_t p = 0; p < pats.size(); p++) {
+        const int d = brute_infix(pats[p], t);
+        if (d > E) continue;
+        if (d < want) { want = d; want_hits.clear(); }
+        if (d == want) want_hits.insert((uint32_t)p);
+    }
+    (void)bl;
+    return want == best && want_hits == hits;
+}
+
 int main() {
     std::mt19937_64 rng(12345);
     auto rnd = [&](int n) { return (int)(rng() % (uint64_t)n); };
@@ -279,6 +340,61 @@ int main() {
         ok = ok && !sct_slot_is_inline(wa) && sct_slot_mid(wa, wb) == first && sct_slot_long_count(wa, sct_slot_top(wb)) == len;
         if (!ok) { printf("FAIL slot n=%u\n", n); return 1; }
         checked++;
+    }
+    // 1d. the whole filter path on the host over tables built by sct_build_tables: pattern sets with shared seed
+    //     pieces (buckets of 1..8 entries, i.e. inline and long ones), exact duplicates, every barcode length 8..16
+    for (int it = 0; it < 260; it++) {
+        const int bl = it % 3 == 0 ? 8 + rnd(9) : 16;
+        const int groups = 1 + rnd(24);
+        std::vector<std::vector<int>> pats;
+        for (int g = 0; g < groups; g++) {
+            std::vector<int> base(bl);
+            for (auto &x : base) x = rnd(4);
+            const int members = 1 + rnd(8);
+            for (int m = 0; m < members; m++) {
+                std::vector<int> p = base;
+                const int keep = rnd(3);  // which part stays shared: the first half, the second half, or everything but one character
+                for (int j = 0; j < bl; j++)
+                    if ((keep == 0 && j >= bl / 2) || (keep == 1 && j < bl / 2)) p[j] = rnd(4);
+                if (keep == 2 && m > 0) p[rnd(bl)] = rnd(4);
+                pats.push_back(p);
+            }
+        }
+        if (pats.size() > 2) pats.push_back(pats[rnd((int)pats.size())]);  // an exact duplicate: two ids, one sequence
+        std::vector<PatPlanes> pp(pats.size());
+        for (size_t p = 0; p < pats.size(); p++) {
+            uint64_t lo, hi;
+            planes(pats[p], lo, hi);
+            pp[p] = {(uint32_t)lo, (uint32_t)hi};
+        }
+        SctSeedTables T;
+        if (!sct_build_tables(pp.data(), (int)pp.size(), bl, false, T)) { printf("FAIL build\n"); return 1; }
+        for (int k = 0; k < 30; k++) {
+            std::vector<int> t;
+            const int n = rnd(32);
+            if (rnd(5)) {
+                const std::vector<int> &p = pats[rnd((int)pats.size())];
+                t = p;
+                for (int e = rnd(4); e > 0; e--) {
+                    const int op = rnd(3), pos = t.empty() ? 0 : rnd((int)t.size());
+                    if (op == 0 && !t.empty()) t[pos] = rnd(4);
+                    else if (op == 1) t.insert(t.begin() + pos, rnd(4));
+                    else if (!t.empty()) t.erase(t.begin() + pos);
+                }
+                for (int l = rnd(6); l > 0; l--) t.insert(t.begin(), rnd(4));
+                for (int r = rnd(6); r > 0; r--) t.push_back(rnd(4));
+                if ((int)t.size() > 31) t.resize(31);
+            } else {
+                t.resize(n);
+                for (auto &x : t) x = rnd(4);
+            }
+            for (int sl = 0; sl < 2; sl++) {
+                const bool ok = emulate_filter<0>(T, pats, bl, t, sl) && emulate_filter<1>(T, pats, bl, t, sl) &&
+                                emulate_filter<2>(T, pats, bl, t, sl);
+                if (!ok) { printf("FAIL filter emulation bl=%d patterns=%zu slots=%d\n", bl, pats.size(), sl); return 1; }
+            }
+            checked++;
+        }
     }
     // 2. transposed Wu-Manber + seed completeness, bl = 16, texts 0..31, planted copies with 0..3 edits
     for (int it = 0; it < 300000; it++) {
