@@ -377,6 +377,91 @@ SCT_HD int wm_anchored(EmFetch &&em, W va, uint32_t code, int t, int t2) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same anchored verification for TWO candidates at once, one in each 16-bit half of the state words (X in
+// bits 0..15, Y in bits 16..31).  A run of the automaton only ever needs a window of the text: the left run must
+// arrive exactly at t, so only the positions t - PA - E .. t matter; after an anchor the states sit at the first
+// position behind the piece and move up by at most (run length + E) <= 10.  Each run therefore works on the 16
+// positions from its own base (per candidate), the match masks are shifted down by that base, and the anchor
+// re-bases the states.  Bitwise operations act on both halves at once; only the shifts are per half.
+// Texts of at most 31 characters (32-bit masks); same result as wm_anchored_rest for each candidate.
+// ---------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned short sct_us2 __attribute__((ext_vector_type(2)));
+SCT_HD uint32_t sct_pk_shl1(uint32_t x) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(sct_us2, x) << (sct_us2)(1)); }
+SCT_HD uint32_t sct_pk_shr(uint32_t x, uint32_t sh) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(sct_us2, x) >> __builtin_bit_cast(sct_us2, sh));
+}
+#else
+SCT_HD uint32_t sct_pk_shl1(uint32_t x) { return (x << 1) & 0xFFFEFFFEu; }
+SCT_HD uint32_t sct_pk_shr(uint32_t x, uint32_t sh) { return ((x & 0xFFFFu) >> (sh & 0xFFFFu)) | (((x >> 16) >> (sh >> 16)) << 16); }
+#endif
+SCT_HD uint32_t sct_pk(uint32_t lo, uint32_t hi) { return (lo & 0xFFFFu) | (hi << 16); }
+
+template <int E>
+struct WmPair {
+    uint32_t R0, R1, R2;
+    SCT_HDM void step(uint32_t Em) {
+        const uint32_t s0 = sct_pk_shl1(R0);
+        const uint32_t n0 = s0 & Em;
+        if (E >= 1) {
+            const uint32_t s1 = sct_pk_shl1(R1);
+            const uint32_t n1 = (s1 & Em) | s0 | R0 | sct_pk_shl1(n0);
+            if (E >= 2) {
+                const uint32_t s2 = sct_pk_shl1(R2);
+                R2 = (s2 & Em) | s1 | R1 | sct_pk_shl1(n1);
+            }
+            R1 = n1;
+        }
+        R0 = n0;
+    }
+    // keep the states that sit exactly `at` positions above the window base (per half), and make that position plus
+    // the skipped piece the new base; text characters inserted right behind the piece: closure under insertion
+    SCT_HDM void anchor(uint32_t at) {
+        const uint32_t one = 0x00010001u;
+        R0 = sct_pk_shr(R0, at) & one;
+        if (E >= 1) R1 = (sct_pk_shr(R1, at) & one) | (R0 << 1);
+        if (E >= 2) R2 = (sct_pk_shr(R2, at) & one) | (R1 << 1);
+    }
+    SCT_HDM uint32_t result(uint32_t m) const {  // d of X | d of Y << 16
+        const uint32_t a0 = R0 & m, a1 = E >= 1 ? (R1 & m) : 0u, a2 = E >= 2 ? (R2 & m) : 0u;
+        const uint32_t dx = (a0 & 0xFFFFu) ? 0u : (a1 & 0xFFFFu) ? 1u : (a2 & 0xFFFFu) ? 2u : (uint32_t)(E + 1);
+        const uint32_t dy = (a0 >> 16) ? 0u : (a1 >> 16) ? 1u : (a2 >> 16) ? 2u : (uint32_t)(E + 1);
+        return dx | (dy << 16);
+    }
+};
+
+template <int E, typename Fam, typename EmX, typename EmY>
+SCT_HD uint32_t wm_anchored_pair(const Fam &fam, EmX &&emx, EmY &&emy, uint32_t vax, uint32_t vay, uint32_t restx, uint32_t resty,
+                                 int tx, int t2x, int ty, int t2y) {
+    WmPair<E> s;
+    int bx, by;
+    if (fam.PA > 0) {  // left run: free start, must arrive exactly at t
+        bx = tx - fam.PA - E > 0 ? tx - fam.PA - E : 0;
+        by = ty - fam.PA - E > 0 ? ty - fam.PA - E : 0;
+        s.R0 = s.R1 = s.R2 = sct_pk(vax >> bx, vay >> by);
+        for (int j = 0; j < fam.PA; j++, restx >>= 2, resty >>= 2) s.step(sct_pk(emx(restx & 3u) >> bx, emy(resty & 3u) >> by));
+        s.anchor(sct_pk((uint32_t)(tx - bx), (uint32_t)(ty - by)));
+    } else {
+        s.R0 = 0x00010001u;
+        s.R1 = 0x00030003u;
+        s.R2 = 0x00070007u;
+    }
+    const int skip1 = fam.ADJ ? fam.LA + fam.LB : fam.LA;
+    bx = tx + skip1;
+    by = ty + skip1;
+    if (!fam.ADJ) {  // middle run: from behind piece A exactly to t2
+        for (int j = fam.PA + fam.LA; j < fam.PB; j++, restx >>= 2, resty >>= 2)
+            s.step(sct_pk(emx(restx & 3u) >> bx, emy(resty & 3u) >> by));
+        s.anchor(sct_pk((uint32_t)(t2x - bx), (uint32_t)(t2y - by)));
+        bx = t2x + fam.LB;
+        by = t2y + fam.LB;
+    }
+    for (int j = fam.PB + fam.LB; j < fam.BL; j++, restx >>= 2, resty >>= 2)  // right run: free end
+        s.step(sct_pk(emx(restx & 3u) >> bx, emy(resty & 3u) >> by));
+    return s.result(sct_pk(vax >> bx, vay >> by));
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Bucket slots of the quarter families (k_filter.hip.h): one 8-byte word per seed key, read as two 32-bit words
 // (a = bits 0..31, b = bits 32..63), that answers most lookups by itself.
 //   bit 15 clear  inline bucket: bits 0..1 = n <= 3 entries, bits 16(j+1) .. 16(j+1)+15 = rest characters of entry j

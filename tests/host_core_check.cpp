@@ -341,6 +341,89 @@ int main() {
         if (!ok) { printf("FAIL slot n=%u\n", n); return 1; }
         checked++;
     }
+    // 1e. two candidates per word in 16-bit windows == the full-width anchored automaton, every family and length
+    for (int it = 0; it < 60000; it++) {
+        const int bl = it % 2 ? 16 : 8 + rnd(9);
+        const int f = rnd(6);
+        const SctFamilyRT fam = sct_family_rt(f, bl);
+        EmArray<uint32_t> em[2];
+        uint32_t va[2], rest[2];
+        int tt[2], tt2[2];
+        bool have = true;
+        for (int h = 0; h < 2; h++) {
+            const int L = rnd(32), alpha = 1 + rnd(4);
+            std::vector<int> t(L);
+            for (auto &x : t) x = rnd(alpha);
+            uint64_t tlo, thi;
+            planes(t, tlo, thi);
+            va[h] = sct_valid_mask<uint32_t>(L);
+            const uint32_t ve = va[h] & ~1u, l1 = (uint32_t)tlo << 1, h1 = (uint32_t)thi << 1;
+            em[h].m[0] = ~l1 & ~h1 & ve; em[h].m[1] = l1 & ~h1 & ve; em[h].m[2] = ~l1 & h1 & ve; em[h].m[3] = l1 & h1 & ve;
+            rest[h] = alpha == 1 ? 0u : (uint32_t)rng() & (rnd(2) ? 0xFFFFu : 0x5555u * (uint32_t)rnd(4));
+            std::vector<std::pair<int, int>> pl;
+            sct_for_each_placement_of(fam, L, [&](int a, int b) { pl.push_back({a, b}); });
+            if (pl.empty()) { have = false; break; }
+            const auto ab = pl[rnd((int)pl.size())];
+            tt[h] = ab.first;
+            tt2[h] = ab.second;
+        }
+        if (!have) continue;
+        bool ok = true;
+        {
+            const uint32_t r = wm_anchored_pair<0>(fam, em[0], em[1], va[0], va[1], rest[0], rest[1], tt[0], tt2[0], tt[1], tt2[1]);
+            ok = ok && (int)(r & 0xFFFFu) == wm_anchored_rest<0, uint32_t>(fam, em[0], va[0], rest[0], tt[0], tt2[0]) &&
+                 (int)(r >> 16) == wm_anchored_rest<0, uint32_t>(fam, em[1], va[1], rest[1], tt[1], tt2[1]);
+        }
+        {
+            const uint32_t r = wm_anchored_pair<1>(fam, em[0], em[1], va[0], va[1], rest[0], rest[1], tt[0], tt2[0], tt[1], tt2[1]);
+            ok = ok && (int)(r & 0xFFFFu) == wm_anchored_rest<1, uint32_t>(fam, em[0], va[0], rest[0], tt[0], tt2[0]) &&
+                 (int)(r >> 16) == wm_anchored_rest<1, uint32_t>(fam, em[1], va[1], rest[1], tt[1], tt2[1]);
+        }
+        {
+            const uint32_t r = wm_anchored_pair<2>(fam, em[0], em[1], va[0], va[1], rest[0], rest[1], tt[0], tt2[0], tt[1], tt2[1]);
+            ok = ok && (int)(r & 0xFFFFu) == wm_anchored_rest<2, uint32_t>(fam, em[0], va[0], rest[0], tt[0], tt2[0]) &&
+                 (int)(r >> 16) == wm_anchored_rest<2, uint32_t>(fam, em[1], va[1], rest[1], tt[1], tt2[1]);
+        }
+        if (!ok) { printf("FAIL pair bl=%d f=%d t=(%d,%d) (%d,%d)\n", bl, f, tt[0], tt2[0], tt[1], tt2[1]); return 1; }
+        checked++;
+    }
+    //     ... and on planted copies (small distances are the common case there): every placement of the text
+    for (int it = 0; it < 20000; it++) {
+        const int bl = it % 2 ? 16 : 8 + rnd(9);
+        std::vector<int> p(bl);
+        for (auto &x : p) x = rnd(4);
+        std::vector<int> t = p;
+        for (int e = rnd(4); e > 0; e--) {
+            const int op = rnd(3), pos = t.empty() ? 0 : rnd((int)t.size());
+            if (op == 0 && !t.empty()) t[pos] = rnd(4);
+            else if (op == 1) t.insert(t.begin() + pos, rnd(4));
+            else if (!t.empty()) t.erase(t.begin() + pos);
+        }
+        for (int l = rnd(7); l > 0; l--) t.insert(t.begin(), rnd(4));
+        for (int r = rnd(7); r > 0; r--) t.push_back(rnd(4));
+        if ((int)t.size() > 31) t.resize(31);
+        const int L = (int)t.size();
+        uint64_t tlo, thi;
+        planes(t, tlo, thi);
+        EmArray<uint32_t> em;
+        const uint32_t va = sct_valid_mask<uint32_t>(L), ve = va & ~1u, l1 = (uint32_t)tlo << 1, h1 = (uint32_t)thi << 1;
+        em.m[0] = ~l1 & ~h1 & ve; em.m[1] = l1 & ~h1 & ve; em.m[2] = ~l1 & h1 & ve; em.m[3] = l1 & h1 & ve;
+        uint32_t code = 0;
+        for (int j = 0; j < bl; j++) code |= (uint32_t)p[j] << (2 * j);
+        for (int f = 0; f < 6; f++) {
+            const SctFamilyRT fam = sct_family_rt(f, bl);
+            const uint32_t rest = sct_rest_of(fam, code);
+            std::vector<std::pair<int, int>> pl;
+            sct_for_each_placement_of(fam, L, [&](int a, int b) { pl.push_back({a, b}); });
+            for (size_t i = 0; i + 1 < pl.size(); i += 2) {
+                const uint32_t r = wm_anchored_pair<2>(fam, em, em, va, va, rest, rest, pl[i].first, pl[i].second, pl[i + 1].first, pl[i + 1].second);
+                const int d0 = wm_anchored_rest<2, uint32_t>(fam, em, va, rest, pl[i].first, pl[i].second);
+                const int d1 = wm_anchored_rest<2, uint32_t>(fam, em, va, rest, pl[i + 1].first, pl[i + 1].second);
+                if ((int)(r & 0xFFFFu) != d0 || (int)(r >> 16) != d1) { printf("FAIL pair (planted) bl=%d f=%d\n", bl, f); return 1; }
+                checked++;
+            }
+        }
+    }
     // 1d. the whole filter path on the host over tables built by sct_build_tables: pattern sets with shared seed
     //     pieces (buckets of 1..8 entries, i.e. inline and long ones), exact duplicates, every barcode length 8..16
     for (int it = 0; it < 260; it++) {
