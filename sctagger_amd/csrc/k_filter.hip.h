@@ -252,6 +252,56 @@ struct FilterWave {
     W lo, hi;
     uint32_t head = 0, tail = 0;  // wave-uniform
 
+    // PK (bucket slots, texts of at most 31 characters): the queue holds ONE word per candidate and a lane verifies TWO
+    // candidates at once, one in each 16-bit half of the automaton's words (wm_anchored_pair, sct_core.h), 128 per
+    // batch.  Entry = rest characters | segment lane << 16 | t << 22 | (t2 - t - GAP + SLACK) << 27 | j << 30, j = the
+    // entry's position in its inline bucket, j = 3: an entry of a long bucket (its rest was read from the code table
+    // when it was queued).  No table is read while a batch is verified; the ring runs over qk and qm.
+    static constexpr bool PK = SL && sizeof(W) == 4;
+    static constexpr uint32_t RING = 2u * (uint32_t)QCAP;
+    __device__ __forceinline__ uint32_t *ring() { return &L.qk[0]; }
+
+    template <typename Fam>
+    __device__ __forceinline__ void record(const Fam &fam, uint32_t e, uint32_t d) {
+        const uint32_t src = (e >> 16) & 63u, j = e >> 30;
+        const int t = (int)((e >> 22) & 31u), t2 = t + fam.GAP + (int)((e >> 27) & 7u) - fam.SLACK;
+        const uint32_t oi = ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.lo[src], L.hi[src], t, t2);
+        atomicMin(&L.best[src], d);
+        if (j < 3u) {
+            const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
+            if (k < HMAX) L.hlist[k][src] = (d << 30) | LOC_INLINE | (oi << 2) | j;
+        } else {
+            // an entry of a long bucket: every entry of the bucket with these rest characters is this barcode
+            // sequence (duplicates are distinct ids and all of them hits; each is also queued itself, the ids are
+            // deduplicated when the segment is finished)
+            const uint32_t s = tab_off[oi], en = tab_off[oi + 1];
+            for (uint32_t g = s; g < en; g++) {
+                if (((sct_rest_of(fam, tab_code[g]) ^ e) & 0xFFFFu) != 0u) continue;
+                const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
+                if (k < HMAX) L.hlist[k][src] = (d << 30) | g;
+            }
+        }
+    }
+
+    template <typename Fam>
+    __device__ __forceinline__ void verify2(const Fam &fam, uint32_t nq) {  // the nq <= 128 entries from head
+        using Lds = FilterWaveLds<W, HM, QCAP>;
+        static_assert(__builtin_offsetof(Lds, qm) == __builtin_offsetof(Lds, qk) + 4 * QCAP && __builtin_offsetof(Lds, qk) % 8 == 0,
+                      "the ring runs over qk and qm");
+        const uint2 pr = *reinterpret_cast<const uint2 *>(&ring()[(head + 2u * (uint32_t)lane) & (RING - 1)]);
+        const bool vx = 2u * (uint32_t)lane < nq, vy = 2u * (uint32_t)lane + 1u < nq;
+        const uint32_t ex = vx ? pr.x : 0u, ey = vy ? pr.y : 0u;
+        const uint32_t sx = (ex >> 16) & 63u, sy = (ey >> 16) & 63u;
+        const int tx = (int)((ex >> 22) & 31u), ty = (int)((ey >> 22) & 31u);
+        const int t2x = tx + fam.GAP + (int)((ex >> 27) & 7u) - fam.SLACK, t2y = ty + fam.GAP + (int)((ey >> 27) & 7u) - fam.SLACK;
+        const uint32_t r = wm_anchored_pair<E>(fam, EmLds<W>(&L.em[sx][0]), EmLds<W>(&L.em[sy][0]), (uint32_t)L.va[sx],
+                                               (uint32_t)L.va[sy], ex, ey, tx, t2x, ty, t2y);
+        const uint32_t dx = r & 0xFFFFu, dy = r >> 16;
+        if (vx && dx <= (uint32_t)E) record(fam, ex, dx);
+        if (vy && dy <= (uint32_t)E) record(fam, ey, dy);
+        __builtin_amdgcn_wave_barrier();
+    }
+
     template <typename Fam>
     __device__ __forceinline__ void verify(const Fam &fam, bool take) {
         if (take) {
@@ -309,7 +359,45 @@ struct FilterWave {
     //   !SL: the bucket's first and end entry index; one entry per lane and pass.
     template <typename Fam>
     __device__ __forceinline__ void push_range(const Fam &fam, uint32_t a, uint32_t b, uint32_t meta) {
-        if constexpr (SL) {
+        if constexpr (PK) {
+            // one-word entries (meta = segment lane << 16 | t << 22 | placement << 27); batches of 128
+            const bool inl = sct_slot_is_inline(a);
+            const uint32_t c = inl ? sct_slot_inline_count(a) : 0u;
+            const uint64_t m0 = __ballot((c & 1u) != 0u), m1 = __ballot((c & 2u) != 0u);
+            const uint32_t A = sct_slot_mid(a, b), B = sct_slot_top(b);
+            if ((m0 | m1) != 0) {
+                const uint32_t pos = tail + lane_rank(m0) + 2u * lane_rank(m1);
+                if (c >= 1u) ring()[pos & (RING - 1)] = (A & 0xFFFFu) | meta;
+                if (c >= 2u) ring()[(pos + 1u) & (RING - 1)] = (A >> 16) | meta | (1u << 30);
+                if (c >= 3u) ring()[(pos + 2u) & (RING - 1)] = B | meta | (2u << 30);
+                tail += (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1);
+                __builtin_amdgcn_wave_barrier();
+                while (tail - head >= 128u) {
+                    verify2(fam, 128u);
+                    head += 128u;
+                }
+            }
+            uint64_t om = __ballot(!inl);
+            while (om != 0) {  // a long bucket, spread over the lanes: lane i reads the code of entry first + i
+                const int src = __builtin_ctzll(om);
+                om &= om - 1;
+                const uint32_t first = __builtin_amdgcn_readlane(A, src);
+                const uint32_t n = sct_slot_long_count(__builtin_amdgcn_readlane(a, src), __builtin_amdgcn_readlane(B, src));
+                const uint32_t hdr = __builtin_amdgcn_readlane(meta, src) | (3u << 30);
+                for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+                    const uint32_t take = n - k0 < 64u ? n - k0 : 64u;
+                    if ((uint32_t)lane < take)
+                        ring()[(tail + (uint32_t)lane) & (RING - 1)] =
+                            (sct_rest_of(fam, tab_code[first + k0 + (uint32_t)lane]) & 0xFFFFu) | hdr;
+                    tail += take;
+                    __builtin_amdgcn_wave_barrier();
+                    while (tail - head >= 128u) {
+                        verify2(fam, 128u);
+                        head += 128u;
+                    }
+                }
+            }
+        } else if constexpr (SL) {
             const bool inl = sct_slot_is_inline(a);
             const uint32_t c = inl ? sct_slot_inline_count(a) : 0u;
             const uint64_t m0 = __ballot((c & 1u) != 0u), m1 = __ballot((c & 2u) != 0u);
@@ -438,7 +526,8 @@ struct FilterWave {
                 const uint2 sv = slot[ok ? key : (uint32_t)fam.NKEYS];
                 s = sv.x;
                 e = sv.y;
-                meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
+                if constexpr (PK) meta = (sl << 16) | ((uint32_t)t << 22) | ((uint32_t)(t2 - t - fam.GAP + fam.SLACK) << 27);
+                else meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
 #ifdef SCT_ABLATE_PUSH  // timing-only build: the slot is loaded but nothing is queued
                 asm volatile("" ::"v"(s), "v"(e), "v"(meta));
                 s = e = 0;
@@ -473,7 +562,10 @@ struct FilterWave {
             pmeta = meta;
         }
         if (pend) push_range(fam, ps, pe, pmeta);
-        if (tail != head) {  // the family's last, partial batch
+        if constexpr (PK) {
+            if (tail != head) verify2(fam, tail - head);  // the family's last, partial batch
+            head = tail = 0;                              // pairs stay 8-byte aligned in the ring
+        } else if (tail != head) {
             verify(fam, (uint32_t)lane < tail - head);
             head = tail;
         }
