@@ -176,7 +176,9 @@ struct QueueCap {
     static constexpr int value = (SL || HM <= 16) ? 256 : 128;
 };
 #ifndef SCT_HMAX
-#define SCT_HMAX 8  // with the tiers a settled segment stops early, so few rows collect more than 8 verified matches
+#define SCT_HMAX 6  // with the tiers a settled segment stops early, so few rows collect more than 6 verified matches;
+                    // 6 x 256 B keeps a block's LDS at 24.5 KB = six blocks per CU for real (27 KB, the size with 8, is
+                    // rounded up by the allocation granule and fits only five: 3.52 vs 3.39 ms)
 #endif
 static constexpr int HMAX = SCT_HMAX;  // main launch
 static constexpr int K_RETRY = 32, H_RETRY = 64;  // retry launch
