@@ -175,12 +175,12 @@ template <bool SL, int HM>
 struct QueueCap {
     static constexpr int value = (SL || HM <= 16) ? 256 : 128;
 };
-#ifndef SCT_HMAX
-#define SCT_HMAX 6  // with the tiers a settled segment stops early, so few rows collect more than 6 verified matches;
-                    // 6 x 256 B keeps a block's LDS at 24.5 KB = six blocks per CU for real (27 KB, the size with 8, is
-                    // rounded up by the allocation granule and fits only five: 3.52 vs 3.39 ms)
-#endif
-static constexpr int HMAX = SCT_HMAX;  // main launch
+// Verified matches kept per segment by the main launch before the row is handed to the retry launch.  With the tiers a
+// settled segment stops early, so few rows collect more.  With bucket slots (small barcode sets) 6 keep a block's LDS at
+// 24.5 KB = six blocks per CU for real (27 KB, the size with 8, is rounded up by the allocation granule and fits only five:
+// 3.52 vs 3.39 ms at 25 k barcodes, 0.09 % of the rows retried); larger sets have more ties and keep 8 (400 k barcodes:
+// 24 % instead of 16 % of the rows retried with 6).
+static constexpr int HMAX = 8, HMAX_SL = 6;  // main launch
 static constexpr int K_RETRY = 32, H_RETRY = 64;  // retry launch
 static constexpr int H_RETRY_SL = 60;              // with bucket slots (larger queue): still two blocks of 80 KB per CU
 static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
