@@ -199,7 +199,9 @@ struct FilterWaveLds {
     static constexpr int HMAX = HM;
     alignas(32) W em[64][4];  // em[lane][c]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
     W va[64];            // bits 0..len
-    W lo[64], hi[64];    // the segments' bit-planes (lookup lanes read the planes of the segment they work for)
+    struct Planes {
+        W lo, hi;
+    } pl[64];            // the segments' bit-planes (lookup lanes read the planes of the segment they work for)
     uint8_t slen[64];    // and lengths
     uint8_t alist[64];   // lanes whose segment still generates candidates, compacted
     uint16_t ptab[sizeof(W) == 4 ? 128 : 320];  // this family's placements for the longest segment: t | t2 << 8
@@ -267,7 +269,7 @@ struct FilterWave {
     __device__ __forceinline__ void record(const Fam &fam, uint32_t e, uint32_t d) {
         const uint32_t src = (e >> 16) & 63u, j = e >> 30;
         const int t = (int)((e >> 22) & 31u), t2 = t + fam.GAP + (int)((e >> 27) & 7u) - fam.SLACK;
-        const uint32_t oi = ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.lo[src], L.hi[src], t, t2);
+        const uint32_t oi = ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[src].lo, L.pl[src].hi, t, t2);
         atomicMin(&L.best[src], d);
         if (j < 3u) {
             const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
@@ -329,7 +331,7 @@ struct FilterWave {
                 // what is kept is the entry's LOCATOR; the pattern ids are read once, when the segment is finished
                 // (resolve), so that no table read sits between two batches
                 if (inl)
-                    gk = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.lo[src], L.hi[src], t, t2)) << 2) |
+                    gk = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[src].lo, L.pl[src].hi, t, t2)) << 2) |
                          ((meta >> 24) & 3u);
                 atomicMin(&L.best[src], (uint32_t)d);
                 const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
@@ -476,9 +478,9 @@ struct FilterWave {
     }
 
     // One family.  The lookups are spread over the lanes as (active segment, placement) PAIRS: with A segments of
-    // the wave still generating candidates, G = 64 / A placements are looked up per pass (lane = g * A + a works on
-    // placement p0 + g for the a-th active segment), so the wave-uniform cost of a pass is shared by 64 lookups
-    // even when most segments have settled.  The placements of the family for the longest segment of the wave are
+    // the wave still generating candidates and P placements, the A * P pairs are numbered placement-major and every
+    // pass takes the next 64 of them, so the wave-uniform cost of a pass is shared by 64 lookups even when most
+    // segments have settled (a lane works for a different segment in every pass and reads its planes from LDS).  The placements of the family for the longest segment of the wave are
     // tabulated in LDS once; a lane skips those its own segment is too short for.  The bucket range of a pass is
     // queued while the loads of the next pass are in flight.
     template <typename Fam>
@@ -499,25 +501,20 @@ struct FilterWave {
         }
         __builtin_amdgcn_wave_barrier();
         if (P == 0) return;
-        const int G = 64 / A;
+        // pair q = 64 * pass + lane: placement q / A of the (q mod A)-th active segment; advancing q by 64 moves the
+        // lane dp placements on and da segments further (with a carry)
         const uint32_t inv = 65536u / (uint32_t)A + 1u;           // lane / A for lane < 64 (checked for every A <= 64)
-        const int g = (int)(((uint32_t)lane * inv) >> 16), a = lane - g * A;
-        const bool worker = g < G;
-        uint32_t sl = 0;
-        W slo = 0, shi = 0;
-        int slen = 0;
-        if (worker) {
-            sl = L.alist[a];
-            slo = L.lo[sl];
-            shi = L.hi[sl];
-            slen = (int)L.slen[sl];
-        }
+        int p = (int)(((uint32_t)lane * inv) >> 16), a = lane - p * A;
+        const int dp = 64 / A, da = 64 - dp * A;
         const uint32_t *off = tab_off + ft.off_base[fam.INDEX];
         const uint2 *slot = tab_slot + ft.off_base[fam.INDEX];
         uint32_t ps = 0, pe = 0, pmeta = 0;  // the pass whose loads were issued last
         bool pend = false;
-        for (int p0 = 0; p0 < P; p0 += G) {
-            const int p = p0 + g;
+        for (int q0 = 0; q0 < A * P; q0 += 64) {
+            const uint32_t sl = L.alist[a];
+            const W slo = L.pl[sl].lo, shi = L.pl[sl].hi;
+            const int slen = (int)L.slen[sl];
+            const bool worker = true;
             uint32_t s = 0, e = 0, meta = 0;
             if constexpr (SL) {
                 // branch-free: a lane without a lookup of its own reads the spare all-zero slot behind the family's keys
@@ -556,6 +553,12 @@ struct FilterWave {
                     s = e = 0;
 #endif
                 }
+            }
+            a += da;
+            p += dp;
+            if (a >= A) {
+                a -= A;
+                p++;
             }
             if (pend) push_range(fam, ps, pe, pmeta);
             pend = true;
@@ -631,8 +634,8 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.em[lane][2] = ~l1 & h1 & ve;
     L.em[lane][3] = l1 & h1 & ve;
     L.va[lane] = va;
-    L.lo[lane] = lo;
-    L.hi[lane] = hi;
+    L.pl[lane].lo = lo;
+    L.pl[lane].hi = hi;
     L.slen[lane] = (uint8_t)len;
     L.best[lane] = E + 1;
     L.hcnt[lane] = 0;
