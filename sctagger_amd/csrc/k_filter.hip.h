@@ -501,20 +501,32 @@ struct FilterWave {
         }
         __builtin_amdgcn_wave_barrier();
         if (P == 0) return;
-        // pair q = 64 * pass + lane: placement q / A of the (q mod A)-th active segment; advancing q by 64 moves the
-        // lane dp placements on and da segments further (with a carry)
+        // SL:  pair q = 64 * pass + lane is placement q / A of the (q mod A)-th active segment; advancing q by 64 moves
+        //      the lane dp placements on and da segments further (with a carry): every pass takes 64 pairs
+        // !SL: lane = g * A + a works for the a-th active segment throughout, on placement dp * pass + g (dp = 64 / A);
+        //      lanes beyond dp * A idle.  (With seed tables far beyond the L2 the fuller passes of the first scheme
+        //      cost more than they save: 10.5 vs 8.4 ms at 1 M barcodes.)
         const uint32_t inv = 65536u / (uint32_t)A + 1u;           // lane / A for lane < 64 (checked for every A <= 64)
         int p = (int)(((uint32_t)lane * inv) >> 16), a = lane - p * A;
         const int dp = 64 / A, da = 64 - dp * A;
+        const bool worker = SL || p < dp;
+        const int passes = SL ? (A * P + 63) / 64 : (P + dp - 1) / dp;
+        uint32_t sl = L.alist[a];
+        W slo = L.pl[sl].lo, shi = L.pl[sl].hi;
+        int slen = (int)L.slen[sl];
         const uint32_t *off = tab_off + ft.off_base[fam.INDEX];
         const uint2 *slot = tab_slot + ft.off_base[fam.INDEX];
         uint32_t ps = 0, pe = 0, pmeta = 0;  // the pass whose loads were issued last
         bool pend = false;
-        for (int q0 = 0; q0 < A * P; q0 += 64) {
-            const uint32_t sl = L.alist[a];
-            const W slo = L.pl[sl].lo, shi = L.pl[sl].hi;
-            const int slen = (int)L.slen[sl];
-            const bool worker = true;
+        for (int pass = 0; pass < passes; pass++) {
+            if constexpr (SL) {
+                if (pass > 0) {
+                    sl = L.alist[a];
+                    slo = L.pl[sl].lo;
+                    shi = L.pl[sl].hi;
+                    slen = (int)L.slen[sl];
+                }
+            }
             uint32_t s = 0, e = 0, meta = 0;
             if constexpr (SL) {
                 // branch-free: a lane without a lookup of its own reads the spare all-zero slot behind the family's keys
@@ -554,11 +566,13 @@ struct FilterWave {
 #endif
                 }
             }
-            a += da;
             p += dp;
-            if (a >= A) {
-                a -= A;
-                p++;
+            if constexpr (SL) {
+                a += da;
+                if (a >= A) {
+                    a -= A;
+                    p++;
+                }
             }
             if (pend) push_range(fam, ps, pe, pmeta);
             pend = true;
