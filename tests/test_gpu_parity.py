@@ -214,6 +214,21 @@ def test_bucket_longer_than_the_slot_length_field(m, e):
     m.set_option("slots", -1)
 
 
+def test_context_reuse_across_table_kinds(m):
+    """One context, barcode sets that make the library pick different seed tables in turn (bucket slots, plain offsets,
+    the thirds scheme at max_err <= 1, slots again): every result equals the exhaustive scan of the same context."""
+    for nbc, e, seed in ((3000, 2, 91), (120_000, 2, 92), (300_000, 1, 93), (300_000, 2, 94), (2000, 1, 95), (3000, 2, 91)):
+        bc = synth.make_barcodes(nbc, seed=seed)
+        segs, offs = synth.make_segments(3000, bc, seed=seed)
+        m.set_barcodes(bc)
+        a = m.match(segs, offs, e, 1)
+        m.set_option("force_exhaustive", 1)
+        b = m.match(segs, offs, e, 1)
+        m.set_option("force_exhaustive", 0)
+        util.assert_same(a, b, "filter vs exhaustive, %d barcodes e<=%d" % (nbc, e))
+        assert m.last_stats()["hits"] > 0
+
+
 def test_empty_and_degenerate_inputs(m):
     bc = synth.make_barcodes(50, seed=7)
     m.set_barcodes(bc)
