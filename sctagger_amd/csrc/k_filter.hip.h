@@ -306,6 +306,37 @@ struct FilterWave {
         __builtin_amdgcn_wave_barrier();
     }
 
+    // Without slots (two-word entries: entry index, lane | t << 8 | t2 << 16) the main launch verifies pairs the same
+    // way, 128 entries per batch; the codes of both candidates are read from the table first.
+    static constexpr bool PKC = !SL && sizeof(W) == 4 && QCAP >= 256;
+    template <typename Fam>
+    __device__ __forceinline__ void verify2c(const Fam &fam, uint32_t nq) {  // the nq <= 128 entries from head
+        if (2u * (uint32_t)lane < nq) {
+            const uint32_t i0 = (head + 2u * (uint32_t)lane) & (QCAP - 1);  // head is even: the pair does not wrap
+            const bool vy = 2u * (uint32_t)lane + 1u < nq;
+            const uint32_t gx = L.qk[i0], mx = L.qm[i0];
+            const uint32_t gy = vy ? L.qk[i0 + 1] : gx, my = vy ? L.qm[i0 + 1] : mx;
+            const uint32_t cx = tab_code[gx], cy = tab_code[gy];
+            const uint32_t sx = mx & 63u, sy = my & 63u;
+            const int tx = (int)((mx >> 8) & 63u), t2x = (int)((mx >> 16) & 63u);
+            const int ty = (int)((my >> 8) & 63u), t2y = (int)((my >> 16) & 63u);
+            const uint32_t r = wm_anchored_pair<E>(fam, EmLds<W>(&L.em[sx][0]), EmLds<W>(&L.em[sy][0]), (uint32_t)L.va[sx],
+                                                   (uint32_t)L.va[sy], sct_rest_of(fam, cx), sct_rest_of(fam, cy), tx, t2x, ty, t2y);
+            const uint32_t dx = r & 0xFFFFu, dy = r >> 16;
+            if (dx <= (uint32_t)E) {
+                atomicMin(&L.best[sx], dx);
+                const uint32_t k = atomicAdd(&L.hcnt[sx], 1u);
+                if (k < HMAX) L.hlist[k][sx] = (dx << 30) | gx;
+            }
+            if (vy && dy <= (uint32_t)E) {
+                atomicMin(&L.best[sy], dy);
+                const uint32_t k = atomicAdd(&L.hcnt[sy], 1u);
+                if (k < HMAX) L.hlist[k][sy] = (dy << 30) | gy;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
     template <typename Fam>
     __device__ __forceinline__ void verify(const Fam &fam, bool take) {
         if (take) {
@@ -469,7 +500,12 @@ struct FilterWave {
                 }
                 tail += (uint32_t)__popcll(m);
                 __builtin_amdgcn_wave_barrier();
-                if (tail - head >= 64) {
+                if constexpr (PKC) {
+                    if (tail - head >= 128u) {
+                        verify2c(fam, 128u);
+                        head += 128u;
+                    }
+                } else if (tail - head >= 64) {
                     verify(fam, true);
                     head += 64;
                 }
@@ -584,6 +620,9 @@ struct FilterWave {
         if constexpr (PK) {
             if (tail != head) verify2(fam, tail - head);  // the family's last, partial batch
             head = tail = 0;                              // pairs stay 8-byte aligned in the ring
+        } else if constexpr (PKC) {
+            if (tail != head) verify2c(fam, tail - head);
+            head = tail = 0;
         } else if (tail != head) {
             verify(fam, (uint32_t)lane < tail - head);
             head = tail;
