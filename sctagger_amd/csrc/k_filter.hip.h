@@ -167,13 +167,11 @@ k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ h
 // All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
 // needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
 // ------------------------------------------------------------------------------------------------------------
-// queue capacity: >= 63 left over + what one pass appends — 64 lanes x 3 inline slot entries, or one entry per lane.
-// The retry launch (long hit lists) takes the small queue where it can, to keep two 80 KB blocks per CU; the main
-// launch keeps 256 either way: its LDS footprint then allows 6 blocks per CU, and with seed tables far beyond the L2
-// a seventh only adds misses (1 M barcodes, e <= 2: 11.9 ms with 7 blocks per CU, 8.6 ms with 6).
+// queue capacity (entries): >= 127 left over + what one pass appends — 64 lanes x 3 inline slot entries (one word each,
+// the ring then runs over both arrays), or one two-word entry per lane
 template <bool SL, int HM>
 struct QueueCap {
-    static constexpr int value = (SL || HM <= 16) ? 256 : 128;
+    static constexpr int value = 256;
 };
 // Verified matches kept per segment by the main launch before the row is handed to the retry launch.  With the tiers a
 // settled segment stops early, so few rows collect more.  With bucket slots (small barcode sets) 6 keep a block's LDS at
@@ -181,8 +179,8 @@ struct QueueCap {
 // 3.52 vs 3.39 ms at 25 k barcodes, 0.09 % of the rows retried); larger sets have more ties and keep 8 (400 k barcodes:
 // 24 % instead of 16 % of the rows retried with 6).
 static constexpr int HMAX = 8, HMAX_SL = 6;  // main launch
-static constexpr int K_RETRY = 32, H_RETRY = 64;  // retry launch
-static constexpr int H_RETRY_SL = 60;              // with bucket slots (larger queue): still two blocks of 80 KB per CU
+static constexpr int K_RETRY = 32, H_RETRY = 60;  // retry launch: 60 x 256 B of hit lists leave two blocks of 80 KB per CU
+static constexpr int H_RETRY_SL = H_RETRY;
 static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
 static constexpr uint32_t LOC_MASK = (1u << 30) - 1u;    // locator in a hit-list entry (2 bits of distance above it)
 static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline slot entry (entry indices stay below it)
