@@ -194,6 +194,21 @@ def test_bucket_slot_shapes(m, e):
     util.assert_same(b, want, "exhaustive path")
 
 
+def test_duplicates_inside_long_buckets(m):
+    """Five and nine copies of one barcode inside seed buckets of more than three entries: every copy is its own id and
+    all of them are reported (the copies of a long bucket are found through their shared rest characters)."""
+    rng = np.random.default_rng(77)
+    bc = _shared_prefix_barcodes([6, 5, 7, 4, 8, 2, 1, 3] * 10, rng)
+    bc = np.concatenate([bc, np.repeat(bc[0:1], 4, axis=0), np.repeat(bc[6:7], 8, axis=0), synth.make_barcodes(300, seed=78)])
+    segs, offs = synth.make_segments(3000, bc, seed=79, frac_background=0.05)
+    for e in (0, 1, 2):
+        want = trie_oracle.match(bc, segs, offs, e, threads=1, workers=8)
+        a, b = run_both(m, bc, segs, offs, e)
+        util.assert_same(a, want, "filter path e=%d" % e)
+        util.assert_same(b, want, "exhaustive path e=%d" % e)
+    assert np.diff(want[1]).max() >= 9
+
+
 @pytest.mark.parametrize("e", [0, 1])
 def test_bucket_longer_than_the_slot_length_field(m, e):
     """40 000 barcodes under ONE 8-character prefix: the bucket length no longer fits the 15 low bits of the slot."""
