@@ -422,8 +422,8 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
             k_filter<E, uint32_t, false, K_SLOTS, HMAX, 64, true, false><<<g, 256, 0, st>>>(WAVE_ARGS);                \
             k_filter<E, uint64_t, false, K_SLOTS, HMAX, 64, true, false><<<g, 256, 0, st>>>(WAVE_ARGS);                \
         } else if (use_slots && !TH) {                                                                                \
-            k_filter<E, uint32_t, false, K_SLOTS, HMAX_SL, 64, false, true><<<g, 256, 0, st>>>(WAVE_ARGS);             \
-            k_filter<E, uint64_t, false, K_SLOTS, HMAX_SL, 64, false, true><<<g, 256, 0, st>>>(WAVE_ARGS);             \
+            k_filter<E, uint32_t, false, HMAX_SL, HMAX_SL, 64, false, true><<<g, 256, 0, st>>>(WAVE_ARGS);             \
+            k_filter<E, uint64_t, false, HMAX_SL, HMAX_SL, 64, false, true><<<g, 256, 0, st>>>(WAVE_ARGS);             \
         } else {                                                                                                      \
             k_filter<E, uint32_t, TH, K_SLOTS, HMAX, 64, false, false><<<g, 256, 0, st>>>(WAVE_ARGS);                  \
             k_filter<E, uint64_t, TH, K_SLOTS, HMAX, 64, false, false><<<g, 256, 0, st>>>(WAVE_ARGS);                  \
