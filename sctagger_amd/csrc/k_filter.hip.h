@@ -411,6 +411,9 @@ struct FilterWave {
                 }
             }
             uint64_t om = __ballot(!inl);
+#ifdef SCT_ABLATE_SPREAD  // timing-only build: long buckets are dropped (results are wrong)
+            om = 0;
+#endif
             while (om != 0) {  // a long bucket, spread over the lanes: lane i reads the code of entry first + i
                 const int src = __builtin_ctzll(om);
                 om &= om - 1;
