@@ -21,6 +21,8 @@ Fixture families:
   g6  bl=12, e<=3, 400 segs x 60 barcodes                (-t 1, -t 4)
   g7  ragged segment lengths 0..45, 500 segs x 200 barcodes, e<=2 (-t 1, -t 16)
   g8  get_matches_prefix / run_get_matches_prefix return values (json) on g3
+  g9  250 segs x 45000 barcodes, e<=2 and e<=1           (-t 8): a set large enough for the library to drop the
+      bucket slots at e<=2 (python make_golden.py g9 generates only this family)
 """
 import contextlib
 import gzip
@@ -217,6 +219,11 @@ def seam_vectors(mod, lr, sr):
 
 def main():
     mod = load_reference()
+    if "g9" in sys.argv[1:]:
+        lr, sr = synth_pair("g9", 250, 45000, 16, seed=9, gz_bc=True)
+        for e in (2, 1):
+            expected(mod, "g9", lr, sr, e, 16, 8)
+        return
     lr, sr = synth_pair("g1", 1000, 100, 16, seed=1)
     for t in (1, 4):
         expected(mod, "g1", lr, sr, 1, 16, t)
