@@ -21,6 +21,8 @@ Fixture families:
   g6  bl=12, e<=3, 400 segs x 60 barcodes                (-t 1, -t 4)
   g7  ragged segment lengths 0..45, 500 segs x 200 barcodes, e<=2 (-t 1, -t 16)
   g8  get_matches_prefix / run_get_matches_prefix return values (json) on g3
+  g10 bl=14, e<=2, 400 segs x 150 barcodes (-t 1, -t 16); g11 bl=9, e<=1 and e<=2, 400 segs x 80 barcodes (-t 4)
+      (python make_golden.py g10 generates these two)
   g9  250 segs x 45000 barcodes, e<=2 and e<=1           (-t 8): a set large enough for the library to drop the
       bucket slots at e<=2 (python make_golden.py g9 generates only this family)
 """
@@ -219,6 +221,14 @@ def seam_vectors(mod, lr, sr):
 
 def main():
     mod = load_reference()
+    if "g10" in sys.argv[1:]:   # barcode lengths 14 and 9: the seed filter's run-time piece boundaries
+        lr, sr = synth_pair("g10", 400, 150, 14, seed=10, seg_len=21)
+        for t in (1, 16):
+            expected(mod, "g10", lr, sr, 2, 14, t)
+        lr, sr = synth_pair("g11", 400, 80, 9, seed=11, seg_len=16)
+        for e in (1, 2):
+            expected(mod, "g11", lr, sr, e, 9, 4)
+        return
     if "g9" in sys.argv[1:]:
         lr, sr = synth_pair("g9", 250, 45000, 16, seed=9, gz_bc=True)
         for e in (2, 1):
