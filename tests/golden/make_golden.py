@@ -23,6 +23,7 @@ Fixture families:
   g8  get_matches_prefix / run_get_matches_prefix return values (json) on g3
   g10 bl=14, e<=2, 400 segs x 150 barcodes (-t 1, -t 16); g11 bl=9, e<=1 and e<=2, 400 segs x 80 barcodes (-t 4)
       (python make_golden.py g10 generates these two)
+  g12 3000 segs x 5000 barcodes, e<=2 (-t 16): sub-sample of BASELINE configs[1] (python make_golden.py g12)
   g9  250 segs x 45000 barcodes, e<=2 and e<=1           (-t 8): a set large enough for the library to drop the
       bucket slots at e<=2 (python make_golden.py g9 generates only this family)
 """
@@ -221,6 +222,10 @@ def seam_vectors(mod, lr, sr):
 
 def main():
     mod = load_reference()
+    if "g12" in sys.argv[1:]:   # a sub-sample of BASELINE configs[1] (1 M x 5 k, e<=2) at the reference's default -t 16
+        lr, sr = synth_pair("g12", 3000, 5000, 16, seed=2, gz_bc=True)
+        expected(mod, "g12", lr, sr, 2, 16, 16)
+        return
     if "g10" in sys.argv[1:]:   # barcode lengths 14 and 9: the seed filter's run-time piece boundaries
         lr, sr = synth_pair("g10", 400, 150, 14, seed=10, seg_len=21)
         for t in (1, 16):

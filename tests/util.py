@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
 
 # name -> (barcode length) of every golden family; expected files are <name>.e<E>.t<T>.expected.tsv
-FAMILY_BL = {"g1": 16, "g2": 16, "g3": 16, "g5": 16, "g6": 12, "g7": 16, "g9": 16, "g10": 14, "g11": 9}
+FAMILY_BL = {"g1": 16, "g2": 16, "g3": 16, "g5": 16, "g6": 12, "g7": 16, "g9": 16, "g10": 14, "g11": 9, "g12": 16}
 
 
 def golden_cases():
