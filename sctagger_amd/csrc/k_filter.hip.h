@@ -167,11 +167,11 @@ k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ h
 // All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
 // needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
 // ------------------------------------------------------------------------------------------------------------
-// queue capacity (entries): >= 127 left over + what one pass appends — 64 lanes x 3 inline slot entries (one word each,
-// the ring then runs over both arrays), or one two-word entry per lane
-template <bool SL, int HM>
+// queue capacity (entries): >= 127 left over + what one pass appends — 64 lanes x 3 inline slot entries, or one entry per
+// lane.  With slots and 32-bit masks the entries are one word each and the ring runs over both arrays of 256.
+template <bool SL, int HM, typename W>
 struct QueueCap {
-    static constexpr int value = 256;
+    static constexpr int value = (SL && sizeof(W) == 8) ? 512 : 256;
 };
 // Verified matches kept per segment by the main launch before the row is handed to the retry launch.  With the tiers a
 // settled segment stops early, so few rows collect more.  With bucket slots (small barcode sets) 6 keep a block's LDS at
@@ -196,7 +196,7 @@ struct FilterWaveLds {
     static constexpr int QCAP = QC;
     static constexpr int HMAX = HM;
     alignas(32) W em[64][4];  // em[lane][c]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
-    W va[64];            // bits 0..len
+    W va[sizeof(W) == 4 ? 64 : 1];  // bits 0..len (64-bit instantiations derive it from slen: their LDS is the scarcer)
     struct Planes {
         W lo, hi;
     } pl[64];            // the segments' bit-planes (lookup lanes read the planes of the segment they work for)
@@ -241,7 +241,7 @@ static constexpr uint32_t QM_INLINE = 0x80000000u;
 template <int E, typename W, int HM, bool SL>
 struct FilterWave {
     static constexpr int HMAX = HM;
-    static constexpr int QCAP = QueueCap<SL, HM>::value;
+    static constexpr int QCAP = QueueCap<SL, HM, W>::value;
     FilterWaveLds<W, HM, QCAP> &L;
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
@@ -304,67 +304,46 @@ struct FilterWave {
         __builtin_amdgcn_wave_barrier();
     }
 
-    // Without slots (two-word entries: entry index, lane | t << 8 | t2 << 16) the main launch verifies pairs the same
-    // way, 128 entries per batch; the codes of both candidates are read from the table first.
-    static constexpr bool PKC = !SL && sizeof(W) == 4 && QCAP >= 256;
+    // Everywhere else — no slots, or 64-bit masks — the queue holds two-word entries (entry index or, for an inline
+    // slot entry, its rest characters; lane | t << 8 | t2 << 16 | j << 24 | inline << 31) and pairs are verified the same
+    // way, 128 entries per batch; the codes of entries queued by index are read from the table first.
+    __device__ __forceinline__ W va_of(uint32_t src) const {
+        if constexpr (sizeof(W) == 4) return L.va[src];
+        else return sct_valid_mask<W>((int)L.slen[src]);
+    }
     template <typename Fam>
-    __device__ __forceinline__ void verify2c(const Fam &fam, uint32_t nq) {  // the nq <= 128 entries from head
+    __device__ __forceinline__ void verify2w(const Fam &fam, uint32_t nq) {  // the nq <= 128 entries from head
         if (2u * (uint32_t)lane < nq) {
             const uint32_t i0 = (head + 2u * (uint32_t)lane) & (QCAP - 1);  // head is even: the pair does not wrap
             const bool vy = 2u * (uint32_t)lane + 1u < nq;
-            const uint32_t gx = L.qk[i0], mx = L.qm[i0];
-            const uint32_t gy = vy ? L.qk[i0 + 1] : gx, my = vy ? L.qm[i0 + 1] : mx;
-            const uint32_t cx = tab_code[gx], cy = tab_code[gy];
+            uint32_t gx = L.qk[i0], gy = vy ? L.qk[i0 + 1] : gx;
+            const uint32_t mx = L.qm[i0], my = vy ? L.qm[i0 + 1] : mx;
+            const bool ix = SL && (mx & QM_INLINE) != 0u, iy = SL && (my & QM_INLINE) != 0u;
+            uint32_t rx = gx, ry = gy;  // an inline entry carries its rest characters (bits above them are ignored)
+            if (!ix) rx = sct_rest_of(fam, tab_code[gx]);
+            if (!iy) ry = sct_rest_of(fam, tab_code[gy]);
             const uint32_t sx = mx & 63u, sy = my & 63u;
             const int tx = (int)((mx >> 8) & 63u), t2x = (int)((mx >> 16) & 63u);
             const int ty = (int)((my >> 8) & 63u), t2y = (int)((my >> 16) & 63u);
-            const uint32_t r = wm_anchored_pair<E>(fam, EmLds<W>(&L.em[sx][0]), EmLds<W>(&L.em[sy][0]), (uint32_t)L.va[sx],
-                                                   (uint32_t)L.va[sy], sct_rest_of(fam, cx), sct_rest_of(fam, cy), tx, t2x, ty, t2y);
+            const uint32_t r = wm_anchored_pair<E>(fam, EmLds<W>(&L.em[sx][0]), EmLds<W>(&L.em[sy][0]), va_of(sx), va_of(sy), rx, ry,
+                                                   tx, t2x, ty, t2y);
             const uint32_t dx = r & 0xFFFFu, dy = r >> 16;
+            // what is kept is the entry's LOCATOR; the pattern ids are read once, when the segment is finished
             if (dx <= (uint32_t)E) {
+                if (ix)
+                    gx = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[sx].lo, L.pl[sx].hi, tx, t2x)) << 2) |
+                         ((mx >> 24) & 3u);
                 atomicMin(&L.best[sx], dx);
                 const uint32_t k = atomicAdd(&L.hcnt[sx], 1u);
                 if (k < HMAX) L.hlist[k][sx] = (dx << 30) | gx;
             }
             if (vy && dy <= (uint32_t)E) {
+                if (iy)
+                    gy = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[sy].lo, L.pl[sy].hi, ty, t2y)) << 2) |
+                         ((my >> 24) & 3u);
                 atomicMin(&L.best[sy], dy);
                 const uint32_t k = atomicAdd(&L.hcnt[sy], 1u);
                 if (k < HMAX) L.hlist[k][sy] = (dy << 30) | gy;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    template <typename Fam>
-    __device__ __forceinline__ void verify(const Fam &fam, bool take) {
-        if (take) {
-            const uint32_t idx = (head + lane) & (QCAP - 1);
-            uint32_t gk = L.qk[idx];
-            const uint32_t meta = L.qm[idx];
-            const uint32_t src = meta & 63u;
-            const int t = (int)((meta >> 8) & 63u), t2 = (int)((meta >> 16) & 63u);
-            const bool inl = SL && (meta & QM_INLINE) != 0u;
-            uint32_t rest = gk;  // an inline entry carries its rest characters (bits above them are ignored)
-#ifdef SCT_ABLATE_MISS  // timing-only build: no table is read after the slot (results are wrong)
-            if (!inl) rest = gk * 2654435761u;
-#else
-            if (!inl) rest = sct_rest_of(fam, tab_code[gk]);
-#endif
-#ifdef SCT_ABLATE_VERIFY  // timing-only build: candidates are fetched but never run through the automaton
-            asm volatile("" ::"v"(rest), "v"(t), "v"(t2));
-            const int d = E + 1;
-#else
-            const int d = wm_anchored_rest<E, W>(fam, EmLds<W>(&L.em[src][0]), L.va[src], rest, t, t2);
-#endif
-            if (d <= E) {
-                // what is kept is the entry's LOCATOR; the pattern ids are read once, when the segment is finished
-                // (resolve), so that no table read sits between two batches
-                if (inl)
-                    gk = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[src].lo, L.pl[src].hi, t, t2)) << 2) |
-                         ((meta >> 24) & 3u);
-                atomicMin(&L.best[src], (uint32_t)d);
-                const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
-                if (k < HMAX) L.hlist[k][src] = ((uint32_t)d << 30) | gk;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -459,9 +438,9 @@ struct FilterWave {
                 }
                 tail += (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1);
                 __builtin_amdgcn_wave_barrier();
-                while (tail - head >= 64) {
-                    verify(fam, true);
-                    head += 64;
+                while (tail - head >= 128u) {
+                    verify2w(fam, 128u);
+                    head += 128u;
                 }
             }
             uint64_t om = __ballot(!inl);
@@ -480,9 +459,9 @@ struct FilterWave {
                     }
                     tail += take;
                     __builtin_amdgcn_wave_barrier();
-                    while (tail - head >= 64) {
-                        verify(fam, true);
-                        head += 64;
+                    while (tail - head >= 128u) {
+                        verify2w(fam, 128u);
+                        head += 128u;
                     }
                 }
             }
@@ -501,14 +480,9 @@ struct FilterWave {
                 }
                 tail += (uint32_t)__popcll(m);
                 __builtin_amdgcn_wave_barrier();
-                if constexpr (PKC) {
-                    if (tail - head >= 128u) {
-                        verify2c(fam, 128u);
-                        head += 128u;
-                    }
-                } else if (tail - head >= 64) {
-                    verify(fam, true);
-                    head += 64;
+                if (tail - head >= 128u) {
+                    verify2w(fam, 128u);
+                    head += 128u;
                 }
             }
         }
@@ -621,12 +595,9 @@ struct FilterWave {
         if constexpr (PK) {
             if (tail != head) verify2(fam, tail - head);  // the family's last, partial batch
             head = tail = 0;                              // pairs stay 8-byte aligned in the ring
-        } else if constexpr (PKC) {
-            if (tail != head) verify2c(fam, tail - head);
+        } else {
+            if (tail != head) verify2w(fam, tail - head);
             head = tail = 0;
-        } else if (tail != head) {
-            verify(fam, (uint32_t)lane < tail - head);
-            head = tail;
         }
     }
 };
@@ -654,8 +625,8 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
          uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer, uint32_t *__restrict__ defer_count,
          unsigned long long *__restrict__ slot_cursor, uint64_t slot_tag, int bl_arg) {
     const int bl = RT ? bl_arg : 16;
-    __shared__ FilterWaveLds<W, HM, QueueCap<SL, HM>::value> lds[4];
-    FilterWaveLds<W, HM, QueueCap<SL, HM>::value> &L = lds[threadIdx.x >> 6];
+    __shared__ FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value> lds[4];
+    FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value> &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     // RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows, so that the pair
     // compaction of run_family spreads each row's lookups over four lanes and the few retried rows finish sooner
@@ -687,7 +658,7 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.em[lane][1] = l1 & ~h1 & ve;
     L.em[lane][2] = ~l1 & h1 & ve;
     L.em[lane][3] = l1 & h1 & ve;
-    L.va[lane] = va;
+    if constexpr (sizeof(W) == 4) L.va[lane] = va;
     L.pl[lane].lo = lo;
     L.pl[lane].hi = hi;
     L.slen[lane] = (uint8_t)len;

@@ -383,7 +383,7 @@ SCT_HD int wm_anchored(EmFetch &&em, W va, uint32_t code, int t, int t2) {
 // position behind the piece and move up by at most (run length + E) <= 10.  Each run therefore works on the 16
 // positions from its own base (per candidate), the match masks are shifted down by that base, and the anchor
 // re-bases the states.  Bitwise operations act on both halves at once; only the shifts are per half.
-// Texts of at most 31 characters (32-bit masks); same result as wm_anchored_rest for each candidate.
+// Match masks of 32 bits (texts of at most 31 characters) or 64 bits; same result as wm_anchored_rest for each candidate.
 // ---------------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned short sct_us2 __attribute__((ext_vector_type(2)));
@@ -430,16 +430,17 @@ struct WmPair {
     }
 };
 
-template <int E, typename Fam, typename EmX, typename EmY>
-SCT_HD uint32_t wm_anchored_pair(const Fam &fam, EmX &&emx, EmY &&emy, uint32_t vax, uint32_t vay, uint32_t restx, uint32_t resty,
+template <int E, typename Fam, typename EmX, typename EmY, typename WV>
+SCT_HD uint32_t wm_anchored_pair(const Fam &fam, EmX &&emx, EmY &&emy, WV vax, WV vay, uint32_t restx, uint32_t resty,
                                  int tx, int t2x, int ty, int t2y) {
     WmPair<E> s;
     int bx, by;
     if (fam.PA > 0) {  // left run: free start, must arrive exactly at t
         bx = tx - fam.PA - E > 0 ? tx - fam.PA - E : 0;
         by = ty - fam.PA - E > 0 ? ty - fam.PA - E : 0;
-        s.R0 = s.R1 = s.R2 = sct_pk(vax >> bx, vay >> by);
-        for (int j = 0; j < fam.PA; j++, restx >>= 2, resty >>= 2) s.step(sct_pk(emx(restx & 3u) >> bx, emy(resty & 3u) >> by));
+        s.R0 = s.R1 = s.R2 = sct_pk((uint32_t)(vax >> bx), (uint32_t)(vay >> by));
+        for (int j = 0; j < fam.PA; j++, restx >>= 2, resty >>= 2)
+            s.step(sct_pk((uint32_t)(emx(restx & 3u) >> bx), (uint32_t)(emy(resty & 3u) >> by)));
         s.anchor(sct_pk((uint32_t)(tx - bx), (uint32_t)(ty - by)));
     } else {
         s.R0 = 0x00010001u;
@@ -451,14 +452,14 @@ SCT_HD uint32_t wm_anchored_pair(const Fam &fam, EmX &&emx, EmY &&emy, uint32_t 
     by = ty + skip1;
     if (!fam.ADJ) {  // middle run: from behind piece A exactly to t2
         for (int j = fam.PA + fam.LA; j < fam.PB; j++, restx >>= 2, resty >>= 2)
-            s.step(sct_pk(emx(restx & 3u) >> bx, emy(resty & 3u) >> by));
+            s.step(sct_pk((uint32_t)(emx(restx & 3u) >> bx), (uint32_t)(emy(resty & 3u) >> by)));
         s.anchor(sct_pk((uint32_t)(t2x - bx), (uint32_t)(t2y - by)));
         bx = t2x + fam.LB;
         by = t2y + fam.LB;
     }
     for (int j = fam.PB + fam.LB; j < fam.BL; j++, restx >>= 2, resty >>= 2)  // right run: free end
-        s.step(sct_pk(emx(restx & 3u) >> bx, emy(resty & 3u) >> by));
-    return s.result(sct_pk(vax >> bx, vay >> by));
+        s.step(sct_pk((uint32_t)(emx(restx & 3u) >> bx), (uint32_t)(emy(resty & 3u) >> by)));
+    return s.result(sct_pk((uint32_t)(vax >> bx), (uint32_t)(vay >> by)));
 }
 
 // ---------------------------------------------------------------------------------------------------

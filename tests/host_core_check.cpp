@@ -387,6 +387,43 @@ int main() {
         if (!ok) { printf("FAIL pair bl=%d f=%d t=(%d,%d) (%d,%d)\n", bl, f, tt[0], tt2[0], tt[1], tt2[1]); return 1; }
         checked++;
     }
+    //     ... 64-bit match masks (texts of up to 63 characters)
+    for (int it = 0; it < 20000; it++) {
+        const int bl = it % 2 ? 16 : 8 + rnd(9);
+        std::vector<int> p(bl);
+        for (auto &x : p) x = rnd(4);
+        std::vector<int> t = p;
+        for (int e = rnd(4); e > 0; e--) {
+            const int op = rnd(3), pos = t.empty() ? 0 : rnd((int)t.size());
+            if (op == 0 && !t.empty()) t[pos] = rnd(4);
+            else if (op == 1) t.insert(t.begin() + pos, rnd(4));
+            else if (!t.empty()) t.erase(t.begin() + pos);
+        }
+        for (int l = rnd(40); l > 0; l--) t.insert(t.begin(), rnd(4));
+        for (int r = rnd(40); r > 0; r--) t.push_back(rnd(4));
+        if ((int)t.size() > 63) t.resize(63);
+        const int L = (int)t.size();
+        uint64_t tlo, thi;
+        planes(t, tlo, thi);
+        EmArray<uint64_t> em;
+        const uint64_t va = sct_valid_mask<uint64_t>(L), ve = va & ~(uint64_t)1, l1 = tlo << 1, h1 = thi << 1;
+        em.m[0] = ~l1 & ~h1 & ve; em.m[1] = l1 & ~h1 & ve; em.m[2] = ~l1 & h1 & ve; em.m[3] = l1 & h1 & ve;
+        uint32_t code = 0;
+        for (int j = 0; j < bl; j++) code |= (uint32_t)p[j] << (2 * j);
+        for (int f = 0; f < 6; f++) {
+            const SctFamilyRT fam = sct_family_rt(f, bl);
+            const uint32_t rest = sct_rest_of(fam, code);
+            std::vector<std::pair<int, int>> pl;
+            sct_for_each_placement_of(fam, L, [&](int a, int b) { pl.push_back({a, b}); });
+            for (size_t i = 0; i + 1 < pl.size(); i += 2) {
+                const uint32_t r = wm_anchored_pair<2>(fam, em, em, va, va, rest, rest, pl[i].first, pl[i].second, pl[i + 1].first, pl[i + 1].second);
+                const int d0 = wm_anchored_rest<2, uint64_t>(fam, em, va, rest, pl[i].first, pl[i].second);
+                const int d1 = wm_anchored_rest<2, uint64_t>(fam, em, va, rest, pl[i + 1].first, pl[i + 1].second);
+                if ((int)(r & 0xFFFFu) != d0 || (int)(r >> 16) != d1) { printf("FAIL pair (64-bit) bl=%d f=%d L=%d\n", bl, f, L); return 1; }
+                checked++;
+            }
+        }
+    }
     //     ... the thirds families (static descriptions, <= 1 edit)
     for (int it = 0; it < 30000; it++) {
         std::vector<int> p(16);
