@@ -125,7 +125,7 @@ int sct_last_timing(sct_ctx *ctx, const char **names, float *ms, int cap);
 
 /* Counters of the last sct_run: [0] segments on the seed-filter path, [1] segments on the exhaustive
  * path, [2] segments on the restricted-start (non-ACGT, k>0) path, [3] total hits, [4] segments the filter path
- * retried with larger lists (more than 8 ties or 16 verified matches). Returns count or <0. */
+ * retried with larger lists (more than 6 or 8 verified matches, by the seed tables in use). Returns count or <0. */
 int sct_last_stats(sct_ctx *ctx, int64_t *out, int cap);
 
 /*
