@@ -237,6 +237,8 @@ struct EmLds {
 // A queued entry is (qk, qm): qm = lane | t << 8 | t2 << 16 | j << 24 | inline << 31; qk = rest characters (inline)
 // or entry index.
 static constexpr uint32_t QM_INLINE = 0x80000000u;
+static constexpr size_t SLOT_TOTAL = (size_t)SCT_NFAM * (SCT_KEYS + 1);  // slots of the six quarter families; behind them, in
+                                                                         // the same buffer, the pattern ids of the inline entries
 
 template <int E, typename W, int HM, bool SL>
 struct FilterWave {
@@ -351,7 +353,11 @@ struct FilterWave {
 
     // pattern id of a verified entry: locator = entry index, or LOC_INLINE | (index into tab_off) << 2 | j
     __device__ __forceinline__ uint32_t resolve(uint32_t loc) const {
-        if (SL && (loc & LOC_INLINE)) loc = tab_off[(loc & (LOC_INLINE - 1u)) >> 2] + (loc & 3u);
+        if (SL && (loc & LOC_INLINE)) {  // one read: the ids of the inline entries lie behind the slots
+            const uint32_t *slot_pid = reinterpret_cast<const uint32_t *>(tab_slot + SLOT_TOTAL);
+            const uint32_t l = loc & (LOC_INLINE - 1u);
+            return slot_pid[3u * (l >> 2) + (l & 3u)];
+        }
         return tab_ent[loc];
     }
 

@@ -3,7 +3,8 @@
 //
 // Per family f (sct_core.h): an offsets array of nkeys(f) + 1 entries holding ABSOLUTE indices into the entry tables
 // (family f's entries start at f * np), the entries as pattern ids (ascending inside a bucket) and as 2-bit codes, and
-// — for the six quarter families — one 8-byte bucket slot per key (sct_slot_*), indexed like the offsets.
+// — for the six quarter families — one 8-byte bucket slot per key (sct_slot_*), indexed like the offsets, with the
+// pattern ids of the slots' inline entries beside them.
 #pragma once
 #include <stdint.h>
 
@@ -16,6 +17,7 @@ struct SctSeedTables {
     uint32_t off_base[SCT_NFAM_ALL] = {};  // where family f's offsets (and slots) start
     std::vector<uint32_t> off, ent, code;
     std::vector<uint64_t> slot;
+    std::vector<uint32_t> slot_pid;        // pattern id of inline entry j of slot i at [3 * i + j]: one read resolves a hit
     double long_share = 1.0;               // share of the quarter families' keys whose bucket does not fit a slot
 };
 
@@ -61,6 +63,7 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
     size_t slot_total = 0;
     for (int f = 0; f < SCT_NFAM; f++) slot_total += (size_t)sct_family_nkeys(f) + 1;
     T.slot.assign(slot_total, 0ull);
+    T.slot_pid.assign(3 * slot_total, 0u);
     size_t long_keys = 0;
     for (int f = 0; f < SCT_NFAM; f++) {
         const SctFamilyRT fam = sct_family_rt(f, bl);
@@ -70,7 +73,10 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
             const uint32_t cnt = o[k + 1] - o[k];
             if (cnt <= 3) {
                 uint32_t rest[3] = {0, 0, 0};
-                for (uint32_t j = 0; j < cnt; j++) rest[j] = sct_rest_of(fam, T.code[o[k] + j]);
+                for (uint32_t j = 0; j < cnt; j++) {
+                    rest[j] = sct_rest_of(fam, T.code[o[k] + j]);
+                    T.slot_pid[3 * ((size_t)T.off_base[f] + k) + j] = T.ent[o[k] + j];
+                }
                 sl[k] = sct_slot_inline(cnt, rest);
             } else {
                 long_keys++;

@@ -308,8 +308,12 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
         const std::vector<uint32_t> &off = tb.off, &ent = tb.ent, &code = tb.code;
         const std::vector<uint64_t> &slot = tb.slot;
         c->long_share = tb.long_share;
-        if (c->tab_slot.ensure(slot.size() * sizeof(uint64_t))) return SCT_E_HIP;
+        // one buffer: the slots, then the pattern ids of their inline entries (k_filter.hip.h: SLOT_PID_AT)
+        if (slot.size() != SLOT_TOTAL) return fail(SCT_E_STATE, "seed tables: unexpected slot count");
+        if (c->tab_slot.ensure(slot.size() * sizeof(uint64_t) + tb.slot_pid.size() * sizeof(uint32_t))) return SCT_E_HIP;
         HIPCHK(hipMemcpyAsync(c->tab_slot.p, slot.data(), slot.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync((char *)c->tab_slot.p + slot.size() * sizeof(uint64_t), tb.slot_pid.data(),
+                              tb.slot_pid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         if (c->tab_off.ensure(off.size() * sizeof(uint32_t) + 16)) return SCT_E_HIP;
         if (c->tab_ent.ensure(ent.size() * sizeof(uint32_t))) return SCT_E_HIP;
         if (c->tab_code.ensure(code.size() * sizeof(uint32_t))) return SCT_E_HIP;

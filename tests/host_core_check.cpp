@@ -266,7 +266,7 @@ static bool emulate_filter(const SctSeedTables &T, const std::vector<std::vector
                 if (sct_slot_is_inline(sa)) {
                     const uint32_t q[3] = {mid, sct_slot_next(mid, top), top};
                     for (uint32_t j = 0; j < sct_slot_inline_count(sa); j++)
-                        add(wm_anchored_rest<E, uint32_t>(fam, em, va, q[j], a, b), T.ent[off[key] + j]);
+                        add(wm_anchored_rest<E, uint32_t>(fam, em, va, q[j], a, b), T.slot_pid[3 * ((size_t)T.off_base[f] + key) + j]);
                 } else {
                     for (uint32_t k = 0; k < sct_slot_long_count(sa, top); k++)
                         add(wm_anchored_rest<E, uint32_t>(fam, em, va, sct_rest_of(fam, T.code[mid + k]), a, b), T.ent[mid + k]);
