@@ -192,7 +192,7 @@ def main():
             roof["traffic"] = int(rd + (q.get("hbm_write_bytes") or 0))
             roof["traffic_source"] = q["source"] + (
                 "; FETCH_SIZE + WRITE_SIZE as read.  Reads = 24 B/segment of packed input streamed once + the L2 misses of "
-                "the pattern-id resolution (offset/entry tables, ~7 MB of tables against a 4 MB L2; FETCH_SIZE counts "
+                "the pattern-id resolution (one read per hit into a 4.7 MB id table beside 3.1 MB of slots, against a 4 MB L2; FETCH_SIZE counts "
                 "Infinity-Cache hits too); writes = the result arrays")
             if q.get("l2_requests_per_launch"):
                 # the seed lookups are random 8-byte reads: one 128-byte L2 request each, whatever the bytes used
