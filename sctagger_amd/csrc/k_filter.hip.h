@@ -189,6 +189,7 @@ static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline
 // concatenated entry tables (family f's entries start at f * np)
 struct FamTables {
     uint32_t off_base[SCT_NFAM_ALL];
+    uint32_t pid16;  // the pattern ids behind the slots are 16-bit (fewer than 65 536 patterns): half the footprint
 };
 
 template <typename W, int HM, int QC>
@@ -354,9 +355,9 @@ struct FilterWave {
     // pattern id of a verified entry: locator = entry index, or LOC_INLINE | (index into tab_off) << 2 | j
     __device__ __forceinline__ uint32_t resolve(uint32_t loc) const {
         if (SL && (loc & LOC_INLINE)) {  // one read: the ids of the inline entries lie behind the slots
-            const uint32_t *slot_pid = reinterpret_cast<const uint32_t *>(tab_slot + SLOT_TOTAL);
-            const uint32_t l = loc & (LOC_INLINE - 1u);
-            return slot_pid[3u * (l >> 2) + (l & 3u)];
+            const uint32_t l = loc & (LOC_INLINE - 1u), at = 3u * (l >> 2) + (l & 3u);
+            if (ft.pid16) return reinterpret_cast<const uint16_t *>(tab_slot + SLOT_TOTAL)[at];
+            return reinterpret_cast<const uint32_t *>(tab_slot + SLOT_TOTAL)[at];
         }
         return tab_ent[loc];
     }

@@ -312,8 +312,16 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
         if (slot.size() != SLOT_TOTAL) return fail(SCT_E_STATE, "seed tables: unexpected slot count");
         if (c->tab_slot.ensure(slot.size() * sizeof(uint64_t) + tb.slot_pid.size() * sizeof(uint32_t))) return SCT_E_HIP;
         HIPCHK(hipMemcpyAsync(c->tab_slot.p, slot.data(), slot.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync((char *)c->tab_slot.p + slot.size() * sizeof(uint64_t), tb.slot_pid.data(),
-                              tb.slot_pid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        ft.pid16 = np <= 65536 ? 1u : 0u;
+        std::vector<uint16_t> pid16;
+        if (ft.pid16) {
+            pid16.assign(tb.slot_pid.begin(), tb.slot_pid.end());
+            HIPCHK(hipMemcpyAsync((char *)c->tab_slot.p + slot.size() * sizeof(uint64_t), pid16.data(), pid16.size() * sizeof(uint16_t),
+                                  hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIPCHK(hipMemcpyAsync((char *)c->tab_slot.p + slot.size() * sizeof(uint64_t), tb.slot_pid.data(),
+                                  tb.slot_pid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        }
         if (c->tab_off.ensure(off.size() * sizeof(uint32_t) + 16)) return SCT_E_HIP;
         if (c->tab_ent.ensure(ent.size() * sizeof(uint32_t))) return SCT_E_HIP;
         if (c->tab_code.ensure(code.size() * sizeof(uint32_t))) return SCT_E_HIP;
