@@ -32,7 +32,8 @@ enum {
     SCT_E_HIP = -2,         /* a HIP runtime call failed */
     SCT_E_NODEV = -3,       /* no usable device */
     SCT_E_STATE = -4,       /* call order (e.g. match before set_barcodes) */
-    SCT_E_UNSUPPORTED = -5  /* barcode length above SCT_MAX_BL */
+    SCT_E_UNSUPPORTED = -5, /* barcode length above SCT_MAX_BL; a -t whose window prefix is not below bl - max_err */
+    SCT_E_RANGE = -6        /* a value does not fit the compact output format that was asked for */
 };
 
 #define SCT_MAX_BL 32       /* barcode length limit of the bit-parallel kernels */
@@ -84,10 +85,40 @@ int sct_match(sct_ctx *ctx, const char *segs, const int64_t *offs, int64_t n, in
 void sct_free_hits(sct_ctx *ctx, uint32_t *hits);
 
 /*
+ * The same seam for callers that care about the PCIe link: compact transfer formats and a pipelined engine.  The rows
+ * are cut into chunks (option "chunk_rows") that move through several streams (option "lanes"), so that the upload of chunk
+ * k+1, the kernels of chunk k and the download of chunk k-1 overlap; sct_match above is this call with 64-bit offsets
+ * both ways.  Give it page-locked buffers (sct_host_alloc) for segs / index / min_e / counts: copies from or to
+ * pageable memory are staged by the runtime, block the calling thread and defeat the overlap (the results are the same).
+ *   segs, seg_bytes   the reference's lr_segs (scTagger.py:616-627) and its size
+ *   index             where each row lies in segs, in one of four forms (index_format):
+ *       SCT_IDX_OFFS64  int64 offs[n+1]   CSR offsets, offs[0] == 0, offs[n] == seg_bytes
+ *       SCT_IDX_OFFS32  int32 offs[n+1]   the same in the reference's own type (its lr_segs_idxs is a c_int array)
+ *       SCT_IDX_LEN8    uint8 len[n]      row lengths (rows of at most 255 characters), sum == seg_bytes
+ *       SCT_IDX_LEN16   uint16 len[n]     row lengths (at most 65 535 characters)
+ *   max_err, threads  as for sct_match
+ * Outputs:
+ *   min_e[n]          as for sct_match
+ *   counts            the number of hits of every row, in one of three forms (count_format):
+ *       SCT_CNT_OFFS64  int64 hit_offs[n+1]  CSR offsets into *hits, exactly sct_match's hit_offs
+ *       SCT_CNT_U32     uint32 cnt[n]        hits per row (offsets = their prefix sum, left to the caller)
+ *       SCT_CNT_U8      uint8 cnt[n]         the same in one byte; fails with SCT_E_RANGE if a row has more than 255 hits
+ *   *hits             all hit lists back to back in row order, (bid << 1 | strand) ascending inside a row.  The array
+ *                     is page-locked memory OWNED BY THE CONTEXT: valid until the next sct_match_stream / sct_match /
+ *                     sct_destroy on it, not to be freed by the caller.
+ *   *n_hits           total number of hits
+ */
+enum { SCT_IDX_OFFS64 = 0, SCT_IDX_OFFS32 = 1, SCT_IDX_LEN8 = 2, SCT_IDX_LEN16 = 3 };
+enum { SCT_CNT_OFFS64 = 0, SCT_CNT_U32 = 1, SCT_CNT_U8 = 2 };
+int sct_match_stream(sct_ctx *ctx, const char *segs, int64_t seg_bytes, const void *index, int32_t index_format, int64_t n,
+                     int32_t max_err, int32_t threads, uint8_t *min_e, void *counts, int32_t count_format,
+                     const uint32_t **hits, int64_t *n_hits);
+
+/*
  * The same path in three steps, for pipelining and for measuring with the inputs resident in HBM:
  *   sct_upload_segments  host -> device copy of segs/offs (kept until the next upload)
  *   sct_run              every kernel of the path on the resident segments; results stay on the device;
- *                        *n_hits receives the total hit count (one 8-byte device->host read)
+ *                        *n_hits receives the total hit count (one host synchronisation and one 64-byte read per run)
  *   sct_download         device -> host copy of the results of the last sct_run; hits must hold
  *                        n_hits entries
  */
@@ -97,7 +128,8 @@ int sct_download(sct_ctx *ctx, uint8_t *min_e, int64_t *hit_offs, uint32_t *hits
 
 /*
  * Page-locked host memory.  Optional: every entry point accepts ordinary (pageable) buffers; buffers obtained here
- * are copied to and from the device by DMA at the full PCIe rate instead of through the runtime's bounce buffer.
+ * are copied to and from the device by DMA at the full PCIe rate, asynchronously, instead of through the runtime's
+ * bounce buffer.
  * sct_host_alloc returns NULL on failure (message in sct_last_error).
  */
 void *sct_host_alloc(sct_ctx *ctx, size_t bytes);
@@ -110,20 +142,28 @@ int sct_sync(sct_ctx *ctx);
  * Options (key, value):
  *   "force_exhaustive" 0|1   skip the seed-filter kernel and scan every barcode for every segment
  *   "timing"           0|1   record HIP events around each kernel of sct_run (default 1)
- *   "filter_mode"      0|1   0 = wave-cooperative seed-filter kernel (default), 1 = lane-per-segment variant
  *   "no_thirds"        0|1   1 = never use the 20/22-bit seed families chosen for >= 2^19 patterns at max_err <= 1
  *   "slots"           -1|0|1 8-byte bucket slots of the 16-character seed tables: -1 = used while few keys hold more
  *                            than three barcodes (3.5 % at max_err 2, 10 % below; default), 0 = never, 1 = always
+ *   "chunk_rows"       n     rows per chunk of sct_match_stream / sct_match; 0 (default) = 2^20 when segs is page-locked
+ *                            memory, 2^24 when it is pageable (staged copies do not overlap with anything)
+ *   "lanes"            1..8  chunks of a stream call in flight at once, each on a stream of its own (default 5)
+ *   "zero_copy"        0|1   1 (default): sct_match_stream's kernels read page-locked segs / index buffers in place over the
+ *                            host link; 0: they are uploaded first (pageable buffers always are)
  */
 int sct_set_option(sct_ctx *ctx, const char *key, int64_t value);
 
 /*
- * Per-kernel device time of the last sct_run, measured with HIP events on the context's stream.
- * Fills up to cap entries of names[] (static strings) and ms[]; returns the number of kernels, or <0.
+ * Device time of the last sct_run / sct_match_stream / sct_match by kernel name, measured with HIP events on the stream
+ * the kernels were launched on: ms[] = sum over the launches of that name, launches[] = how many there were (one per
+ * chunk for a stream call).  The stream calls also report their copies as "copy_h2d" / "copy_d2h" and the HOST time
+ * of the calling thread as "host_queue" (queueing the chunks) and "host_wait" (waiting for them, collecting the hits).
+ * Fills up to cap entries of names[] (static strings), ms[] and launches[]; returns the number of names, or <0.
  */
 int sct_last_timing(sct_ctx *ctx, const char **names, float *ms, int cap);
+int sct_last_timing_ex(sct_ctx *ctx, const char **names, float *ms, int32_t *launches, int cap);
 
-/* Counters of the last sct_run: [0] segments on the seed-filter path, [1] segments on the exhaustive
+/* Counters of the last sct_run / sct_match_stream / sct_match: [0] segments on the seed-filter path, [1] segments on the exhaustive
  * path, [2] segments on the restricted-start (non-ACGT, k>0) path, [3] total hits, [4] segments the filter path
  * retried with larger lists (more than 6 or 8 verified matches, by the seed tables in use). Returns count or <0. */
 int sct_last_stats(sct_ctx *ctx, int64_t *out, int cap);

@@ -20,8 +20,15 @@ EXPORTS = (
     "sct_device_count", "sct_create", "sct_destroy", "sct_last_error", "sct_prefix_len", "sct_set_barcodes",
     "sct_match", "sct_free_hits", "sct_upload_segments", "sct_run", "sct_download", "sct_sync", "sct_set_option",
     "sct_last_timing", "sct_last_stats", "sct_wl_set", "sct_wl_count", "sct_adapter_align", "sct_free_locs",
-    "sct_host_alloc", "sct_host_free",
+    "sct_host_alloc", "sct_host_free", "sct_match_stream", "sct_last_timing_ex",
 )
+
+# index / count formats of sct_match_stream (include/sctagger_hip.h)
+IDX_OFFS64, IDX_OFFS32, IDX_LEN8, IDX_LEN16 = 0, 1, 2, 3
+CNT_OFFS64, CNT_U32, CNT_U8 = 0, 1, 2
+_IDX_DTYPE = {IDX_OFFS64: np.int64, IDX_OFFS32: np.int32, IDX_LEN8: np.uint8, IDX_LEN16: np.uint16}
+_CNT_DTYPE = {CNT_OFFS64: np.int64, CNT_U32: np.uint32, CNT_U8: np.uint8}
+E_RANGE = -6
 
 _lib = None
 
@@ -59,6 +66,8 @@ def load():
     lib.sct_sync.argtypes = [vp]
     lib.sct_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     lib.sct_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    lib.sct_last_timing_ex.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32), ctypes.c_int]
+    lib.sct_match_stream.argtypes = [vp, vp, i64, vp, i32, i64, i32, i32, vp, vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     lib.sct_last_stats.argtypes = [vp, ctypes.POINTER(i64), ctypes.c_int]
     lib.sct_wl_set.argtypes = [vp, vp, vp, i32]
     lib.sct_wl_count.argtypes = [vp, vp, vp, vp, i64, vp, vp]
@@ -134,6 +143,12 @@ class Matcher:
         buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(p)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
 
+    def release_host_arrays(self):
+        """Free every page-locked array handed out by host_array (the arrays must not be used afterwards)."""
+        for p in self._pinned:
+            self._lib.sct_host_free(self._ctx, p)
+        self._pinned = []
+
     def set_option(self, key, value):
         self._check(self._lib.sct_set_option(self._ctx, key.encode(), int(value)))
 
@@ -187,6 +202,41 @@ class Matcher:
         self.n_seg = n
         return min_e, hit_offs, hits
 
+    def match_stream(self, segs, index, max_err, threads=1, index_format=IDX_OFFS64, count_format=CNT_U8, min_e=None, counts=None,
+                     copy_hits=True):
+        """sct_match_stream: the pipelined seam with compact transfer formats.
+
+        segs: uint8 bytes of all rows; index: int64/int32 offsets[n+1] or uint8/uint16 lengths[n] (index_format);
+        -> (min_e uint8[n], counts, hits uint32[total]); counts is int64 hit_offs[n+1], uint32 cnt[n] or uint8 cnt[n]
+        (count_format).  min_e / counts may be given (e.g. page-locked arrays from host_array).  With copy_hits=False
+        `hits` is a view of the library's page-locked result buffer, valid until the next match on this Matcher."""
+        if isinstance(segs, (bytes, bytearray, memoryview)):
+            segs = np.frombuffer(segs, dtype=np.uint8)
+        segs = np.ascontiguousarray(segs, dtype=np.uint8)
+        index = np.ascontiguousarray(index, dtype=_IDX_DTYPE[index_format])
+        n = index.size - 1 if index_format in (IDX_OFFS64, IDX_OFFS32) else index.size
+        if n < 0:
+            raise ValueError("offsets must hold n+1 entries")
+        if min_e is None:
+            min_e = np.empty(max(n, 1), dtype=np.uint8)
+        n_counts = n + 1 if count_format == CNT_OFFS64 else n
+        if counts is None:
+            counts = np.empty(max(n_counts, 1), dtype=_CNT_DTYPE[count_format])
+        assert min_e.dtype == np.uint8 and min_e.size >= n and counts.dtype == _CNT_DTYPE[count_format] and counts.size >= n_counts
+        hp = ctypes.c_void_p()
+        nh = ctypes.c_int64()
+        self._check(self._lib.sct_match_stream(self._ctx, _ptr(segs), segs.size, _ptr(index), int(index_format), n, int(max_err),
+                                               int(threads), _ptr(min_e), _ptr(counts), int(count_format), ctypes.byref(hp),
+                                               ctypes.byref(nh)))
+        if nh.value:
+            hits = np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_uint32)), shape=(nh.value,))
+            if copy_hits:
+                hits = hits.copy()
+        else:
+            hits = np.empty(0, dtype=np.uint32)
+        self.n_seg = n
+        return min_e[:n], counts[:n_counts], hits
+
     def upload_segments(self, segs, offs):
         segs, offs = self._csr(segs, offs)
         self._check(self._lib.sct_upload_segments(self._ctx, _ptr(segs), _ptr(offs), offs.size - 1))
@@ -217,14 +267,20 @@ class Matcher:
         self._check(self._lib.sct_sync(self._ctx))
 
     def last_timing(self):
-        """-> list of (kernel name, ms) of the last run, from HIP events on the library's stream."""
+        """-> list of (kernel name, ms summed over its launches) of the last run / match, from HIP events on the streams
+        the kernels ran on."""
+        return [(nm, ms) for nm, ms, _ in self.last_timing_ex()]
+
+    def last_timing_ex(self):
+        """-> list of (name, ms summed over its launches, launches); stream calls also report "copy_h2d" / "copy_d2h"."""
         cap = 32
         names = (ctypes.c_char_p * cap)()
         ms = (ctypes.c_float * cap)()
-        k = self._lib.sct_last_timing(self._ctx, names, ms, cap)
+        launches = (ctypes.c_int32 * cap)()
+        k = self._lib.sct_last_timing_ex(self._ctx, names, ms, launches, cap)
         if k < 0:
             self._check(k)
-        return [(names[i].decode(), float(ms[i])) for i in range(min(k, cap))]
+        return [(names[i].decode(), float(ms[i]), int(launches[i])) for i in range(min(k, cap))]
 
     def wl_set(self, words):
         """The whitelist dictionary of extract_sr_bc_from_lr (scTagger.py:801-809). words: list of str/bytes."""

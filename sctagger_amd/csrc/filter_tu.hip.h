@@ -1,0 +1,69 @@
+// filter_tu.hip.h — body of the three translation units filter_e0.hip / filter_e1.hip / filter_e2.hip: the instantiations of
+// k_filter for ONE error budget E (SCT_FILTER_E) and the host function that picks among them.  The seed-filter kernel
+// is by far the largest part of the library's device code; cutting it by E lets `make -j` build the parts side by side.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "../../include/sctagger_hip.h"
+#include "sct_core.h"
+#include "sct_kernels_common.h"
+#include "k_decode.hip.h"
+#include "k_filter.hip.h"
+#include "filter_launch.h"
+
+#ifndef SCT_FILTER_E
+#error "define SCT_FILTER_E (0, 1 or 2) before including filter_tu.hip.h"
+#endif
+
+namespace {
+template <typename OffT>
+void launch(const SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, unsigned g64, hipStream_t st) {
+    constexpr int E = SCT_FILTER_E;
+    // both mask widths are launched over all rows; a wave leaves a group of rows at once if it is not its kind (k_filter).
+    // g = grid of the 32-bit instantiation, g64 = the (smaller, striding) grid of the 64-bit one; the striding launches
+    // (every one but the main launch's 32-bit instantiation) run one wave per block (FilterWavesPerBlock)
+    if (!v.retry) {
+        if (v.rt) {
+            k_filter<E, uint32_t, false, K_SLOTS, HMAX, 64, true, false, OffT><<<g, 256, 0, st>>>(fa);
+            k_filter<E, uint64_t, false, K_SLOTS, HMAX, 64, true, false, OffT><<<g64, 64, 0, st>>>(fa);
+        } else if (v.thirds) {
+            if constexpr (E <= 1) {
+                k_filter<E, uint32_t, true, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
+                k_filter<E, uint64_t, true, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+            }
+        } else if (v.slots) {
+            k_filter<E, uint32_t, false, HMAX_SL, HMAX_SL, 64, false, true, OffT><<<g, 256, 0, st>>>(fa);
+            k_filter<E, uint64_t, false, HMAX_SL, HMAX_SL, 64, false, true, OffT><<<g64, 64, 0, st>>>(fa);
+        } else {
+            k_filter<E, uint32_t, false, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
+            k_filter<E, uint64_t, false, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+        }
+    } else {
+        if (v.rt) {
+            k_filter<E, uint32_t, false, K_RETRY, H_RETRY, 16, true, false, OffT><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, false, K_RETRY, H_RETRY, 16, true, false, OffT><<<g64, 64, 0, st>>>(fa);
+        } else if (v.thirds) {
+            if constexpr (E <= 1) {
+                k_filter<E, uint32_t, true, K_RETRY, H_RETRY, 16, false, false, OffT><<<g, 64, 0, st>>>(fa);
+                k_filter<E, uint64_t, true, K_RETRY, H_RETRY, 16, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+            }
+        } else if (v.slots) {
+            k_filter<E, uint32_t, false, K_RETRY, H_RETRY_SL, 16, false, true, OffT><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, false, K_RETRY, H_RETRY_SL, 16, false, true, OffT><<<g64, 64, 0, st>>>(fa);
+        } else {
+            k_filter<E, uint32_t, false, K_RETRY, H_RETRY, 16, false, false, OffT><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, false, K_RETRY, H_RETRY, 16, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+        }
+    }
+}
+}  // namespace
+
+#define SCT_CAT2(a, b) a##b
+#define SCT_CAT(a, b) SCT_CAT2(a, b)
+void SCT_CAT(sct_launch_filter_e, SCT_FILTER_E)(SctFilterVariant v, const FilterArgs<int64_t> &fa, unsigned g, unsigned g64, hipStream_t st) {
+    launch(v, fa, g, g64, st);
+}
+void SCT_CAT(sct_launch_filter_e, SCT_FILTER_E)(SctFilterVariant v, const FilterArgs<uint32_t> &fa, unsigned g, unsigned g64, hipStream_t st) {
+    launch(v, fa, g, g64, st);
+}

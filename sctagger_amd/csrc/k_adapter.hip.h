@@ -1,5 +1,5 @@
 // k_adapter.hip.h — k_adapter_count / k_adapter_fill: extract_lr_bc adapter alignment.
-// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, pack, filter, scan,
+// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, decode, filter, scan,
 // offsets, whitelist, adapter, validate).  gfx950 only.
 #pragma once
 // ------------------------------------------------------------------------------------------------------------

@@ -1,11 +1,24 @@
-// k_filter.hip.h — the seed filter: LaneResult, k_filter_lane (A/B), k_filter (wave-cooperative, bucket slots).
-// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, pack, filter, scan,
+// k_filter.hip.h — the seed filter: LaneResult, k_filter (wave-cooperative, bucket slots; reads the ASCII rows itself).
+// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, decode, filter, scan,
 // offsets, whitelist, adapter, validate).  gfx950 only.
 #pragma once
 // ------------------------------------------------------------------------------------------------------------
 // Per-lane result of the filter kernels: running minimum distance and up to K_SLOTS distinct pattern ids at
 // that minimum, in registers (static indexing only).  More than K_SLOTS ties defer the segment to the scan path.
 // ------------------------------------------------------------------------------------------------------------
+// The wave's 64 min_e bytes (rows r0 .. r0 + 63, `mine` = this lane's byte) as four 16-byte stores instead of 64 one-byte ones:
+// when min_e is the caller's page-locked array every store instruction crosses the PCIe link as it is, and one-byte writes
+// cost 0.8 ms per 10 M rows.  &min_e[r0] must be 16-byte aligned.
+__device__ __forceinline__ void store_min_e_line(uint8_t *__restrict__ min_e, int64_t r0, uint32_t mine) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = mine | (__shfl_down(mine, 1, 64) << 8) | (__shfl_down(mine, 2, 64) << 16) | (__shfl_down(mine, 3, 64) << 24);
+    const uint32_t w1 = __shfl_down(w, 4, 64), w2 = __shfl_down(w, 8, 64), w3 = __shfl_down(w, 12, 64);
+    if ((lane & 15) == 0) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u4 *>(min_e + r0 + lane) = u4{w, w1, w2, w3};
+    }
+}
+
 template <int E, int KS = K_SLOTS>
 struct LaneResult {
     static constexpr int K_SLOTS = KS;  // shadows the global default inside this struct
@@ -39,13 +52,17 @@ struct LaneResult {
     // The hit lists of the wave are written back to back into the dense `slots` array: one wave-wide prefix sum
     // of the list lengths and one 64-bit atomic per wave reserve the space, slot_off[r] remembers where row r's
     // list starts.  Rows with too many ties are pushed to the scan list instead.
-    __device__ __forceinline__ void store(bool row, int64_t r, bool overflow, uint8_t *__restrict__ min_e,
-                                          uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
+    // `slots_cap` = entries the slot array holds: a wave whose lists would run past it defers all its rows (the main
+    // launch's array holds K_SLOTS entries for every row and cannot overflow; the retry launch's is sized for the usual case).
+    // `line`: the wave's rows are 64 consecutive ones starting at r - lane and their min_e bytes are written as one line
+    // (store_min_e_line; lanes without a result of their own contribute SCT_NO_HIT)
+    __device__ __forceinline__ void store(bool row, int64_t r, bool overflow, bool line, uint8_t *__restrict__ min_e,
+                                          uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots, uint64_t slots_cap,
                                           uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer,
                                           uint32_t *__restrict__ defer_count, unsigned long long *__restrict__ slot_cursor,
                                           uint64_t slot_tag) {
         const int lane = threadIdx.x & 63;
-        const bool defer = row && (overflow || nh > K_SLOTS);
+        bool defer = row && (overflow || nh > K_SLOTS);
         const uint32_t mine = (row && !defer) ? (uint32_t)nh : 0u;
         uint32_t inc = mine;
 #pragma unroll
@@ -57,6 +74,8 @@ struct LaneResult {
         unsigned long long base = 0;
         if (lane == 0 && total) base = atomicAdd(slot_cursor, (unsigned long long)total);
         base = __shfl(base, 0, 64);
+        if (base + total > slots_cap) defer = row;  // wave-uniform: no room for this wave's lists
+        if (line) store_min_e_line(min_e, r - lane, (row && !defer && mine) ? (uint32_t)best : (uint32_t)SCT_NO_HIT);
         if (!row) return;
         if (defer) {
             const uint32_t k = atomicAdd(defer_count, 1u);
@@ -66,7 +85,7 @@ struct LaneResult {
         }
         cnt[r] = mine;
         if (mine == 0) {
-            min_e[r] = SCT_NO_HIT;
+            if (!line) min_e[r] = SCT_NO_HIT;
             return;
         }
         if (nh > 1) {  // sort ascending: odd-even transposition network on registers
@@ -83,7 +102,7 @@ struct LaneResult {
                 }
             }
         }
-        min_e[r] = (uint8_t)best;
+        if (!line) min_e[r] = (uint8_t)best;
         const uint64_t start = base + inc - mine;
         slot_off[r] = start | slot_tag;
 #pragma unroll
@@ -93,64 +112,7 @@ struct LaneResult {
 };
 
 // ------------------------------------------------------------------------------------------------------------
-// k_filter_lane<E> (first version, kept for A/B: option "filter_mode" = 1): one lane per segment, each lane walks
-// its own buckets and verifies its own candidates; lanes idle while the longest bucket of the wave is walked.
-// ------------------------------------------------------------------------------------------------------------
-template <int E>
-struct FilterLane {
-    const uint32_t *__restrict__ tab_off;
-    const uint32_t *__restrict__ tab_ent;
-    const uint2 *__restrict__ pat;
-    int np;
-    uint32_t tls, ths, ve, va;
-    LaneResult<E> res;
-
-    __device__ __forceinline__ void operator()(int f, uint32_t key) {
-        const uint32_t *off = tab_off + (size_t)f * (SCT_KEYS + 1) + key;
-        const uint32_t s = off[0], e = off[1];
-        for (uint32_t k = s; k < e; k++) {  // offsets index the concatenated entry table
-            const uint32_t pid = tab_ent[k];
-            const uint2 p = pat[pid];
-            res.add(wm_verify<E>(tls, ths, ve, va, p.x, p.y, 16), pid);
-        }
-    }
-};
-
-template <int E>
-__global__ void __launch_bounds__(256)
-k_filter_lane(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
-              int64_t n, const uint32_t *__restrict__ tab_off, const uint32_t *__restrict__ tab_ent,
-              const uint2 *__restrict__ pat, int np, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt,
-              uint32_t *__restrict__ slots, uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_scan,
-              uint32_t *__restrict__ counters) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = r < n;
-    if (active) active = cnt[r] != CNT_DEFER;  // routed to a scan path by k_pack
-    int len = 0;
-    if (active) {
-        len = (int)(meta_in[r] & 0xFF);
-        active = len >= 16 - E;  // shorter rows were finished by k_pack
-    }
-    FilterLane<E> L;
-    L.res.init();
-    if (active) {
-        const uint32_t lo = (uint32_t)lo_in[r], hi = (uint32_t)hi_in[r];
-        L.tab_off = tab_off;
-        L.tab_ent = tab_ent;
-        L.pat = pat;
-        L.np = np;
-        L.tls = lo << 1;
-        L.ths = hi << 1;
-        L.va = len >= 31 ? 0xFFFFFFFFu : ((1u << (len + 1)) - 1u);
-        L.ve = L.va & ~1u;
-        sct_for_each_seed<E, uint32_t>(lo, hi, len, L);
-    }
-    L.res.store(active, r, false, min_e, cnt, slots, slot_off, list_scan, counters + 0,
-                reinterpret_cast<unsigned long long *>(counters + 4), 0ull);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// k_filter<E> (default): one WAVE per 64 segments, cooperating through LDS so that verification always runs on
+// k_filter<E>: one WAVE per 64 segments, cooperating through LDS so that verification always runs on
 // full waves.  The seed families are processed one after the other; within a family
 //   lookup   every lane computes the seed key of its own segment for the current placement (t, t2) — the
 //            placements are walked wave-uniformly up to the longest segment of the wave — and reads its bucket
@@ -206,7 +168,7 @@ struct FilterWaveLds {
     uint16_t ptab[sizeof(W) == 4 ? 128 : 320];  // this family's placements for the longest segment: t | t2 << 8
     uint32_t best[64];   // smallest distance verified so far for the lane's segment
     uint32_t hcnt[64];
-    uint32_t hlist[HM][64];
+    alignas(16) uint32_t hlist[HM][64];  // hlist, qk and qm double as the stage of the ASCII decode (k_decode.hip.h)
     uint32_t qk[QCAP];   // queue: global table entry index f*np + k
     uint32_t qm[QCAP];   //        lane | t << 8 | t2 << 16
 };
@@ -609,12 +571,6 @@ struct FilterWave {
     }
 };
 
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
 // W = uint32_t handles the waves whose longest segment has at most 31 characters, W = uint64_t the others
 // (up to 63); both instantiations are launched over all rows and a wave leaves at once if it is not its kind.
 // THIRDS = true (max_err <= 1 only) walks the 20/22-bit families of the thirds scheme instead of the quarters.
@@ -623,41 +579,106 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // (16 listed rows per wave), and only what that launch defers again goes to the exhaustive scan.
 // RT = true: barcode length `bl` (8..16) other than 16, piece boundaries computed at run time (sct_family_rt).
 // SL = true: lookups read bucket slots (FilterWave); chosen by the host while few buckets are longer than a slot.
-template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT, bool SL>
-__global__ void __launch_bounds__(256)
-k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in, const uint32_t *__restrict__ meta_in,
-         int64_t n, const int32_t *__restrict__ rows, const uint32_t *__restrict__ tab_off,
-         const uint32_t *__restrict__ tab_ent, const uint32_t *__restrict__ tab_code,
-         const uint2 *__restrict__ tab_slot, FamTables ft, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots,
-         uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer, uint32_t *__restrict__ defer_count,
-         unsigned long long *__restrict__ slot_cursor, uint64_t slot_tag, int bl_arg) {
-    const int bl = RT ? bl_arg : 16;
-    __shared__ FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value> lds[4];
-    FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value> &L = lds[threadIdx.x >> 6];
+// OffT: type of the CSR offsets (FilterArgs).
+//
+// Everything a launch needs besides its template parameters.
+template <typename OffT>
+struct FilterArgs {
+    const uint8_t *segs;          // the rows' ASCII bytes (padded by 64 bytes past the end)
+    const OffT *offs;             // CSR offsets of the rows: int64 (resident upload) or uint32 relative to the chunk (stream)
+    int64_t seg_bytes;
+    int64_t n;                    // rows (main launch) / listed rows (retry launch) ...
+    const uint32_t *n_dev;        // ... or, if not NULL, where that number lives on the device (the retry launch is queued
+                                  // before the host knows how many rows the main launch handed over)
+    const int32_t *rows;          // NULL = all rows; else the listed rows (retry launch)
+    const uint32_t *tab_off, *tab_ent, *tab_code;
+    const uint2 *tab_slot;
+    FamTables ft;
+    uint8_t *min_e;
+    uint32_t *cnt;
+    uint32_t *slots;
+    uint64_t slots_cap;
+    uint64_t *slot_off;
+    int32_t *list_defer;          // main launch: list_retry; retry launch: list_scan
+    uint32_t *defer_count;
+    int32_t *list_long, *list_dp; // routing lists of the main launch (rows the filter cannot take)
+    uint32_t *ctr;                // the batch's counter record (CTR_*)
+    unsigned long long *slot_cursor;
+    uint64_t slot_tag;
+    int bl, prefix_len;
+};
+
+// One wave's RPW rows, starting at row (or list position) `first`.
+template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT, bool SL, typename OffT>
+__device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value> &L, int64_t first,
+                                            int64_t n) {
+    const int bl = RT ? a.bl : 16;
     const int lane = threadIdx.x & 63;
-    // RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows, so that the pair
-    // compaction of run_family spreads each row's lookups over four lanes and the few retried rows finish sooner
-    const int64_t gid = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * RPW + lane;
-    bool active = lane < RPW && gid < n;
+    const int64_t gid = first + lane;
+    const bool inrange = lane < RPW && gid < n;
     int64_t r = gid;
-    int len = 0;
-    if (active) {
-        // per-row data is read once: non-temporal, so that it does not push the seed tables out of the L2
-        if (rows) r = rows[gid];                       // a retried row: listed explicitly
-        else active = __builtin_nontemporal_load(&cnt[r]) != CNT_DEFER;  // routed to a scan path by k_pack
-    }
-    if (active) {
-        len = (int)(__builtin_nontemporal_load(&meta_in[r]) & 0xFF);
-        active = len >= bl - E;  // shorter rows were finished by k_pack
-    }
-    if (!active) len = 0;
+    if (inrange && a.rows) r = a.rows[gid];  // a retried row: listed explicitly
+    int64_t start = 0, len64 = 0;
+    if (inrange) sct_row_span(a.offs, r, a.seg_bytes, start, len64);
+    const int len_all = (int)(len64 < 0x7FFFFFFF ? len64 : 0x7FFFFFFF);
+    // rows the filter can take by their length: at least bl - E characters (shorter ones cannot match anything: every
+    // window the reference inserts is at least that long, scTagger.py:681) and at most PLANE_MAX
+    const bool fits = inrange && len_all >= bl - E && len_all <= PLANE_MAX;
+    int len = fits ? len_all : 0;
     const int maxlen = wave_max_i(len);
-    if (maxlen == 0) return;  // the whole wave has nothing to do
-    if ((maxlen <= 31) != (sizeof(W) == 4)) return;  // the other instantiation's wave
-    W lo = 0, hi = 0;
-    if (active) {
-        lo = (W)__builtin_nontemporal_load(&lo_in[r]);
-        hi = (W)__builtin_nontemporal_load(&hi_in[r]);
+    // W = uint32_t handles the waves whose longest such row has at most 31 characters (waves without any included:
+    // their rows still have to be routed), W = uint64_t the others; a wave leaves at once if it is not its kind
+    if ((maxlen <= 31) != (sizeof(W) == 4)) return;
+    if (__ballot(inrange) == 0) return;
+    W lo, hi;
+    bool nonacgt;
+    {
+        using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value>;
+        static_assert(__builtin_offsetof(Lds, qk) == __builtin_offsetof(Lds, hlist) + 4 * 64 * HM &&
+                          __builtin_offsetof(Lds, qm) == __builtin_offsetof(Lds, qk) + 4 * Lds::QCAP && __builtin_offsetof(Lds, hlist) % 16 == 0,
+                      "hlist, qk and qm form the decode stage");
+        constexpr int STAGE_BYTES = 4 * (64 * HM + 2 * Lds::QCAP);
+        // all rows: one coalesced pass over the wave's stretch of bytes; listed rows lie anywhere: word by word
+        if (a.rows != nullptr || !sct_decode_rows_staged<W>(a.segs, start, len, &L.hlist[0][0], STAGE_BYTES, lo, hi, nonacgt))
+            sct_decode_row<W>(a.segs, start, len, lo, hi, nonacgt);
+    }
+    if (__ballot(nonacgt) != 0) {
+        // rare: is one of the offending bytes >= 128?  The reference indexes map_char with it (scTagger.py:512-516, :555) and raises
+        if (nonacgt) {
+            for (int i = 0; i < len; i++)
+                if (a.segs[start + i] >= 128) {
+                    atomicMin(reinterpret_cast<unsigned long long *>(a.ctr + CTR_BAD_BYTE), (unsigned long long)(start + i));
+                    break;
+                }
+        }
+    }
+    bool active = fits;
+    // all 64 rows of the wave exist and lie side by side: their min_e bytes go out as one 64-byte line
+    const bool line = a.rows == nullptr && first + 64 <= n && (((uintptr_t)(a.min_e + first)) & 15) == 0;
+    if (a.rows == nullptr && inrange) {
+        // routing (main launch): what k_pack did in round 1
+        if (!fits) {
+            if (len_all > PLANE_MAX) {  // not representable in the planes: the exhaustive scan or the DP takes the row
+                a.list_long[atomicAdd(&a.ctr[CTR_LONG], 1u)] = (int32_t)r;
+                a.cnt[r] = CNT_DEFER;
+            } else {
+                if (!line) a.min_e[r] = SCT_NO_HIT;
+                a.cnt[r] = 0;
+            }
+        } else if (nonacgt && a.prefix_len > 0) {
+            // the reference drops every window whose first k raw bytes are not all in ACGT (scTagger.py:681): restricted-start DP
+            a.list_dp[atomicAdd(&a.ctr[CTR_DP], 1u)] = (int32_t)r;
+            a.cnt[r] = CNT_DEFER;
+            active = false;
+        }
+    }
+    if (!active) {
+        len = 0;
+        lo = hi = 0;
+    }
+    if (__ballot(active) == 0) {  // the whole wave has nothing to filter
+        if (line) store_min_e_line(a.min_e, first, SCT_NO_HIT);
+        return;
     }
     const W va = sct_valid_mask<W>(len);
     const W ve = va & ~(W)1, l1 = lo << 1, h1 = hi << 1;
@@ -673,7 +694,7 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     static_assert(!(SL && (THIRDS || RT)), "bucket slots exist for the 16-character quarter families only");
-    FilterWave<E, W, HM, SL> W_{L, tab_off, tab_ent, tab_code, tab_slot, ft, lane, active, len, lo, hi};
+    FilterWave<E, W, HM, SL> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.ft, lane, active, len, lo, hi};
 #define RUN_FAMILY(FID)                                                         \
     do {                                                                        \
         if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \
@@ -727,6 +748,39 @@ k_filter(const uint64_t *__restrict__ lo_in, const uint64_t *__restrict__ hi_in,
         const uint32_t v = L.hlist[k][lane];
         res.add((int)(v >> 30), v & LOC_MASK);
     }
-    res.store(active, r, nc > (uint32_t)HM, min_e, cnt, slots, slot_off, list_defer, defer_count, slot_cursor, slot_tag);
+    res.store(active, r, nc > (uint32_t)HM, line, a.min_e, a.cnt, a.slots, a.slots_cap, a.slot_off, a.list_defer, a.defer_count, a.slot_cursor,
+              a.slot_tag);
 }
 
+// RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows, so that the pair compaction of
+// run_family spreads each row's lookups over four lanes and the few retried rows finish sooner.  The waves
+// of the retry launch — whose row count only exists on the device when it is queued — and of the 64-bit instantiation —
+// which usually has nothing to do — come as a small fixed grid and stride over the rows.
+// Waves per workgroup: four for the main launch's 32-bit instantiation; ONE for the striding launches.  Their blocks then
+// need a quarter of the LDS (10 - 20 KB instead of 40 - 80 KB) and fit into whatever a retiring block of another chunk's main
+// launch frees on a CU; as four-wave blocks they waited until that other grid had been dispatched to its last block
+// (profiles/r02_stream_timeline_zero_copy_3lanes.txt: 0.9 ms for a launch that takes 10 us alone).
+template <typename W, int RPW>
+struct FilterWavesPerBlock {
+    static constexpr int value = (RPW == 64 && sizeof(W) == 4) ? 4 : 1;
+};
+
+template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT, bool SL, typename OffT>
+__global__ void __launch_bounds__(256)
+k_filter(const FilterArgs<OffT> a) {
+    constexpr int WPB = FilterWavesPerBlock<W, RPW>::value;
+    __shared__ FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value> lds[WPB];
+    const int64_t n = a.n_dev ? (int64_t)*a.n_dev : a.n;
+    const int64_t first = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * RPW;
+    if constexpr (WPB == 4) {
+        // the main launch's 32-bit instantiation — where the time goes — is launched over all rows and stays loop-free:
+        // wrapped in the loop below the compiler hoists enough address arithmetic out of it to cost two waves per SIMD
+        if (first < n) filter_rows<E, W, THIRDS, KS, HM, RPW, RT, SL, OffT>(a, lds[threadIdx.x >> 6], first, n);
+    } else {
+        const int64_t step = (int64_t)gridDim.x * WPB * RPW;
+        for (int64_t f = first; f < n; f += step) {
+            filter_rows<E, W, THIRDS, KS, HM, RPW, RT, SL, OffT>(a, lds[0], f, n);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}

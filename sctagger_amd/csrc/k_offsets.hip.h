@@ -1,9 +1,10 @@
-// k_offsets.hip.h — hit-count scan into CSR offsets and k_fill.
-// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, pack, filter, scan,
+// k_offsets.hip.h — prefix sums (hit counts -> CSR offsets, row lengths -> row offsets), the index-format kernels of the
+// stream path, and k_fill.
+// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, decode, filter, scan,
 // offsets, whitelist, adapter, validate).  gfx950 only.
 #pragma once
 // ------------------------------------------------------------------------------------------------------------
-// exclusive scan of cnt[n] (u32) into hit_offs[n+1] (i64): per-block sums, one-block scan of the sums, offsets
+// exclusive scan over n items: per-block sums, one-block scan of the sums, per-item offsets
 // ------------------------------------------------------------------------------------------------------------
 static constexpr int SCAN_ITEMS = 8;                       // per thread
 static constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;        // elements per block
@@ -28,13 +29,53 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *t
     return r;
 }
 
-__global__ void __launch_bounds__(256) k_sum_blocks(const uint32_t *__restrict__ cnt, int64_t n, uint64_t *__restrict__ sums) {
+// what an item contributes: a hit count (rows still marked CNT_DEFER wait for the slow path and count as 0) or a row length
+template <typename T>
+__device__ __forceinline__ uint64_t scan_value(T v) { return (uint64_t)v; }
+template <>
+__device__ __forceinline__ uint64_t scan_value<uint32_t>(uint32_t v) { return v == CNT_DEFER ? 0ull : (uint64_t)v; }
+
+// a thread's SCAN_ITEMS consecutive items; one- and two-byte items (row lengths, possibly read in place from page-locked
+// host memory) come as ONE 8- or 16-byte load when the address allows it
+template <typename T>
+__device__ __forceinline__ void load_scan_items(const T *__restrict__ in, int64_t base, int64_t n, uint64_t (&v)[SCAN_ITEMS]) {
+    static_assert(SCAN_ITEMS == 8, "the wide loads below fetch eight items");
+    if constexpr (sizeof(T) == 1) {
+        if (base + SCAN_ITEMS <= n && ((uintptr_t)(in + base) & 7) == 0) {
+            const uint64_t w = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(in + base));
+#pragma unroll
+            for (int i = 0; i < SCAN_ITEMS; i++) v[i] = (w >> (8 * i)) & 0xFFu;
+            return;
+        }
+    } else if constexpr (sizeof(T) == 2) {
+        if (base + SCAN_ITEMS <= n && ((uintptr_t)(in + base) & 15) == 0) {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            const u4 w = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(in + base));
+            v[0] = w.x & 0xFFFFu; v[1] = w.x >> 16; v[2] = w.y & 0xFFFFu; v[3] = w.y >> 16;
+            v[4] = w.z & 0xFFFFu; v[5] = w.z >> 16; v[6] = w.w & 0xFFFFu; v[7] = w.w >> 16;
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) v[i] = base + i < n ? scan_value<T>(in[base + i]) : 0ull;
+}
+
+// `keep` != NULL: the items are also written there (a device copy of an index that was read in place from host memory, so
+// that the second pass of the scan does not cross the link again)
+template <typename T>
+__global__ void __launch_bounds__(256) k_sum_blocks(const T *__restrict__ in, int64_t n, uint64_t *__restrict__ sums, T *__restrict__ keep) {
     __shared__ uint64_t lds[8];
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    load_scan_items<T>(in, base, n, v);
     uint64_t s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++)
-        if (base + i < n) s += cnt[base + i];
+    for (int i = 0; i < SCAN_ITEMS; i++) s += v[i];
+    if (keep) {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++)
+            if (base + i < n) keep[base + i] = (T)v[i];
+    }
     uint64_t total;
     block_exclusive_scan(s, &total, lds);
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
@@ -54,34 +95,71 @@ __global__ void __launch_bounds__(256) k_scan_sums(uint64_t *__restrict__ sums, 
     if (threadIdx.x == 0) *total_out = carry;
 }
 
+// hit counts -> hit_offs[n+1] (int64, relative to the batch) and, on request, the counts in the caller's compact
+// format: cnt8 (uint8, a row with more than 255 hits raises CTR_CNT_OVERFLOW) or cnt32
 __global__ void __launch_bounds__(256) k_offsets(const uint32_t *__restrict__ cnt, int64_t n, const uint64_t *__restrict__ sums,
-                                                  const uint64_t *__restrict__ total, int64_t *__restrict__ hit_offs) {
+                                                  const uint64_t *__restrict__ total, int64_t *__restrict__ hit_offs,
+                                                  uint8_t *__restrict__ cnt8, uint32_t *__restrict__ cnt32, uint32_t *__restrict__ ctr) {
     __shared__ uint64_t lds[8];
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint64_t s = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
-        v[i] = base + i < n ? cnt[base + i] : 0u;
+        v[i] = base + i < n ? (uint32_t)scan_value<uint32_t>(cnt[base + i]) : 0u;
         s += v[i];
     }
     uint64_t tot;
     uint64_t run = sums[blockIdx.x] + block_exclusive_scan(s, &tot, lds);
+    bool over = false;
+    // the compact counts go out as one 8-byte (cnt8) or two 16-byte (cnt32) stores per thread where the address allows it:
+    // they may be the caller's page-locked arrays, where every store instruction is a PCIe write of its own
+    const bool whole = base + SCAN_ITEMS <= n;
+    const bool wide8 = cnt8 && whole && ((uintptr_t)(cnt8 + base) & 7) == 0;
+    const bool wide32 = cnt32 && whole && ((uintptr_t)(cnt32 + base) & 15) == 0;
+    uint64_t pack8 = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
-        if (base + i < n) hit_offs[base + i] = (int64_t)run;
+        if (base + i < n) {
+            hit_offs[base + i] = (int64_t)run;
+            if (cnt8) {
+                const uint32_t b = v[i] < 255u ? v[i] : 255u;
+                if (wide8) pack8 |= (uint64_t)b << (8 * i);
+                else cnt8[base + i] = (uint8_t)b;
+                over |= v[i] > 255u;
+            }
+            if (cnt32 && !wide32) cnt32[base + i] = v[i];
+        }
         run += v[i];
     }
+    if (wide8) *reinterpret_cast<uint64_t *>(cnt8 + base) = pack8;
+    if (wide32) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        static_assert(SCAN_ITEMS == 8, "two 16-byte stores");
+        *reinterpret_cast<u4 *>(cnt32 + base) = u4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<u4 *>(cnt32 + base + 4) = u4{v[4], v[5], v[6], v[7]};
+    }
+    if (over) atomicOr(&ctr[CTR_CNT_OVERFLOW], 1u);
     if (blockIdx.x == 0 && threadIdx.x == 0) hit_offs[n] = (int64_t)*total;
+}
+
+// hit_offs += base (the hits of the earlier chunks of a stream call), in place, n + 1 entries
+__global__ void __launch_bounds__(256) k_rebase(int64_t *__restrict__ hit_offs, int64_t n1, int64_t base) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n1) hit_offs[i] += base;
 }
 
 // filter path: slots -> CSR
 __global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ slots,
                                                const uint32_t *__restrict__ slots_retry,
                                                const uint64_t *__restrict__ slot_off, const int64_t *__restrict__ hit_offs,
-                                               const uint32_t *__restrict__ route_cnt, int64_t n, uint32_t *__restrict__ hits) {
+                                               const uint32_t *__restrict__ route_cnt, int64_t n, uint32_t *__restrict__ hits,
+                                               uint64_t hits_cap, const uint32_t *__restrict__ ctr) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    // more hits than `hits` can take (only possible when it is the caller-visible page-locked buffer, sized by an estimate):
+    // nothing is written; the host sees the total, enlarges the buffer and fills again
+    if (*reinterpret_cast<const uint64_t *>(ctr + CTR_TOTAL) > hits_cap) return;
     if (route_cnt[r] == CNT_DEFER) return;  // written by the scan path's fill pass
     const uint32_t c = cnt[r];
     const int64_t o = hit_offs[r];
@@ -92,3 +170,79 @@ __global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, 
     for (uint32_t i = 0; i < c; i++) hits[o + i] = src[at + i];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Index formats of the stream path (include/sctagger_hip.h: SCT_IDX_*): the caller's row index of one chunk ->
+// uint32 offsets relative to the chunk's first byte, checked on the way (CTR_BAD_ROW = smallest offending row of the
+// chunk).  Offsets: n + 1 entries in[0..n] are uploaded, out[i] = in[i] - in[0]; they must not decrease and must end
+// at `bytes`.  Lengths: n entries, out = their exclusive prefix sum (k_sum_blocks / k_scan_sums first).
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_index_offs(const T *__restrict__ in, int64_t n, int64_t bytes, uint32_t *__restrict__ out,
+                                                     unsigned long long *__restrict__ bad_row) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const int64_t base = (int64_t)in[0];
+    const int64_t a = (int64_t)in[i] - base;
+    bool bad = a < 0 || a > bytes;
+    if (i < n) bad |= (int64_t)in[i + 1] < (int64_t)in[i];
+    else bad |= a != bytes;
+    if (bad) atomicMin(bad_row, (unsigned long long)(i < n ? i : (n > 0 ? n - 1 : 0)));
+    out[i] = (uint32_t)(a < 0 ? 0 : (a > bytes ? bytes : a));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_index_lens(const T *__restrict__ lens, int64_t n, const uint64_t *__restrict__ sums,
+                                                     const uint64_t *__restrict__ total, int64_t bytes, uint32_t *__restrict__ out,
+                                                     unsigned long long *__restrict__ bad_row) {
+    __shared__ uint64_t lds[8];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    load_scan_items<T>(lens, base, n, v);
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) s += v[i];
+    uint64_t tot;
+    uint64_t run = sums[blockIdx.x] + block_exclusive_scan(s, &tot, lds);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = (uint32_t)(run < (uint64_t)bytes ? run : (uint64_t)bytes);
+        run += v[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[n] = (uint32_t)(*total < (uint64_t)bytes ? *total : (uint64_t)bytes);
+        if (*total != (uint64_t)bytes) atomicMin(bad_row, (unsigned long long)(n > 0 ? n - 1 : 0));
+    }
+}
+
+// uint32 chunk offsets -> int64 (the scan kernels of the slow path take int64 offsets)
+__global__ void __launch_bounds__(256) k_widen_offs(const uint32_t *__restrict__ in, int64_t n1, int64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n1) out[i] = (int64_t)in[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_route_all: routing without the filter kernel (barcode lengths or error budgets the seed filter does not cover, or
+// option force_exhaustive): one lane per row.  Rows shorter than bl - max_err are finished here; the others go to the
+// restricted-start DP (a byte outside ACGT while the reference's prefix length k > 0) or to the exhaustive scan.
+// ------------------------------------------------------------------------------------------------------------
+template <typename OffT>
+__global__ void __launch_bounds__(256)
+k_route_all(const uint8_t *__restrict__ segs, const OffT *__restrict__ offs, int64_t seg_bytes, int64_t n, int bl, int max_err,
+            int prefix_len, uint8_t *__restrict__ min_e, uint32_t *__restrict__ cnt, int32_t *__restrict__ list_scan,
+            int32_t *__restrict__ list_dp, uint32_t *__restrict__ ctr) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int64_t b0, len;
+    sct_row_span(offs, r, seg_bytes, b0, len);
+    if (len < bl - max_err) {
+        min_e[r] = SCT_NO_HIT;
+        cnt[r] = 0;
+        return;
+    }
+    bool nonacgt = false;
+    if (prefix_len > 0)
+        for (int64_t i = 0; i < len; i++) nonacgt |= !sct_is_acgt(segs[b0 + i]);
+    if (nonacgt) list_dp[atomicAdd(&ctr[CTR_DP], 1u)] = (int32_t)r;
+    else list_scan[atomicAdd(&ctr[CTR_SCAN], 1u)] = (int32_t)r;
+    cnt[r] = CNT_DEFER;
+}

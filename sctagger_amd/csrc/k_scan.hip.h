@@ -1,5 +1,5 @@
 // k_scan.hip.h — the exhaustive scan path: k_scan, k_scan_pk, k_scan_reduce.
-// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, pack, filter, scan,
+// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, decode, filter, scan,
 // offsets, whitelist, adapter, validate).  gfx950 only.
 #pragma once
 // ------------------------------------------------------------------------------------------------------------
@@ -23,7 +23,7 @@ static constexpr int DP_BIG = 100;
 
 template <bool DP, bool FILL>
 __global__ void __launch_bounds__(256)
-k_scan(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const int32_t *__restrict__ list,
+k_scan(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, int64_t seg_bytes, const int32_t *__restrict__ list,
        int64_t n_list, int n_slices, const uint2 *__restrict__ pat, int np, int bl, int max_err, int prefix_len,
        const uint8_t *__restrict__ min_e, uint32_t *__restrict__ part_best, uint32_t *__restrict__ part_cnt,
        const int64_t *__restrict__ hit_offs, uint32_t *__restrict__ hits) {
@@ -36,8 +36,8 @@ k_scan(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const
         const int64_t li = w / n_slices;
         const int slice = (int)(w - li * n_slices);
         const int64_t r = (int64_t)list[li];
-        const int64_t b0 = offs[r];
-        const int64_t len = offs[r + 1] - b0;
+        int64_t b0, len;
+        sct_row_span(offs, r, seg_bytes, b0, len);
         const int p_begin = slice * tiles_per_slice * 64;
         const int p_end = min(np, p_begin + tiles_per_slice * 64);
         int target = 0;
@@ -166,7 +166,7 @@ __device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) {
 
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-k_scan_pk(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, const int32_t *__restrict__ list,
+k_scan_pk(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, int64_t seg_bytes, const int32_t *__restrict__ list,
           int64_t n_list, int n_slices, const uint2 *__restrict__ pat, int np, int bl, int max_err,
           const uint8_t *__restrict__ min_e, uint32_t *__restrict__ part_best, uint32_t *__restrict__ part_cnt,
           const int64_t *__restrict__ hit_offs, uint32_t *__restrict__ hits) {
@@ -180,8 +180,8 @@ k_scan_pk(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, co
         const int64_t li = w / n_slices;
         const int slice = (int)(w - li * n_slices);
         const int64_t r = (int64_t)list[li];
-        const int64_t b0 = offs[r];
-        const int64_t len = offs[r + 1] - b0;
+        int64_t b0, len;
+        sct_row_span(offs, r, seg_bytes, b0, len);
         const int p_begin = slice * tiles_per_slice * 64;
         const int p_end = min(np, p_begin + tiles_per_slice * 64);
         int target = 0;
@@ -290,3 +290,30 @@ k_scan_reduce(const int32_t *__restrict__ list, int64_t n_list, int n_slices, in
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// k_route_long: rows longer than PLANE_MAX characters, which the filter kernel only listed (list_long): one wave per
+// row decides between the exhaustive Myers scan and, when the reference's prefix length k > 0 and the row holds a byte
+// that is not one of ACGT, the restricted-start DP (scTagger.py:681).  Runs on the slow path only.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_route_long(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, int64_t seg_bytes, const int32_t *__restrict__ list_long,
+             int64_t n_long, int prefix_len, int32_t *__restrict__ list_scan, int32_t *__restrict__ list_dp, uint32_t *__restrict__ ctr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t li = wave; li < n_long; li += n_waves) {
+        const int64_t r = list_long[li];
+        bool bad = false;
+        if (prefix_len > 0) {
+            int64_t b0, len;
+            sct_row_span(offs, r, seg_bytes, b0, len);
+            for (int64_t i = lane; i < len; i += 64) bad |= !sct_is_acgt(segs[b0 + i]);
+        }
+        const bool dp = __ballot(bad) != 0;
+        if (lane == 0) {
+            if (dp) list_dp[atomicAdd(&ctr[CTR_DP], 1u)] = (int32_t)r;
+            else list_scan[atomicAdd(&ctr[CTR_SCAN], 1u)] = (int32_t)r;
+        }
+    }
+}

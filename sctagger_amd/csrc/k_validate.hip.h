@@ -1,5 +1,5 @@
 // k_validate.hip.h — k_validate: device-side input checks.
-// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, pack, filter, scan,
+// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, decode, filter, scan,
 // offsets, whitelist, adapter, validate).  gfx950 only.
 #pragma once
 // ------------------------------------------------------------------------------------------------------------
@@ -10,7 +10,7 @@ __global__ void __launch_bounds__(256)
 k_validate(const uint8_t *__restrict__ segs, int64_t bytes, const int64_t *__restrict__ offs, int64_t n,
            unsigned long long *__restrict__ bad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
+    if (offs && i < n) {  // offs == NULL: the bytes only (the stream path checks its index in k_index_*)
         const int64_t a = offs[i], b = offs[i + 1];
         if (b < a || a < 0 || b > bytes) atomicMin(&bad[0], (unsigned long long)i);
     }

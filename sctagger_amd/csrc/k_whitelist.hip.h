@@ -1,5 +1,5 @@
 // k_whitelist.hip.h — k_wl_count: extract_sr_bc_from_lr whitelist probes.
-// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, pack, filter, scan,
+// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, decode, filter, scan,
 // offsets, whitelist, adapter, validate).  gfx950 only.
 #pragma once
 // ------------------------------------------------------------------------------------------------------------

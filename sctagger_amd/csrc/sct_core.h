@@ -21,6 +21,26 @@ SCT_HD uint32_t sct_code(uint8_t b) { return b == 'C' ? 1u : b == 'G' ? 2u : b =
 SCT_HD bool sct_is_acgt(uint8_t b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
 
 // ---------------------------------------------------------------------------------------------------
+// Four ASCII bytes at once (one aligned 32-bit word of a segment) -> three nibbles, bit j = byte j of the word:
+//   lo4, hi4  the two bits of map_char's code (scTagger.py:512-516), 0 where the byte is not one of A C G T
+//   bad4      1 where the byte is not exactly 'A', 'C', 'G' or 'T'
+// A = 0x41, C = 0x43, G = 0x47, T = 0x54: bit 2 of the byte is the high code bit, bit 1 ^ bit 2 the low one.  With
+// d = byte ^ 0x41 the byte is valid iff bits 7, 6, 5, 3 of d are clear and bits 4 and 0 both equal (lo & hi) — only T
+// (d = 0x15) has them set; bits 1 and 2 carry the code.  The bits of interest sit 8 apart; a multiplication whose
+// partial products all land on distinct bit positions moves them next to each other.
+// ---------------------------------------------------------------------------------------------------
+SCT_HD void sct_decode4(uint32_t w, uint32_t &lo4, uint32_t &hi4, uint32_t &bad4) {
+    const uint32_t x = w ^ (w >> 1);                                  // bit 1 of each byte: low code bit
+    const uint32_t d = w ^ 0x41414141u;
+    const uint32_t t = (x >> 1) & (w >> 2) & 0x01010101u;              // both code bits set
+    const uint32_t bad = (d & 0xF9F9F9F9u) ^ (t | (t << 4));           // zero byte <=> valid byte
+    const uint32_t nz = (((bad & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | bad) & 0x80808080u;
+    bad4 = (nz * 0x00204081u) >> 28;
+    lo4 = (((x & 0x02020202u) * 0x00810204u) >> 24) & ~bad4;
+    hi4 = (((w & 0x04040404u) * 0x00408102u) >> 24) & ~bad4;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Myers / Hyyro bit-vector column step, pattern vertical (bit i = pattern row i+1), text streamed.
 // Semi-global: free start in the text (horizontal delta 0 enters row 0), the pattern is matched whole.
 // After the step `score` is D[m][j], the best distance of the pattern to any substring ending at j.

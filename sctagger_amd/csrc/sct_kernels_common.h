@@ -1,5 +1,5 @@
 // sct_kernels_common.h — shared constants of the match_trie kernels.
-// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, pack, filter, scan,
+// Part of libsctagger_hip.so; included by sctagger_hip.hip (in this order: common, decode, filter, scan,
 // offsets, whitelist, adapter, validate).  gfx950 only.
 #pragma once
 static constexpr int K_SLOTS = 8;          // hits kept per segment by the filter kernel before it defers
@@ -10,7 +10,31 @@ static constexpr uint32_t CNT_DEFER = 0xFFFFFFFFu;
 // e <= 1: 50 k 0.54 / 0.51, 70 k (17 %) 0.58 / 0.76.
 static constexpr double SLOTS_MAX_LONG_SHARE_E2 = 0.035, SLOTS_MAX_LONG_SHARE_E1 = 0.10;
 static constexpr int THIRDS_MIN_PATTERNS = 1 << 19;  // from here on (8 barcodes per 16-bit bucket) the thirds scheme pays
-static constexpr int META_NONACGT = 1 << 8;
-static constexpr int META_LONG = 1 << 9;   // more than 63 characters: not representable in the filter's planes
 static constexpr int PLANE_MAX = 63;       // characters kept in the packed bit-planes
 
+// Per-batch device counters (one 64-byte record per lane, read back by the host in ONE copy when the batch is done).
+// 32-bit words:
+enum {
+    CTR_SCAN = 0,       // rows listed for the exhaustive scan (list_scan): rows longer than PLANE_MAX, rows the retry launch gave up on
+    CTR_DP = 1,         // rows listed for the restricted-start DP (list_dp): non-ACGT bytes while the reference's prefix length k > 0
+    CTR_RETRY = 2,      // rows the main filter launch hands to the retry launch (list_retry)
+    CTR_LONG = 3,       // rows longer than PLANE_MAX characters, not yet routed (list_long)
+    CTR_CURSOR = 4,     // (64-bit, words 4-5)  entries used in the main launch's dense hit slots
+    CTR_CURSOR_RETRY = 6,  // (64-bit, words 6-7)  the same for the retry launch
+    CTR_BAD_ROW = 8,    // (64-bit, words 8-9)  smallest row whose index entry is invalid, ~0 = none
+    CTR_BAD_BYTE = 10,  // (64-bit, words 10-11) smallest offset of a segment byte >= 128, ~0 = none
+    CTR_CNT_OVERFLOW = 12,  // a row's hit count did not fit the requested count format
+    CTR_TOTAL = 14,     // (64-bit, words 14-15) total number of hits of the batch
+    CTR_WORDS = 16
+};
+
+// Start and length of row r from its CSR offsets, forced into [0, bytes] so that no kernel reads outside the segment
+// buffer even if the caller's index is inconsistent (the inconsistency itself is reported through CTR_BAD_ROW).
+template <typename OffT>
+__device__ __forceinline__ void sct_row_span(const OffT *__restrict__ offs, int64_t r, int64_t bytes, int64_t &start, int64_t &len) {
+    int64_t a = (int64_t)offs[r], b = (int64_t)offs[r + 1];
+    a = a < 0 ? 0 : (a > bytes ? bytes : a);
+    b = b < a ? a : (b > bytes ? bytes : b);
+    start = a;
+    len = b - a;
+}

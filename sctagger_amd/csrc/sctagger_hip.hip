@@ -1,41 +1,52 @@
-// sctagger_hip.hip — contexts, seed-table construction, kernel launches and the C-ABI (include/sctagger_hip.h);
-// the gfx950 kernels themselves are in the k_*.hip.h headers included below.
+// sctagger_hip.hip — contexts, lanes, seed-table construction, kernel launches and the C-ABI (include/sctagger_hip.h);
+// the gfx950 kernels themselves are in the k_*.hip.h headers included below and, for the seed filter, in the three
+// translation units filter_e0/1/2.hip.
 //
 // match_trie (reference scTagger.py:643-716, observable semantics in SURVEY.md §8(a)-Q): for every long-read
 // segment the minimum infix edit distance (<= max_err) to any barcode on either strand, and the sorted list of
 // all (bid, strand) at that minimum.  The reference gets there with a trie of segment windows and a recursive
 // DFS per barcode; none of that is imitated here.
 //
-// Device data (all in HBM, resident for the life of the context / upload):
+// Device data:
 //   patterns   np = 2*n_bc entries, index p = bid*2 + strand (strand 1 = forward, 0 = reverse complement, so
 //              ascending p is the reference's sorted(bids) order), stored as bit-planes uint2{lo, hi}
 //   seed tables (bl 8..16): per family 8-byte bucket slots and an offsets array (65537 entries; 2^20+1 / 2^22+1
 //              offsets, no slots, for the thirds scheme of large barcode sets) and np entries as pattern ids and as
 //              2-bit codes, see sct_core.h and k_filter.hip.h
-//   segments   the caller's CSR bytes + int64 offsets, plus per segment the packed bit-planes {lo, hi, meta}
-//   results    min_e u8[n], cnt u32[n], slot_off u64[n] + dense slots u32[] (filter path), hit_offs i64[n+1],
-//              hits u32[total]
+//   per LANE (a stream with its own buffers; lane 0 serves the resident three-step API, lanes 0..2 the chunks of the
+//   stream API in turn):
+//     segments   the rows' ASCII bytes + CSR offsets (int64 as uploaded, or uint32 relative to the chunk)
+//     results    min_e u8[n], cnt u32[n], slot_off u64[n] + dense slots u32[] (filter path), hit_offs i64[n+1],
+//                hits u32[total], and a 64-byte counter record (CTR_*) the host reads back once per batch
+//
+// A batch (all resident rows, or one chunk) is queued WITHOUT any host synchronisation: main filter launch, retry launch
+// (its row count is read on the device), offsets scan, fill, read-back of the counter record.  Only when that record
+// says that rows went to the lists the filter cannot serve — longer than 63 characters, bytes outside ACGT under the
+// reference's prefix rule, more ties than the retry launch keeps — does the host run the scan kernels for them
+// (slow_path) and redo offsets and fill.
 //
 // Kernels of the match_trie path:
-//   k_pack          ASCII -> bit-planes, routes each segment to the filter / exhaustive / restricted-start path
-//   k_filter<...>   one wave per 64 segments: seed lookups spread over the lanes, candidates queued in LDS and
-//                   verified 64 at a time by the anchored transposed Wu-Manber automaton, tiers, retry launch
-//   k_filter_lane   the first, lane-per-segment version of the filter (option filter_mode = 1, for A/B)
-//   k_scan<...>     one wave per (segment, barcode slice), lanes = barcodes: Myers bit-vector over every barcode
-//                   (any bl <= 32, any max_err) or, for segments with non-ACGT bytes when the reference's prefix
+//   k_filter<...>   one wave per 64 rows: ASCII -> bit-planes (k_decode.hip.h), routing, seed lookups spread over the
+//                   lanes, candidates queued in LDS and verified 128 at a time by the anchored transposed Wu-Manber
+//                   automaton, tiers, retry launch
+//   k_scan<...>     one wave per (row, barcode slice), lanes = barcodes: Myers bit-vector over every barcode
+//                   (any bl <= 32, any max_err) or, for rows with non-ACGT bytes when the reference's prefix
 //                   length k > 0, a plain DP whose row 0 encodes the allowed window starts; count + fill pass
-//   k_sum_* / k_offsets   exclusive scan of the per-segment hit counts into the CSR offsets
+//   k_sum_blocks / k_scan_sums / k_offsets   exclusive scan of the per-row hit counts into the CSR offsets
 //   k_fill          copies the filter path's hit lists into the CSR hit array
+//   k_index_*       stream path: the caller's row index (int64 / int32 offsets, uint8 / uint16 lengths) -> uint32 offsets
 // Kernels of the two neighbouring stages:
 //   k_wl_count                        extract_sr_bc_from_lr: whitelist dictionary probes (scTagger.py:818-826)
 //   k_adapter_count / k_adapter_fill  extract_lr_bc: adapter alignment over whole reads (scTagger.py:176-196)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -62,18 +73,20 @@ static int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(SCT_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-
 #include "sct_kernels_common.h"
-#include "k_pack.hip.h"
+#include "k_decode.hip.h"
 #include "k_filter.hip.h"
+#include "filter_launch.h"
 #include "k_scan.hip.h"
 #include "k_offsets.hip.h"
 #include "k_whitelist.hip.h"
 #include "k_adapter.hip.h"
 #include "k_validate.hip.h"
 
-
-static inline unsigned blocks_for_n(int64_t n, int per) { return (unsigned)((n + per - 1) / per > 0 ? (n + per - 1) / per : 1); }
+static inline unsigned blocks_for(int64_t n, int per) {
+    const int64_t b = (n + per - 1) / per;
+    return (unsigned)(b > 0 ? b : 1);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // host side
@@ -101,42 +114,50 @@ struct DevBuf {
     T *as() const { return (T *)p; }
 };
 
-struct TimedKernel {
+struct TimedSpan {
     const char *name;
     hipEvent_t a, b;
 };
 
-struct sct_ctx {
-    int device = 0;
+// What one batch is run with (set when it is queued, used again by the slow path).
+struct BatchParams {
+    int max_err = 0, threads = 1, prefix_len = 0;
+    bool filter_ok = false, use_slots = false, use_thirds = false, rt_families = false;
+    int count_format = SCT_CNT_OFFS64;  // SCT_CNT_*: which compact form of the counts the offsets kernel also writes
+};
+
+// A lane: one stream with every buffer a batch of rows needs.
+struct Lane {
     hipStream_t stream = nullptr;
-    // barcodes
-    int n_bc = 0, bl = 0, np = 0;
-    bool have_bc = false, have_tables = false, have_thirds = false;
-    FamTables ft{};
-    DevBuf pat, tab_off, tab_ent, tab_code, tab_slot;
-    // segments
+    hipEvent_t done = nullptr;
+    uint32_t *h_ctr = nullptr;  // page-locked copy of the counter record
+    // rows
     int64_t n_seg = -1, seg_bytes = 0;
-    DevBuf segs, offs;
+    bool wide = true;           // offsets are int64 in offs64 (resident upload); else uint32 in offs32 (stream chunk)
+    bool have_offs64 = false;   // offs64 holds this batch's offsets (uploaded, or widened by the slow path)
+    const uint8_t *segs_ptr = nullptr;  // the rows' bytes as the kernels see them: `segs` below, or the caller's page-locked buffer itself
+    const char *host_segs = nullptr;    // zero-copy batches: the same bytes on the host (the slow path copies them to `segs`)
+    DevBuf segs, offs64, offs32, index_in;
     // work / results
-    DevBuf lo, hi, meta, min_e, cnt, route, slots, slots_retry, list_retry, slot_off, list_scan, list_dp, counters, hit_offs, sums, total, hits, part_best, part_cnt;
+    DevBuf min_e, cnt, route, slots, slots_retry, list_retry, slot_off, list_long, list_scan, list_dp, counters, hit_offs, sums, hits,
+        part_best, part_cnt, cnt_out;
+    uint64_t slots_cap = 0, retry_cap = 0;
+    // where the kernels write the results the caller sees: the lane's own buffers (copied out afterwards) or, for a stream
+    // call whose output arrays are page-locked, those arrays themselves through their device mapping
+    uint8_t *min_e_ptr = nullptr;
+    uint8_t *cnt8_ptr = nullptr;
+    uint32_t *cnt32_ptr = nullptr;
+    uint32_t *hits_ptr = nullptr;
+    uint64_t hits_cap = 0;      // entries hits_ptr can take
+    bool direct_min_e = false, direct_cnt = false, direct_hits = false;
+    BatchParams bp;
     int64_t n_hits = 0;
+    int64_t stats[5] = {0, 0, 0, 0, 0};
     bool have_result = false;
-    // whitelist dictionary (extract_sr_bc_from_lr)
-    DevBuf wl_table, wl_counts, wl_first, wl_skip;
-    DevBuf ad_peq, ad_strand, ad_dist, ad_locs, ad_first, ad_last;
-    uint32_t wl_mask = 0, wl_len_set = 0;
-    int32_t wl_n = -1;
-    // options
-    bool force_exhaustive = false, timing = true, no_thirds = false;
-    int slots_mode = -1;       // -1 = by the share of long buckets, 0 = never, 1 = whenever the tables hold them
-    double long_share = 1.0;   // share of the seed keys whose bucket does not fit a slot (sct_set_barcodes)
-    int filter_mode = 0;  // 0 = wave-cooperative k_filter, 1 = k_filter_lane
     // timing
-    std::vector<TimedKernel> timed;
-    std::vector<std::pair<const char *, float>> last_ms;
+    std::vector<TimedSpan> timed;
     std::vector<hipEvent_t> pool;
     size_t pool_used = 0;
-    int64_t stats[5] = {0, 0, 0, 0, 0};
 
     hipEvent_t ev() {
         if (pool_used == pool.size()) {
@@ -146,26 +167,109 @@ struct sct_ctx {
         }
         return pool[pool_used++];
     }
+    uint32_t *ctr() const { return counters.as<uint32_t>(); }
+    void release() {
+        DevBuf *bufs[] = {&segs, &offs64, &offs32, &index_in, &min_e, &cnt, &route, &slots, &slots_retry, &list_retry, &slot_off, &list_long,
+                          &list_scan, &list_dp, &counters, &hit_offs, &sums, &hits, &part_best, &part_cnt, &cnt_out};
+        for (DevBuf *b : bufs) b->release();
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+        if (done) (void)hipEventDestroy(done);
+        if (h_ctr) (void)hipHostFree(h_ctr);
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+        done = nullptr;
+        h_ctr = nullptr;
+    }
+};
+
+static constexpr int STREAM_LANES_MAX = 8;
+
+struct sct_ctx {
+    int device = 0;
+    // barcodes
+    int n_bc = 0, bl = 0, np = 0;
+    bool have_bc = false, have_tables = false, have_thirds = false;
+    FamTables ft{};
+    DevBuf pat, tab_off, tab_ent, tab_code, tab_slot;
+    std::vector<Lane *> lanes;  // lanes[0] always exists
+    // stream API: page-locked result buffer, owned by the context, valid until the next stream call
+    uint32_t *h_hits = nullptr;
+    size_t h_hits_cap = 0;  // entries
+    // whitelist dictionary (extract_sr_bc_from_lr) and adapter alignment (extract_lr_bc): lane 0's rows
+    DevBuf wl_table, wl_counts, wl_first, wl_skip;
+    DevBuf ad_peq, ad_strand, ad_dist, ad_locs, ad_first, ad_last;
+    uint32_t wl_mask = 0, wl_len_set = 0;
+    int32_t wl_n = -1;
+    // options
+    bool force_exhaustive = false, timing = true, no_thirds = false;
+    int slots_mode = -1;       // -1 = by the share of long buckets, 0 = never, 1 = whenever the tables hold them
+    double long_share = 1.0;   // share of the seed keys whose bucket does not fit a slot (sct_set_barcodes)
+    bool zero_copy = true;     // stream API: kernels read page-locked caller buffers in place instead of uploading them
+    int stream_lanes = 5;      // chunks of a stream call in flight (each on a lane of its own)
+    int64_t chunk_rows = 0;    // rows per chunk of the stream API; 0 = chosen by where the caller's buffers live
+    // what the last run / stream call measured and counted
+    struct Span {
+        double ms = 0;
+        int launches = 0;
+    };
+    std::vector<std::pair<const char *, Span>> last_ms;
+    int64_t stats[5] = {0, 0, 0, 0, 0};
+
+    Lane &lane0() { return *lanes[0]; }
 };
 
 struct Timer {
-    sct_ctx *c;
-    TimedKernel t{};
+    Lane *l;
+    TimedSpan t{};
     bool on;
-    Timer(sct_ctx *c_, const char *name) : c(c_), on(c_->timing) {
+    Timer(sct_ctx *c, Lane &lane, const char *name) : l(&lane), on(c->timing) {
         if (!on) return;
         t.name = name;
-        t.a = c->ev();
-        t.b = c->ev();
+        t.a = l->ev();
+        t.b = l->ev();
         if (!t.a || !t.b) { on = false; return; }
-        (void)hipEventRecord(t.a, c->stream);
+        (void)hipEventRecord(t.a, l->stream);
     }
     ~Timer() {
         if (!on) return;
-        (void)hipEventRecord(t.b, c->stream);
-        c->timed.push_back(t);
+        (void)hipEventRecord(t.b, l->stream);
+        l->timed.push_back(t);
     }
 };
+
+// fold a lane's recorded spans into the context's table (the lane's stream must be idle)
+static void collect_timing(sct_ctx *c, Lane &l) {
+    for (const TimedSpan &t : l.timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) continue;
+        bool found = false;
+        for (auto &kv : c->last_ms)
+            if (!strcmp(kv.first, t.name)) {
+                kv.second.ms += ms;
+                kv.second.launches++;
+                found = true;
+                break;
+            }
+        if (!found) c->last_ms.emplace_back(t.name, sct_ctx::Span{(double)ms, 1});
+    }
+    l.timed.clear();
+    l.pool_used = 0;
+}
+
+static int lane_create(Lane **out) {
+    Lane *l = new Lane();
+    hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l->done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&l->h_ctr, sizeof(uint32_t) * CTR_WORDS, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        l->release();
+        delete l;
+        return fail(SCT_E_HIP, "creating a lane: %s", hipGetErrorString(e));
+    }
+    *out = l;
+    return SCT_OK;
+}
 
 extern "C" const char *sct_last_error(void) { return g_err.c_str(); }
 
@@ -197,11 +301,12 @@ extern "C" int sct_create(int device, sct_ctx **out) {
     HIPCHK(hipSetDevice(device));
     sct_ctx *c = new sct_ctx();
     c->device = device;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
+    Lane *l = nullptr;
+    if (int rc = lane_create(&l)) {
         delete c;
-        return fail(SCT_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        return rc;
     }
+    c->lanes.push_back(l);
     *out = c;
     return SCT_OK;
 }
@@ -209,18 +314,20 @@ extern "C" int sct_create(int device, sct_ctx **out) {
 extern "C" void sct_destroy(sct_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->tab_slot, &c->segs, &c->offs, &c->lo, &c->hi, &c->meta, &c->min_e,
-                      &c->cnt, &c->route, &c->slots, &c->slots_retry, &c->list_retry, &c->slot_off, &c->list_scan, &c->list_dp, &c->counters, &c->hit_offs, &c->sums,
-                      &c->total, &c->hits, &c->part_best, &c->part_cnt, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip, &c->ad_peq, &c->ad_strand, &c->ad_dist, &c->ad_locs, &c->ad_first, &c->ad_last};
+    for (Lane *l : c->lanes) {
+        if (l->stream) (void)hipStreamSynchronize(l->stream);
+        l->release();
+        delete l;
+    }
+    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->tab_slot, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip,
+                      &c->ad_peq, &c->ad_strand, &c->ad_dist, &c->ad_locs, &c->ad_first, &c->ad_last};
     for (DevBuf *b : bufs) b->release();
-    for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->h_hits) (void)hipHostFree(c->h_hits);
     delete c;
 }
 
-// page-locked host memory: buffers allocated here move over PCIe by DMA at the full link rate (pageable
-// buffers are staged through a bounce buffer by the runtime)
+// page-locked host memory: buffers allocated here move over PCIe by DMA at the full link rate and asynchronously
+// (copies from or to pageable buffers are staged through a bounce buffer by the runtime and block the calling thread)
 extern "C" void *sct_host_alloc(sct_ctx *c, size_t bytes) {
     if (!c) return nullptr;
     if (hipSetDevice(c->device) != hipSuccess) return nullptr;
@@ -241,7 +348,7 @@ extern "C" void sct_host_free(sct_ctx *c, void *p) {
 extern "C" int sct_sync(sct_ctx *c) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    for (Lane *l : c->lanes) HIPCHK(hipStreamSynchronize(l->stream));
     return SCT_OK;
 }
 
@@ -249,10 +356,16 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return fail(SCT_E_ARG, "sct_set_option: NULL argument");
     if (!strcmp(key, "force_exhaustive")) c->force_exhaustive = value != 0;
     else if (!strcmp(key, "timing")) c->timing = value != 0;
-    else if (!strcmp(key, "filter_mode")) c->filter_mode = (int)value;
     else if (!strcmp(key, "no_thirds")) c->no_thirds = value != 0;
     else if (!strcmp(key, "slots")) c->slots_mode = value < 0 ? -1 : (value != 0);
-    else return fail(SCT_E_ARG, "unknown option '%s'", key);
+    else if (!strcmp(key, "chunk_rows")) {
+        if (value < 0 || value > 0x7FFFFFF0) return fail(SCT_E_ARG, "chunk_rows must be in 0 .. 2^31-16");
+        c->chunk_rows = value;
+    } else if (!strcmp(key, "zero_copy")) c->zero_copy = value != 0;
+    else if (!strcmp(key, "lanes")) {
+        if (value < 1 || value > STREAM_LANES_MAX) return fail(SCT_E_ARG, "lanes must be in 1 .. %d", STREAM_LANES_MAX);
+        c->stream_lanes = (int)value;
+    } else return fail(SCT_E_ARG, "unknown option '%s'", key);
     return SCT_OK;
 }
 
@@ -277,6 +390,12 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
     for (int64_t i = 0; i < (int64_t)n * bl; i++)
         if (b[i] >= 128) return fail(SCT_E_ARG, "barcode %lld contains byte 0x%02x >= 128", (long long)(i / bl), b[i]);
     HIPCHK(hipSetDevice(c->device));
+    // the tables are shared by every lane: nothing may still be reading the old ones
+    for (Lane *l : c->lanes) HIPCHK(hipStreamSynchronize(l->stream));
+    hipStream_t st = c->lane0().stream;
+    c->have_bc = false;
+    c->have_tables = false;
+    c->have_thirds = false;
     const int np = 2 * n;
     std::vector<uint2> pat((size_t)np);
     for (int i = 0; i < n; i++) {
@@ -294,214 +413,293 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
         pat[(size_t)2 * i + 1] = make_uint2(flo, fhi);  // strand 1 = forward
     }
     if (c->pat.ensure(sizeof(uint2) * (size_t)(np ? np : 1))) return SCT_E_HIP;
-    if (np) HIPCHK(hipMemcpyAsync(c->pat.p, pat.data(), sizeof(uint2) * (size_t)np, hipMemcpyHostToDevice, c->stream));
-    c->have_tables = false;
-    c->have_thirds = false;
+    // every copy below reads a host vector of this scope: each path out of the function synchronises the stream first
+    if (np) HIPCHK(hipMemcpyAsync(c->pat.p, pat.data(), sizeof(uint2) * (size_t)np, hipMemcpyHostToDevice, st));
     if (bl >= 8 && bl <= 16) {
         // seed tables (sct_tables.h): counting sort of the pattern ids by key, per family, plus the bucket slots.
         // The thirds families (20/22-bit keys) are only worth their 38 MB of offsets for very large barcode sets.
         const bool thirds = bl == 16 && np >= THIRDS_MIN_PATTERNS;
         SctSeedTables tb;
-        if (!sct_build_tables(pat.data(), np, bl, thirds, tb)) return fail(SCT_E_UNSUPPORTED, "too many barcodes for the seed tables");
-        FamTables ft{};
-        for (int f = 0; f < tb.nfam; f++) ft.off_base[f] = tb.off_base[f];
-        const std::vector<uint32_t> &off = tb.off, &ent = tb.ent, &code = tb.code;
-        const std::vector<uint64_t> &slot = tb.slot;
-        c->long_share = tb.long_share;
-        // one buffer: the slots, then the pattern ids of their inline entries (k_filter.hip.h: SLOT_PID_AT)
-        if (slot.size() != SLOT_TOTAL) return fail(SCT_E_STATE, "seed tables: unexpected slot count");
-        if (c->tab_slot.ensure(slot.size() * sizeof(uint64_t) + tb.slot_pid.size() * sizeof(uint32_t))) return SCT_E_HIP;
-        HIPCHK(hipMemcpyAsync(c->tab_slot.p, slot.data(), slot.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        ft.pid16 = np <= 65536 ? 1u : 0u;
         std::vector<uint16_t> pid16;
-        if (ft.pid16) {
-            pid16.assign(tb.slot_pid.begin(), tb.slot_pid.end());
-            HIPCHK(hipMemcpyAsync((char *)c->tab_slot.p + slot.size() * sizeof(uint64_t), pid16.data(), pid16.size() * sizeof(uint16_t),
-                                  hipMemcpyHostToDevice, c->stream));
-        } else {
-            HIPCHK(hipMemcpyAsync((char *)c->tab_slot.p + slot.size() * sizeof(uint64_t), tb.slot_pid.data(),
-                                  tb.slot_pid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        int rc = SCT_OK;
+        do {
+            if (!sct_build_tables(pat.data(), np, bl, thirds, tb)) {
+                rc = fail(SCT_E_UNSUPPORTED, "too many barcodes for the seed tables");
+                break;
+            }
+            FamTables ft{};
+            for (int f = 0; f < tb.nfam; f++) ft.off_base[f] = tb.off_base[f];
+            c->long_share = tb.long_share;
+            // one buffer: the slots, then the pattern ids of their inline entries (k_filter.hip.h: resolve)
+            if (tb.slot.size() != SLOT_TOTAL) {
+                rc = fail(SCT_E_STATE, "seed tables: unexpected slot count");
+                break;
+            }
+            if (c->tab_slot.ensure(tb.slot.size() * sizeof(uint64_t) + tb.slot_pid.size() * sizeof(uint32_t)) ||
+                c->tab_off.ensure(tb.off.size() * sizeof(uint32_t) + 16) || c->tab_ent.ensure(tb.ent.size() * sizeof(uint32_t)) ||
+                c->tab_code.ensure(tb.code.size() * sizeof(uint32_t))) {
+                rc = SCT_E_HIP;
+                break;
+            }
+            ft.pid16 = np <= 65536 ? 1u : 0u;
+            hipError_t e = hipMemcpyAsync(c->tab_slot.p, tb.slot.data(), tb.slot.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+            char *ids = (char *)c->tab_slot.p + tb.slot.size() * sizeof(uint64_t);
+            if (ft.pid16) {
+                pid16.assign(tb.slot_pid.begin(), tb.slot_pid.end());
+                if (e == hipSuccess) e = hipMemcpyAsync(ids, pid16.data(), pid16.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st);
+            } else if (e == hipSuccess) {
+                e = hipMemcpyAsync(ids, tb.slot_pid.data(), tb.slot_pid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(c->tab_code.p, tb.code.data(), tb.code.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->tab_off.p, tb.off.data(), tb.off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->tab_ent.p, tb.ent.data(), tb.ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            const hipError_t es = hipStreamSynchronize(st);  // also on failure: the vectors above are about to go away
+            if (e == hipSuccess) e = es;
+            if (e != hipSuccess) {
+                rc = fail(SCT_E_HIP, "uploading the seed tables: %s", hipGetErrorString(e));
+                break;
+            }
+            c->ft = ft;
+            c->have_tables = true;
+            c->have_thirds = thirds;
+        } while (0);
+        if (rc) {
+            (void)hipStreamSynchronize(st);
+            return rc;
         }
-        if (c->tab_off.ensure(off.size() * sizeof(uint32_t) + 16)) return SCT_E_HIP;
-        if (c->tab_ent.ensure(ent.size() * sizeof(uint32_t))) return SCT_E_HIP;
-        if (c->tab_code.ensure(code.size() * sizeof(uint32_t))) return SCT_E_HIP;
-        HIPCHK(hipMemcpyAsync(c->tab_code.p, code.data(), code.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->tab_off.p, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->tab_ent.p, ent.data(), ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        c->ft = ft;
-        c->have_tables = true;
-        c->have_thirds = thirds;
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(st));
     c->n_bc = n;
     c->bl = bl;
     c->np = np;
     c->have_bc = true;
-    c->have_result = false;
+    for (Lane *l : c->lanes) l->have_result = false;
     return SCT_OK;
 }
 
-extern "C" int sct_upload_segments(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n) {
-    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
-    if (n < 0 || !offs) return fail(SCT_E_ARG, "sct_upload_segments: bad offsets");
-    if (n >= 0x7FFFFFF0) return fail(SCT_E_ARG, "at most 2^31-16 segments per call (shard the input)");
-    if (offs[0] != 0) return fail(SCT_E_ARG, "offs[0] must be 0");
-    const int64_t bytes = offs[n];
-    if (bytes < 0) return fail(SCT_E_ARG, "offs[n] is negative");
-    if (bytes > 0 && !segs) return fail(SCT_E_ARG, "segs is NULL");
-    HIPCHK(hipSetDevice(c->device));
-    if (c->segs.ensure((size_t)bytes + 64)) return SCT_E_HIP;
-    if (c->offs.ensure(sizeof(int64_t) * (size_t)(n + 1))) return SCT_E_HIP;
-    if (c->counters.ensure(64)) return SCT_E_HIP;
-    hipStream_t st = c->stream;
-    if (bytes) HIPCHK(hipMemcpyAsync(c->segs.p, segs, (size_t)bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->offs.p, offs, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, st));
-    // validation on the device, before any kernel trusts the offsets: non-decreasing, inside the byte buffer, and
-    // no byte >= 128 (the reference raises on those); the host only reads back two words
-    HIPCHK(hipMemsetAsync(c->counters.p, 0xFF, 16, st));
-    const int64_t items = (n + 1) > (bytes + 15) / 16 ? (n + 1) : (bytes + 15) / 16;
-    k_validate<<<blocks_for_n(items, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), bytes, c->offs.as<int64_t>(), n,
-                                                        c->counters.as<unsigned long long>());
-    unsigned long long bad[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(bad, c->counters.p, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipGetLastError());
-    c->n_seg = -1;
-    if (bad[0] != ~0ull) return fail(SCT_E_ARG, "offs must be non-decreasing and end at the size of segs (row %llu)", bad[0]);
-    if (bad[1] != ~0ull) return fail(SCT_E_ARG, "segment bytes contain a value >= 128 at offset %llu", bad[1]);
-    c->n_seg = n;
-    c->seg_bytes = bytes;
-    c->have_result = false;
-    return SCT_OK;
-}
-
-static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
-
-extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_hits_out) {
-    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
-    if (!c->have_bc) return fail(SCT_E_STATE, "sct_run before sct_set_barcodes");
-    if (c->n_seg < 0) return fail(SCT_E_STATE, "sct_run before sct_upload_segments");
+// ------------------------------------------------------------------------------------------------------------
+// one batch of rows on one lane
+// ------------------------------------------------------------------------------------------------------------
+static int batch_params(sct_ctx *c, int32_t max_err, int32_t threads, int count_format, BatchParams &bp) {
+    if (!c->have_bc) return fail(SCT_E_STATE, "matching before sct_set_barcodes");
     if (max_err < 0 || max_err >= c->bl) return fail(SCT_E_ARG, "need 0 <= max_err < barcode length (got %d, bl %d)", max_err, c->bl);
     if (threads < 1) return fail(SCT_E_ARG, "threads must be >= 1");
-    HIPCHK(hipSetDevice(c->device));
-    const int64_t n = c->n_seg;
-    const int np = c->np, bl = c->bl;
-    const int prefix_len = sct_prefix_len(threads);
-    const bool filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && np > 0 && (uint64_t)SCT_NFAM_ALL * (uint64_t)np < LOC_INLINE;
-    const bool use_slots = bl == 16 && (c->slots_mode < 0 ? c->long_share <= (max_err <= 1 ? SLOTS_MAX_LONG_SHARE_E1 : SLOTS_MAX_LONG_SHARE_E2)
-                                                          : c->slots_mode == 1);
-    const bool use_thirds = filter_ok && c->have_thirds && max_err <= 1 && c->filter_mode != 1 && !c->no_thirds;
-    const bool rt_families = bl != 16;  // quarter families with run-time piece boundaries
+    bp.max_err = max_err;
+    bp.threads = threads;
+    bp.prefix_len = sct_prefix_len(threads);
+    // With a prefix as long as the shortest window (k >= bl - max_err) the reference's own sentinel insert
+    // (`trie.insert(prefix, -1)`, scTagger.py:675, :563) reaches the result dict as rid -1; that needs -t > 4^(bl - max_err - 1)
+    //  and is not reproduced.
+    if (bp.prefix_len >= c->bl - max_err)
+        return fail(SCT_E_UNSUPPORTED, "threads = %d gives the reference a window prefix of %d characters, not below bl - max_err = %d: "
+                    "its sentinel entry would enter the results (scTagger.py:675); not supported", threads, bp.prefix_len, c->bl - max_err);
+    bp.filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && c->np > 0 && (uint64_t)SCT_NFAM_ALL * (uint64_t)c->np < LOC_INLINE;
+    bp.rt_families = c->bl != 16;  // quarter families with run-time piece boundaries
+    bp.use_thirds = bp.filter_ok && c->have_thirds && max_err <= 1 && !c->no_thirds;
+    bp.use_slots = c->bl == 16 && !bp.use_thirds &&
+                   (c->slots_mode < 0 ? c->long_share <= (max_err <= 1 ? SLOTS_MAX_LONG_SHARE_E1 : SLOTS_MAX_LONG_SHARE_E2) : c->slots_mode == 1);
+    bp.count_format = count_format;
+    return SCT_OK;
+}
+
+// buffers of a batch of n rows
+static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
     const size_t n1 = (size_t)(n ? n : 1);
-    if (c->lo.ensure(8 * n1) || c->hi.ensure(8 * n1) || c->meta.ensure(4 * n1) || c->min_e.ensure(n1) ||
-        c->cnt.ensure(4 * n1) || c->route.ensure(4 * n1) || c->list_scan.ensure(4 * n1) || c->list_dp.ensure(4 * n1) ||
-        c->counters.ensure(64) || c->hit_offs.ensure(8 * (n1 + 1)) || c->total.ensure(8))
+    if (l.min_e.ensure(n1) || l.cnt.ensure(4 * n1) || l.list_long.ensure(4 * n1) || l.list_scan.ensure(4 * n1) || l.list_dp.ensure(4 * n1) ||
+        l.counters.ensure(sizeof(uint32_t) * CTR_WORDS) || l.hit_offs.ensure(8 * (n1 + 1)))
         return SCT_E_HIP;
-    if (filter_ok && (c->slots.ensure(4 * n1 * K_SLOTS) || c->slot_off.ensure(8 * n1) || c->list_retry.ensure(4 * n1))) return SCT_E_HIP;
     const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    if (c->sums.ensure(8 * (size_t)(nb ? nb : 1))) return SCT_E_HIP;
-    c->timed.clear();
-    c->pool_used = 0;
-    c->have_result = false;
-    hipStream_t st = c->stream;
-    HIPCHK(hipMemsetAsync(c->counters.p, 0, 64, st));
-    uint32_t *counters = c->counters.as<uint32_t>();
+    if (l.sums.ensure(8 * (size_t)(nb ? nb : 1))) return SCT_E_HIP;
+    if (bp.count_format == SCT_CNT_U8 && l.cnt_out.ensure(n1)) return SCT_E_HIP;
+    if (bp.count_format == SCT_CNT_U32 && l.cnt_out.ensure(4 * n1)) return SCT_E_HIP;
+    l.slots_cap = l.retry_cap = 0;
+    if (bp.filter_ok) {
+        // the main launch keeps at most K_SLOTS hits per row, the retry launch shares a pool of the same size; the CSR hit
+        // array can therefore hold whatever the two launches produce (rows of the scan lists are sized by the slow path)
+        l.slots_cap = (uint64_t)n1 * K_SLOTS;
+        l.retry_cap = (uint64_t)n1 * K_SLOTS < 65536 ? 65536 : (uint64_t)n1 * K_SLOTS;
+        if (l.slots.ensure(4 * l.slots_cap) || l.slots_retry.ensure(4 * l.retry_cap) || l.slot_off.ensure(8 * n1) || l.list_retry.ensure(4 * n1))
+            return SCT_E_HIP;
+    }
+    if (l.hits.ensure(4 * (size_t)(l.slots_cap + l.retry_cap + 1))) return SCT_E_HIP;
+    l.min_e_ptr = l.min_e.as<uint8_t>();
+    l.cnt8_ptr = bp.count_format == SCT_CNT_U8 ? l.cnt_out.as<uint8_t>() : nullptr;
+    l.cnt32_ptr = bp.count_format == SCT_CNT_U32 ? l.cnt_out.as<uint32_t>() : nullptr;
+    l.hits_ptr = l.hits.as<uint32_t>();
+    l.hits_cap = l.hits.cap / 4;
+    l.direct_min_e = l.direct_cnt = l.direct_hits = false;
+    return SCT_OK;
+}
+
+template <typename OffT>
+static void launch_filter(int max_err, SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, unsigned g64, hipStream_t st) {
+    if (max_err == 0) sct_launch_filter_e0(v, fa, g, g64, st);
+    else if (max_err == 1) sct_launch_filter_e1(v, fa, g, g64, st);
+    else sct_launch_filter_e2(v, fa, g, g64, st);
+}
+
+// grids of the striding launches (k_filter): enough blocks to fill the chip several times over, few enough to cost nothing
+// when their waves find no work
+static constexpr unsigned GRID_STRIDE_MAX = 8192;  // one-wave blocks
+static inline unsigned capped(int64_t g) { return (unsigned)(g < 1 ? 1 : (g < GRID_STRIDE_MAX ? g : GRID_STRIDE_MAX)); }
+
+template <typename OffT>
+static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
+    const BatchParams &bp = l.bp;
+    const int64_t n = l.n_seg;
+    hipStream_t st = l.stream;
+    uint32_t *ctr = l.ctr();
+    FilterArgs<OffT> fa{};
+    fa.segs = l.segs_ptr;
+    fa.offs = offs;
+    fa.seg_bytes = l.seg_bytes;
+    fa.tab_off = c->tab_off.as<uint32_t>();
+    fa.tab_ent = c->tab_ent.as<uint32_t>();
+    fa.tab_code = c->tab_code.as<uint32_t>();
+    fa.tab_slot = c->tab_slot.as<uint2>();
+    fa.ft = c->ft;
+    fa.min_e = l.min_e_ptr;
+    fa.cnt = l.cnt.as<uint32_t>();
+    fa.slot_off = l.slot_off.as<uint64_t>();
+    fa.list_long = l.list_long.as<int32_t>();
+    fa.list_dp = l.list_dp.as<int32_t>();
+    fa.ctr = ctr;
+    fa.bl = c->bl;
+    fa.prefix_len = bp.prefix_len;
+    SctFilterVariant v{false, bp.rt_families, bp.use_slots && !bp.rt_families, bp.use_thirds};
+    {
+        Timer t(c, l, "k_filter");
+        fa.n = n;
+        fa.n_dev = nullptr;
+        fa.rows = nullptr;
+        fa.slots = l.slots.as<uint32_t>();
+        fa.slots_cap = l.slots_cap;
+        fa.list_defer = l.list_retry.as<int32_t>();
+        fa.defer_count = ctr + CTR_RETRY;
+        fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR);
+        fa.slot_tag = 0ull;
+        launch_filter(bp.max_err, v, fa, blocks_for(n, 256), capped((n + 63) / 64), st);
+    }
+    {
+        // rows with more ties / verified matches than the main launch keeps: once more with larger lists.  How many
+        // there are is only known on the device: a fixed grid strides over them.  Rows this launch cannot hold either go
+        // to the exhaustive scan (list_scan).
+        Timer t(c, l, "k_filter_retry");
+        v.retry = true;
+        fa.n = 0;
+        fa.n_dev = ctr + CTR_RETRY;
+        fa.rows = l.list_retry.as<int32_t>();
+        fa.slots = l.slots_retry.as<uint32_t>();
+        fa.slots_cap = l.retry_cap;
+        fa.list_defer = l.list_scan.as<int32_t>();
+        fa.defer_count = ctr + CTR_SCAN;
+        fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR_RETRY);
+        fa.slot_tag = SLOT_TAG_RETRY;
+        launch_filter(bp.max_err, v, fa, capped((n + 15) / 16), capped((n + 15) / 16), st);  // one wave of 16 rows per block
+    }
+}
+
+// cnt -> hit_offs (+ the compact counts) -> total, on the lane's stream
+static void queue_offsets(sct_ctx *c, Lane &l) {
+    const int64_t n = l.n_seg;
+    hipStream_t st = l.stream;
+    const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    uint64_t *total = reinterpret_cast<uint64_t *>(l.ctr() + CTR_TOTAL);
     if (n > 0) {
-        {
-            Timer t(c, "k_pack");
-            k_pack<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), n, bl, max_err, prefix_len,
-                                                       !filter_ok ? 0 : ((c->filter_mode == 1 && bl == 16) ? 31 : PLANE_MAX), c->lo.as<uint64_t>(),
-                                                       c->hi.as<uint64_t>(),
-                                                       c->meta.as<uint32_t>(), c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(),
-                                                       c->list_scan.as<int32_t>(), c->list_dp.as<int32_t>(), counters);
-        }
-        if (filter_ok) {
-            Timer t(c, "k_filter");
-            const unsigned g = blocks_for(n, 256);
-#define LANE_ARGS                                                                                                     \
-    c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), n, c->tab_off.as<uint32_t>(),                  \
-        c->tab_ent.as<uint32_t>(), c->pat.as<uint2>(), np, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>(),              \
-        c->slots.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_scan.as<int32_t>(), counters
-#define WAVE_ARGS                                                                                                     \
-    c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), n, (const int32_t *)nullptr,                   \
-        c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->tab_slot.as<uint2>(), c->ft, c->min_e.as<uint8_t>(), \
-        c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_retry.as<int32_t>(),       \
-        counters + 2, reinterpret_cast<unsigned long long *>(counters + 4), 0ull, bl
-#define LAUNCH_WAVE(E, TH)                                                                                            \
-    do {                                                                                                              \
-        if (rt_families) {                                                                                            \
-            k_filter<E, uint32_t, false, K_SLOTS, HMAX, 64, true, false><<<g, 256, 0, st>>>(WAVE_ARGS);                \
-            k_filter<E, uint64_t, false, K_SLOTS, HMAX, 64, true, false><<<g, 256, 0, st>>>(WAVE_ARGS);                \
-        } else if (use_slots && !TH) {                                                                                \
-            k_filter<E, uint32_t, false, HMAX_SL, HMAX_SL, 64, false, true><<<g, 256, 0, st>>>(WAVE_ARGS);             \
-            k_filter<E, uint64_t, false, HMAX_SL, HMAX_SL, 64, false, true><<<g, 256, 0, st>>>(WAVE_ARGS);             \
-        } else {                                                                                                      \
-            k_filter<E, uint32_t, TH, K_SLOTS, HMAX, 64, false, false><<<g, 256, 0, st>>>(WAVE_ARGS);                  \
-            k_filter<E, uint64_t, TH, K_SLOTS, HMAX, 64, false, false><<<g, 256, 0, st>>>(WAVE_ARGS);                  \
-        }                                                                                                             \
-    } while (0)
-#define LAUNCH_FILTER(E)                                                                                              \
-    do {                                                                                                              \
-        if (c->filter_mode == 1 && !rt_families) k_filter_lane<E><<<g, 256, 0, st>>>(LANE_ARGS);                                       \
-        else LAUNCH_WAVE(E, false);                                                                                   \
-    } while (0)
-            if (use_thirds && max_err == 0) LAUNCH_WAVE(0, true);
-            else if (use_thirds) LAUNCH_WAVE(1, true);
-            else if (max_err == 0) LAUNCH_FILTER(0);
-            else if (max_err == 1) LAUNCH_FILTER(1);
-            else LAUNCH_FILTER(2);
-#undef LAUNCH_FILTER
-#undef LAUNCH_WAVE
-#undef WAVE_ARGS
-#undef LANE_ARGS
+        Timer t(c, l, "k_offsets");
+        k_sum_blocks<uint32_t><<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), nullptr);
+        k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
+        k_offsets<<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), total, l.hit_offs.as<int64_t>(),
+                                                l.cnt8_ptr, l.cnt32_ptr, l.ctr());
+    } else {
+        (void)hipMemsetAsync(l.hit_offs.p, 0, 8, st);
+    }
+}
+
+// Queue everything a batch needs on the lane's stream — no host synchronisation.  The rows (segs + offsets, l.n_seg,
+// l.seg_bytes, l.wide) are already on the device or their copies are queued on the same stream.  The counter record must
+// have been reset (reset_counters) before whatever checks the input wrote to it.
+static int reset_counters(Lane &l) {
+    if (l.counters.ensure(sizeof(uint32_t) * CTR_WORDS)) return SCT_E_HIP;
+    HIPCHK(hipMemsetAsync(l.counters.p, 0, sizeof(uint32_t) * CTR_WORDS, l.stream));
+    HIPCHK(hipMemsetAsync(l.ctr() + CTR_BAD_ROW, 0xFF, 16, l.stream));
+    return SCT_OK;
+}
+
+static int queue_batch(sct_ctx *c, Lane &l) {
+    const BatchParams &bp = l.bp;
+    const int64_t n = l.n_seg;
+    hipStream_t st = l.stream;
+    l.have_result = false;
+    if (n > 0) {
+        if (bp.filter_ok) {
+            if (l.wide) queue_filter_launches<int64_t>(c, l, l.offs64.as<int64_t>());
+            else queue_filter_launches<uint32_t>(c, l, l.offs32.as<uint32_t>());
+        } else {
+            Timer t(c, l, "k_route");
+            if (l.wide)
+                k_route_all<int64_t><<<blocks_for(n, 256), 256, 0, st>>>(l.segs_ptr, l.offs64.as<int64_t>(), l.seg_bytes, n, c->bl,
+                                                                        bp.max_err, bp.prefix_len, l.min_e_ptr, l.cnt.as<uint32_t>(),
+                                                                        l.list_scan.as<int32_t>(), l.list_dp.as<int32_t>(), l.ctr());
+            else
+                k_route_all<uint32_t><<<blocks_for(n, 256), 256, 0, st>>>(l.segs_ptr, l.offs32.as<uint32_t>(), l.seg_bytes, n, c->bl,
+                                                                         bp.max_err, bp.prefix_len, l.min_e_ptr, l.cnt.as<uint32_t>(),
+                                                                         l.list_scan.as<int32_t>(), l.list_dp.as<int32_t>(), l.ctr());
         }
     }
-    // host sync #1: how many rows go through the scan paths (normally none or a handful) / are to be retried
-    uint32_t hc[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(hc, c->counters.p, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const int64_t n_retried = hc[2];
-    if (n > 0 && filter_ok && !(c->filter_mode == 1 && !rt_families) && hc[2] > 0) {
-        // rows with more ties / verified matches than the main launch keeps: once more with larger lists
-        const int64_t nr = hc[2];
-        if (c->slots_retry.ensure(4 * (size_t)nr * K_RETRY)) return SCT_E_HIP;
-        Timer t(c, "k_filter_retry");
-        const unsigned g = blocks_for(nr, 64);  // 4 waves x 16 rows per block
-#define RETRY_ARGS                                                                                                    \
-    c->lo.as<uint64_t>(), c->hi.as<uint64_t>(), c->meta.as<uint32_t>(), nr, c->list_retry.as<int32_t>(),               \
-        c->tab_off.as<uint32_t>(), c->tab_ent.as<uint32_t>(), c->tab_code.as<uint32_t>(), c->tab_slot.as<uint2>(), c->ft, c->min_e.as<uint8_t>(), \
-        c->cnt.as<uint32_t>(), c->slots_retry.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->list_scan.as<int32_t>(),  \
-        counters + 0, reinterpret_cast<unsigned long long *>(counters + 6), SLOT_TAG_RETRY, bl
-#define LAUNCH_RETRY(E, TH)                                                                                           \
-    do {                                                                                                              \
-        if (rt_families) {                                                                                            \
-            k_filter<E, uint32_t, false, K_RETRY, H_RETRY, 16, true, false><<<g, 256, 0, st>>>(RETRY_ARGS);            \
-            k_filter<E, uint64_t, false, K_RETRY, H_RETRY, 16, true, false><<<g, 256, 0, st>>>(RETRY_ARGS);            \
-        } else if (use_slots && !TH) {                                                                                \
-            k_filter<E, uint32_t, false, K_RETRY, H_RETRY_SL, 16, false, true><<<g, 256, 0, st>>>(RETRY_ARGS);            \
-            k_filter<E, uint64_t, false, K_RETRY, H_RETRY_SL, 16, false, true><<<g, 256, 0, st>>>(RETRY_ARGS);            \
-        } else {                                                                                                      \
-            k_filter<E, uint32_t, TH, K_RETRY, H_RETRY, 16, false, false><<<g, 256, 0, st>>>(RETRY_ARGS);              \
-            k_filter<E, uint64_t, TH, K_RETRY, H_RETRY, 16, false, false><<<g, 256, 0, st>>>(RETRY_ARGS);              \
-        }                                                                                                             \
-    } while (0)
-        if (use_thirds && max_err == 0) LAUNCH_RETRY(0, true);
-        else if (use_thirds) LAUNCH_RETRY(1, true);
-        else if (max_err == 0) LAUNCH_RETRY(0, false);
-        else if (max_err == 1) LAUNCH_RETRY(1, false);
-        else LAUNCH_RETRY(2, false);
-#undef LAUNCH_RETRY
-#undef RETRY_ARGS
+    queue_offsets(c, l);
+    if (n > 0 && bp.filter_ok) {
+        Timer t(c, l, "k_fill");
+        k_fill<<<blocks_for(n, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
+                                                   l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(), n, l.hits_ptr,
+                                                   l.hits_cap, l.ctr());
     }
-    // The rows of the scan lists are those k_pack routed there (known since sync #1) and, rarely, rows the retry launch
-    // could not hold either.  The tail below — scan-path count passes, offsets, sync #2 — first runs with the lists as
-    // known; sync #2 also brings the counters back, and only if the retry launch did add rows is the tail run again
-    // with them (the count passes rewrite the same values for the rows they had already seen).
-    uint32_t *pb_scan = nullptr, *pc_scan = nullptr, *pb_dp = nullptr, *pc_dp = nullptr;
-    int sl_scan = 1, sl_dp = 1;
-    const uint32_t *route = c->cnt.as<uint32_t>();  // which rows are deferred (CNT_DEFER), as k_fill sees it
-    uint64_t total = 0;
+    HIPCHK(hipMemcpyAsync(l.h_ctr, l.counters.p, sizeof(uint32_t) * CTR_WORDS, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipGetLastError());
+    return SCT_OK;
+}
+
+static int ensure_host_hits(sct_ctx *c, size_t entries);
+static inline uint64_t ctr64(const uint32_t *h, int at) { return (uint64_t)h[at] | ((uint64_t)h[at + 1] << 32); }
+
+// The rows the filter kernels left on the lists: scan kernels, then offsets and fill once more.  Synchronises the lane.
+static int slow_path(sct_ctx *c, Lane &l) {
+    const BatchParams &bp = l.bp;
+    const int64_t n = l.n_seg;
+    const int np = c->np, bl = c->bl;
+    hipStream_t st = l.stream;
+    uint32_t *ctr = l.ctr();
+    uint32_t *h = l.h_ctr;
+    if (l.host_segs) {
+        // a zero-copy batch: the scan kernels read every listed row once per barcode slice — bring the bytes to the device first
+        if (l.segs.ensure((size_t)l.seg_bytes + 64)) return SCT_E_HIP;
+        if (l.seg_bytes) HIPCHK(hipMemcpyAsync(l.segs.p, l.host_segs, (size_t)l.seg_bytes, hipMemcpyHostToDevice, st));
+        l.segs_ptr = l.segs.as<uint8_t>();
+        l.host_segs = nullptr;
+    }
+    if (!l.wide && l.seg_bytes) {
+        // stream batches: the filter kernel looked for bytes >= 128 only in the rows it decoded; the listed rows are checked here
+        k_validate<<<blocks_for((l.seg_bytes + 15) / 16, 256), 256, 0, st>>>(l.segs.as<uint8_t>(), l.seg_bytes, nullptr, 0,
+                                                                           reinterpret_cast<unsigned long long *>(ctr + CTR_BAD_ROW));
+    }
+    // the scan kernels take int64 offsets
+    if (!l.have_offs64) {
+        if (l.offs64.ensure(8 * (size_t)(n + 1))) return SCT_E_HIP;
+        k_widen_offs<<<blocks_for(n + 1, 256), 256, 0, st>>>(l.offs32.as<uint32_t>(), n + 1, l.offs64.as<int64_t>());
+        l.have_offs64 = true;
+    }
+    const int64_t *offs = l.offs64.as<int64_t>();
+    if (h[CTR_LONG]) {  // rows the filter only listed: exhaustive scan or DP?
+        k_route_long<<<blocks_for((int64_t)h[CTR_LONG], 4), 256, 0, st>>>(l.segs_ptr, offs, l.seg_bytes, l.list_long.as<int32_t>(),
+                                                                         (int64_t)h[CTR_LONG], bp.prefix_len, l.list_scan.as<int32_t>(),
+                                                                         l.list_dp.as<int32_t>(), ctr);
+        HIPCHK(hipMemcpyAsync(h, l.counters.p, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    const uint32_t n_scan = h[CTR_SCAN], n_dp = h[CTR_DP];
+    // remember which rows are deferred: their cnt is about to be overwritten by the count passes (k_fill skips them)
+    if (l.route.ensure(4 * (size_t)(n ? n : 1))) return SCT_E_HIP;
+    HIPCHK(hipMemcpyAsync(l.route.p, l.cnt.p, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
     auto slices_for = [&](uint32_t rows) {  // a short list is cut into pattern slices so that the whole chip works on it
         if (rows == 0) return 1;
         const int tiles = (np + 63) / 64;
@@ -516,122 +714,503 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
         const int64_t blocks = (waves + 3) / 4;
         return (unsigned)(blocks < 2048 ? (blocks < 1 ? 1 : blocks) : 2048);
     };
-    auto tail = [&]() -> int {
-        if (n > 0 && (hc[0] || hc[1]) && route == c->cnt.as<uint32_t>()) {
-            // remember which rows are deferred: their cnt is about to be overwritten by the count passes (taken once:
-            // the marks of the retry launch's rows are already in place when the tail first runs)
-            HIPCHK(hipMemcpyAsync(c->route.p, c->cnt.p, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
-            route = c->route.as<uint32_t>();
-        }
-        sl_scan = slices_for(hc[0]);
-        sl_dp = slices_for(hc[1]);
-        if (c->part_best.ensure(4 * ((size_t)hc[0] * sl_scan + (size_t)hc[1] * sl_dp + 1)) ||
-            c->part_cnt.ensure(4 * ((size_t)hc[0] * sl_scan + (size_t)hc[1] * sl_dp + 1)))
-            return SCT_E_HIP;
-        pb_scan = c->part_best.as<uint32_t>();
-        pc_scan = c->part_cnt.as<uint32_t>();
-        pb_dp = pb_scan + (size_t)hc[0] * sl_scan;
-        pc_dp = pc_scan + (size_t)hc[0] * sl_scan;
-        if (n > 0) {
-            if (hc[0]) {
-                Timer t(c, "k_scan_count");
-                if (bl <= 16)
-                    k_scan_pk<false><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
-                        c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
-                        np, bl, max_err, c->min_e.as<uint8_t>(), pb_scan, pc_scan, nullptr, nullptr);
-                else
-                    k_scan<false, false><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
-                        c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
-                        np, bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_scan, pc_scan, nullptr, nullptr);
-                k_scan_reduce<<<blocks_for(hc[0], 256), 256, 0, st>>>(c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, max_err, pb_scan,
-                                                                      pc_scan, c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>());
-            }
-            if (hc[1]) {
-                Timer t(c, "k_dp_count");
-                k_scan<true, false><<<grid_for(hc[1], sl_dp), 256, 0, st>>>(
-                    c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_dp.as<int32_t>(), (int64_t)hc[1], sl_dp, c->pat.as<uint2>(), np,
-                    bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_dp, pc_dp, nullptr, nullptr);
-                k_scan_reduce<<<blocks_for(hc[1], 256), 256, 0, st>>>(c->list_dp.as<int32_t>(), (int64_t)hc[1], sl_dp, max_err, pb_dp, pc_dp,
-                                                                      c->min_e.as<uint8_t>(), c->cnt.as<uint32_t>());
-            }
-            {
-                Timer t(c, "k_offsets");
-                k_sum_blocks<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>());
-                k_scan_sums<<<1, 256, 0, st>>>(c->sums.as<uint64_t>(), nb, c->total.as<uint64_t>());
-                k_offsets<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>(), c->total.as<uint64_t>(),
-                                                        c->hit_offs.as<int64_t>());
-            }
-        } else {
-            HIPCHK(hipMemsetAsync(c->hit_offs.p, 0, 8, st));
-            HIPCHK(hipMemsetAsync(c->total.p, 0, 8, st));
-        }
-        return SCT_OK;
-    };
-    const uint32_t listed0 = hc[0];
-    if (int rc = tail()) return rc;
-    // host sync #2: the total hit count sizes the CSR hit array; the counters say whether the retry launch deferred rows
-    uint32_t hc2[4] = {hc[0], hc[1], hc[2], 0};
-    HIPCHK(hipMemcpyAsync(&total, c->total.p, 8, hipMemcpyDeviceToHost, st));
-    if (n > 0) HIPCHK(hipMemcpyAsync(hc2, c->counters.p, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (hc2[0] != listed0) {
-        hc[0] = hc2[0];
-        if (int rc = tail()) return rc;
-        HIPCHK(hipMemcpyAsync(&total, c->total.p, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+    const int sl_scan = slices_for(n_scan), sl_dp = slices_for(n_dp);
+    if (l.part_best.ensure(4 * ((size_t)n_scan * sl_scan + (size_t)n_dp * sl_dp + 1)) ||
+        l.part_cnt.ensure(4 * ((size_t)n_scan * sl_scan + (size_t)n_dp * sl_dp + 1)))
+        return SCT_E_HIP;
+    uint32_t *pb_scan = l.part_best.as<uint32_t>(), *pc_scan = l.part_cnt.as<uint32_t>();
+    uint32_t *pb_dp = pb_scan + (size_t)n_scan * sl_scan, *pc_dp = pc_scan + (size_t)n_scan * sl_scan;
+    const uint8_t *segs = l.segs_ptr;
+    if (n_scan) {
+        Timer t(c, l, "k_scan_count");
+        if (bl <= 16)
+            k_scan_pk<false><<<grid_for(n_scan, sl_scan), 256, 0, st>>>(segs, offs, l.seg_bytes, l.list_scan.as<int32_t>(), (int64_t)n_scan, sl_scan,
+                                                                       c->pat.as<uint2>(), np, bl, bp.max_err, l.min_e_ptr, pb_scan,
+                                                                       pc_scan, nullptr, nullptr);
+        else
+            k_scan<false, false><<<grid_for(n_scan, sl_scan), 256, 0, st>>>(segs, offs, l.seg_bytes, l.list_scan.as<int32_t>(), (int64_t)n_scan,
+                                                                           sl_scan, c->pat.as<uint2>(), np, bl, bp.max_err, bp.prefix_len,
+                                                                           l.min_e_ptr, pb_scan, pc_scan, nullptr, nullptr);
+        k_scan_reduce<<<blocks_for(n_scan, 256), 256, 0, st>>>(l.list_scan.as<int32_t>(), (int64_t)n_scan, sl_scan, bp.max_err, pb_scan, pc_scan,
+                                                              l.min_e_ptr, l.cnt.as<uint32_t>());
     }
-    if (c->hits.ensure(4 * (size_t)(total ? total : 1))) return SCT_E_HIP;
+    if (n_dp) {
+        Timer t(c, l, "k_dp_count");
+        k_scan<true, false><<<grid_for(n_dp, sl_dp), 256, 0, st>>>(segs, offs, l.seg_bytes, l.list_dp.as<int32_t>(), (int64_t)n_dp, sl_dp,
+                                                                  c->pat.as<uint2>(), np, bl, bp.max_err, bp.prefix_len, l.min_e_ptr,
+                                                                  pb_dp, pc_dp, nullptr, nullptr);
+        k_scan_reduce<<<blocks_for(n_dp, 256), 256, 0, st>>>(l.list_dp.as<int32_t>(), (int64_t)n_dp, sl_dp, bp.max_err, pb_dp, pc_dp,
+                                                            l.min_e_ptr, l.cnt.as<uint32_t>());
+    }
+    HIPCHK(hipMemsetAsync(ctr + CTR_CNT_OVERFLOW, 0, 4, st));
+    queue_offsets(c, l);
+    HIPCHK(hipMemcpyAsync(h, l.counters.p, sizeof(uint32_t) * CTR_WORDS, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint64_t total = ctr64(h, CTR_TOTAL);
+    if (l.hits_cap < total) {
+        if (l.direct_hits) {
+            if (int rc = ensure_host_hits(c, (size_t)total + 1)) return rc;
+            l.hits_ptr = c->h_hits;
+            l.hits_cap = c->h_hits_cap;
+        } else {
+            if (l.hits.ensure(4 * (size_t)(total + 1))) return SCT_E_HIP;
+            l.hits_ptr = l.hits.as<uint32_t>();
+            l.hits_cap = l.hits.cap / 4;
+        }
+    }
     if (n > 0 && total > 0) {
-        if (filter_ok) {
-            Timer t(c, "k_fill");
-            k_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->cnt.as<uint32_t>(), c->slots.as<uint32_t>(), c->slots_retry.as<uint32_t>(), c->slot_off.as<uint64_t>(), c->hit_offs.as<int64_t>(),
-                                                       route, n, c->hits.as<uint32_t>());
+        if (bp.filter_ok) {
+            Timer t(c, l, "k_fill");
+            k_fill<<<blocks_for(n, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
+                                                       l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.route.as<uint32_t>(), n,
+                                                       l.hits_ptr, l.hits_cap, l.ctr());
         }
-        if (hc[0]) {
-            Timer t(c, "k_scan_fill");
+        if (n_scan) {
+            Timer t(c, l, "k_scan_fill");
             if (bl <= 16)
-                k_scan_pk<true><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
-                    c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
-                    np, bl, max_err, c->min_e.as<uint8_t>(), pb_scan, pc_scan, c->hit_offs.as<int64_t>(), c->hits.as<uint32_t>());
+                k_scan_pk<true><<<grid_for(n_scan, sl_scan), 256, 0, st>>>(segs, offs, l.seg_bytes, l.list_scan.as<int32_t>(), (int64_t)n_scan,
+                                                                          sl_scan, c->pat.as<uint2>(), np, bl, bp.max_err, l.min_e_ptr,
+                                                                          pb_scan, pc_scan, l.hit_offs.as<int64_t>(), l.hits_ptr);
             else
-                k_scan<false, true><<<grid_for(hc[0], sl_scan), 256, 0, st>>>(
-                    c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_scan.as<int32_t>(), (int64_t)hc[0], sl_scan, c->pat.as<uint2>(),
-                    np, bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_scan, pc_scan, c->hit_offs.as<int64_t>(), c->hits.as<uint32_t>());
+                k_scan<false, true><<<grid_for(n_scan, sl_scan), 256, 0, st>>>(segs, offs, l.seg_bytes, l.list_scan.as<int32_t>(), (int64_t)n_scan,
+                                                                              sl_scan, c->pat.as<uint2>(), np, bl, bp.max_err, bp.prefix_len,
+                                                                              l.min_e_ptr, pb_scan, pc_scan, l.hit_offs.as<int64_t>(),
+                                                                              l.hits_ptr);
         }
-        if (hc[1]) {
-            Timer t(c, "k_dp_fill");
-            k_scan<true, true><<<grid_for(hc[1], sl_dp), 256, 0, st>>>(
-                c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->list_dp.as<int32_t>(), (int64_t)hc[1], sl_dp, c->pat.as<uint2>(), np,
-                bl, max_err, prefix_len, c->min_e.as<uint8_t>(), pb_dp, pc_dp, c->hit_offs.as<int64_t>(), c->hits.as<uint32_t>());
+        if (n_dp) {
+            Timer t(c, l, "k_dp_fill");
+            k_scan<true, true><<<grid_for(n_dp, sl_dp), 256, 0, st>>>(segs, offs, l.seg_bytes, l.list_dp.as<int32_t>(), (int64_t)n_dp, sl_dp,
+                                                                     c->pat.as<uint2>(), np, bl, bp.max_err, bp.prefix_len, l.min_e_ptr,
+                                                                     pb_dp, pc_dp, l.hit_offs.as<int64_t>(), l.hits_ptr);
         }
     }
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
-    c->last_ms.clear();
-    for (const TimedKernel &t : c->timed) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) c->last_ms.emplace_back(t.name, ms);
+    return SCT_OK;
+}
+
+// After the lane's queued work is done (the caller waited for it): read the counter record, report bad input, run the
+// slow path if rows were listed.  On return the batch's results are complete on the device; *slow says whether the slow
+// path ran (copies of min_e / counts queued before it are then stale).
+static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
+    const uint32_t *h = l.h_ctr;
+    if (slow) *slow = false;
+    const uint64_t bad_row = ctr64(h, CTR_BAD_ROW), bad_byte = ctr64(h, CTR_BAD_BYTE);
+    if (bad_row != ~0ull)
+        return fail(SCT_E_ARG, "the row index must not decrease and must end at the size of segs (row %llu)",
+                    (unsigned long long)(bad_row + (uint64_t)row_base));
+    if (bad_byte != ~0ull) return fail(SCT_E_ARG, "segment bytes contain a value >= 128 (row block starting at row %lld, byte offset %llu in it)",
+                                       (long long)row_base, (unsigned long long)bad_byte);
+    const int64_t n_retried = h[CTR_RETRY];
+    if (h[CTR_LONG] || h[CTR_SCAN] || h[CTR_DP]) {
+        if (int rc = slow_path(c, l)) return rc;
+        if (slow) *slow = true;
+        if (ctr64(h, CTR_BAD_BYTE) != ~0ull)
+            return fail(SCT_E_ARG, "segment bytes contain a value >= 128 (row block starting at row %lld, byte offset %llu in it)",
+                        (long long)row_base, (unsigned long long)ctr64(h, CTR_BAD_BYTE));
     }
-    c->n_hits = (int64_t)total;
-    c->stats[0] = n - hc[0] - hc[1];
-    c->stats[1] = hc[0];
-    c->stats[2] = hc[1];
-    c->stats[3] = (int64_t)total;
-    c->stats[4] = n_retried;
-    c->have_result = true;
-    if (n_hits_out) *n_hits_out = (int64_t)total;
+    if (l.direct_hits && ctr64(h, CTR_TOTAL) > l.hits_cap) {
+        // the fill kernel found the caller-visible hit buffer too small and wrote nothing: enlarge it, fill again
+        if (int rc = ensure_host_hits(c, (size_t)ctr64(h, CTR_TOTAL) + 1)) return rc;
+        l.hits_ptr = c->h_hits;
+        l.hits_cap = c->h_hits_cap;
+        if (l.bp.filter_ok && l.n_seg > 0)
+            k_fill<<<blocks_for(l.n_seg, 256), 256, 0, l.stream>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
+                                                                   l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(),
+                                                                   l.n_seg, l.hits_ptr, l.hits_cap, l.ctr());
+        HIPCHK(hipStreamSynchronize(l.stream));
+        HIPCHK(hipGetLastError());
+    }
+    if (l.bp.count_format == SCT_CNT_U8 && h[CTR_CNT_OVERFLOW])
+        return fail(SCT_E_RANGE, "a row has more than 255 hits: ask for SCT_CNT_U32 or SCT_CNT_OFFS64 counts");
+    l.n_hits = (int64_t)ctr64(h, CTR_TOTAL);
+    l.stats[0] = l.n_seg - h[CTR_SCAN] - h[CTR_DP];
+    l.stats[1] = h[CTR_SCAN];
+    l.stats[2] = h[CTR_DP];
+    l.stats[3] = l.n_hits;
+    l.stats[4] = n_retried;
+    l.have_result = true;
+    return SCT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the resident three-step API (lane 0)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int sct_upload_segments(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    if (n < 0 || !offs) return fail(SCT_E_ARG, "sct_upload_segments: bad offsets");
+    if (n >= 0x7FFFFFF0) return fail(SCT_E_ARG, "at most 2^31-16 segments per call (shard the input)");
+    if (offs[0] != 0) return fail(SCT_E_ARG, "offs[0] must be 0");
+    const int64_t bytes = offs[n];
+    if (bytes < 0) return fail(SCT_E_ARG, "offs[n] is negative");
+    if (bytes > 0 && !segs) return fail(SCT_E_ARG, "segs is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    Lane &l = c->lane0();
+    if (l.segs.ensure((size_t)bytes + 64)) return SCT_E_HIP;
+    if (l.offs64.ensure(sizeof(int64_t) * (size_t)(n + 1))) return SCT_E_HIP;
+    hipStream_t st = l.stream;
+    l.n_seg = -1;
+    l.have_result = false;
+    if (int rc = reset_counters(l)) return rc;
+    if (bytes) HIPCHK(hipMemcpyAsync(l.segs.p, segs, (size_t)bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(l.offs64.p, offs, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+    // validation on the device, before any kernel trusts the offsets: non-decreasing, inside the byte buffer, and
+    // no byte >= 128 (the reference raises on those); the host only reads back two words
+    const int64_t items = (n + 1) > (bytes + 15) / 16 ? (n + 1) : (bytes + 15) / 16;
+    k_validate<<<blocks_for(items, 256), 256, 0, st>>>(l.segs.as<uint8_t>(), bytes, l.offs64.as<int64_t>(), n,
+                                                      reinterpret_cast<unsigned long long *>(l.ctr() + CTR_BAD_ROW));
+    unsigned long long bad[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(bad, l.ctr() + CTR_BAD_ROW, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    if (bad[0] != ~0ull) return fail(SCT_E_ARG, "offs must be non-decreasing and end at the size of segs (row %llu)", bad[0]);
+    if (bad[1] != ~0ull) return fail(SCT_E_ARG, "segment bytes contain a value >= 128 at offset %llu", bad[1]);
+    l.n_seg = n;
+    l.seg_bytes = bytes;
+    l.wide = true;
+    l.have_offs64 = true;
+    l.segs_ptr = l.segs.as<uint8_t>();
+    l.host_segs = nullptr;
+    return SCT_OK;
+}
+
+extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_hits_out) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    if (!c->have_bc) return fail(SCT_E_STATE, "sct_run before sct_set_barcodes");
+    Lane &l = c->lane0();
+    if (l.n_seg < 0 || !l.wide) return fail(SCT_E_STATE, "sct_run before sct_upload_segments");
+    HIPCHK(hipSetDevice(c->device));
+    if (int rc = batch_params(c, max_err, threads, SCT_CNT_OFFS64, l.bp)) return rc;
+    if (int rc = lane_ensure(l, l.n_seg, l.bp)) return rc;
+    c->last_ms.clear();
+    l.timed.clear();
+    l.pool_used = 0;
+    if (int rc = reset_counters(l)) return rc;
+    if (int rc = queue_batch(c, l)) return rc;
+    HIPCHK(hipStreamSynchronize(l.stream));  // the one host synchronisation of a run without listed rows
+    HIPCHK(hipGetLastError());
+    if (int rc = finish_batch(c, l, 0, nullptr)) return rc;
+    collect_timing(c, l);
+    memcpy(c->stats, l.stats, sizeof(c->stats));
+    if (n_hits_out) *n_hits_out = l.n_hits;
     return SCT_OK;
 }
 
 extern "C" int sct_download(sct_ctx *c, uint8_t *min_e, int64_t *hit_offs, uint32_t *hits) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
-    if (!c->have_result) return fail(SCT_E_STATE, "sct_download without a completed sct_run");
+    Lane &l = c->lane0();
+    if (!l.have_result) return fail(SCT_E_STATE, "sct_download without a completed sct_run");
     HIPCHK(hipSetDevice(c->device));
-    const int64_t n = c->n_seg;
-    if (min_e && n) HIPCHK(hipMemcpyAsync(min_e, c->min_e.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (hit_offs) HIPCHK(hipMemcpyAsync(hit_offs, c->hit_offs.p, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, c->stream));
-    if (hits && c->n_hits) HIPCHK(hipMemcpyAsync(hits, c->hits.p, 4 * (size_t)c->n_hits, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    const int64_t n = l.n_seg;
+    if (min_e && n) HIPCHK(hipMemcpyAsync(min_e, l.min_e.p, (size_t)n, hipMemcpyDeviceToHost, l.stream));
+    if (hit_offs) HIPCHK(hipMemcpyAsync(hit_offs, l.hit_offs.p, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, l.stream));
+    if (hits && l.n_hits) HIPCHK(hipMemcpyAsync(hits, l.hits.p, 4 * (size_t)l.n_hits, hipMemcpyDeviceToHost, l.stream));
+    HIPCHK(hipStreamSynchronize(l.stream));
+    return SCT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the stream API: the seam in one call, rows cut into chunks that move through L lanes (option "lanes", default 5)
+//   lane k mod L:   H2D(chunk k) -> index / byte checks -> filter launches -> offsets -> fill -> D2H(min_e, counts, counters)
+// queued L - 1 chunks ahead of the chunk the host is waiting for, so that while chunk k computes, the chunks after it are on
+// their way to the device and the results of the chunks before it on their way back.  One chunk takes about three times as
+// long from its first byte up to its last byte down as its upload alone (1 M rows: 0.4 ms up, 0.65 ms of kernels, 0.15 ms
+// down, the host's turn-around in between), and a lane is busy for all of that: three lanes leave both the link and the
+// chip idle a third of the time (profiles/r02_stream_timeline_3lanes.txt), five keep the link busy.
+// ------------------------------------------------------------------------------------------------------------
+static int ensure_host_hits(sct_ctx *c, size_t entries) {
+    if (entries <= c->h_hits_cap) return SCT_OK;
+    // copies into the old buffer may still be in flight
+    for (Lane *l : c->lanes) HIPCHK(hipStreamSynchronize(l->stream));
+    size_t want = c->h_hits_cap ? c->h_hits_cap : (size_t)1 << 20;
+    while (want < entries) want *= 2;
+    uint32_t *p = nullptr;
+    hipError_t e = hipHostMalloc((void **)&p, want * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(SCT_E_HIP, "hipHostMalloc(%zu) for the hit buffer: %s", want * sizeof(uint32_t), hipGetErrorString(e));
+    if (c->h_hits) {
+        memcpy(p, c->h_hits, c->h_hits_cap * sizeof(uint32_t));
+        (void)hipHostFree(c->h_hits);
+    }
+    c->h_hits = p;
+    c->h_hits_cap = want;
+    return SCT_OK;
+}
+
+static inline size_t index_entry_size(int fmt) {
+    return fmt == SCT_IDX_OFFS64 ? 8 : fmt == SCT_IDX_OFFS32 ? 4 : fmt == SCT_IDX_LEN16 ? 2 : 1;
+}
+
+struct ChunkPlan {
+    int64_t r0, r1;  // rows
+    int64_t b0, b1;  // bytes of segs
+    int64_t hit_base = 0;
+};
+
+extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes, const void *index, int32_t index_format, int64_t n,
+                                int32_t max_err, int32_t threads, uint8_t *min_e, void *counts, int32_t count_format,
+                                const uint32_t **hits_out, int64_t *n_hits_out) {
+    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    if (!hits_out || !n_hits_out) return fail(SCT_E_ARG, "sct_match_stream: NULL output pointer");
+    *hits_out = nullptr;
+    *n_hits_out = 0;
+    if (n < 0 || seg_bytes < 0) return fail(SCT_E_ARG, "sct_match_stream: negative size");
+    if (n > 0 && (!index || !min_e)) return fail(SCT_E_ARG, "sct_match_stream: NULL index or min_e");
+    if (!counts) return fail(SCT_E_ARG, "sct_match_stream: counts is NULL");
+    if (seg_bytes > 0 && !segs) return fail(SCT_E_ARG, "segs is NULL");
+    if (index_format < SCT_IDX_OFFS64 || index_format > SCT_IDX_LEN16) return fail(SCT_E_ARG, "unknown index format %d", index_format);
+    if (count_format < SCT_CNT_OFFS64 || count_format > SCT_CNT_U8) return fail(SCT_E_ARG, "unknown count format %d", count_format);
+    HIPCHK(hipSetDevice(c->device));
+    BatchParams bp;
+    if (int rc = batch_params(c, max_err, threads, count_format, bp)) return rc;
+    const bool by_offs = index_format == SCT_IDX_OFFS64 || index_format == SCT_IDX_OFFS32;
+    auto offs_at = [&](int64_t i) -> int64_t {
+        return index_format == SCT_IDX_OFFS64 ? ((const int64_t *)index)[i] : (int64_t)((const int32_t *)index)[i];
+    };
+    if (by_offs && index) {
+        if (offs_at(0) != 0) return fail(SCT_E_ARG, "offs[0] must be 0");
+        if (offs_at(n) != seg_bytes) return fail(SCT_E_ARG, "offs[n] = %lld but segs holds %lld bytes", (long long)offs_at(n), (long long)seg_bytes);
+    }
+    if (n == 0) {
+        if (seg_bytes != 0) return fail(SCT_E_ARG, "no rows but %lld segment bytes", (long long)seg_bytes);
+        if (count_format == SCT_CNT_OFFS64) ((int64_t *)counts)[0] = 0;
+        c->last_ms.clear();
+        memset(c->stats, 0, sizeof(c->stats));
+        *hits_out = c->h_hits;
+        return SCT_OK;
+    }
+    // Page-locked host memory (sct_host_alloc, hipHostMalloc, hipHostRegister) is mapped into the device's address space: the
+    // kernels read the rows and their index from it directly ("zero copy"), at the rate of the PCIe link (57 GB/s measured,
+    // profiles/r02_pcie_probe.json), every byte once — there is no upload step to wait for.  Pageable memory is copied.
+    auto device_view = [&](const void *p) -> const void * {
+        if (!p || !c->zero_copy) return nullptr;
+        hipPointerAttribute_t at;
+        const void *d = nullptr;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) d = at.devicePointer;
+        (void)hipGetLastError();
+        return d;
+    };
+    const uint8_t *zc_segs = (const uint8_t *)device_view(segs);
+    const char *zc_index = (const char *)device_view(index);
+    // outputs the kernels can write in place (page-locked arrays): min_e and the compact counts; the 64-bit offsets need the
+    // hits of the earlier chunks added and stay on the copy path
+    uint8_t *zc_min_e = (uint8_t *)device_view(min_e);
+    void *zc_counts = count_format == SCT_CNT_OFFS64 ? nullptr : (void *)device_view(counts);
+    int64_t chunk = c->chunk_rows;
+    if (chunk <= 0) {
+        // Zero copy: ONE launch over as many rows as possible — a launch begins with every resident wave asking for its rows at
+        // once and ends with compute only, about a quarter of a millisecond in which link and chip do not overlap
+        // (1 M-row launches: 0.58 ms each against 0.43 ms per 1 M rows of a 10 M-row launch).  Uploaded page-locked segments:
+        // 2^20 rows per chunk keep the lanes busy.  Pageable segments: every copy is staged by the runtime and blocks this
+        // thread, so nothing overlaps anyway, and few large copies are staged faster than many small ones.
+        hipPointerAttribute_t at;
+        const bool pinned = zc_segs != nullptr || (hipPointerGetAttributes(&at, segs) == hipSuccess && at.type == hipMemoryTypeHost);
+        (void)hipGetLastError();
+        chunk = zc_segs ? (int64_t)1 << 24 : pinned ? (int64_t)1 << 20 : (int64_t)1 << 24;
+        // the offsets on the device are 32-bit and relative to the chunk
+        const int64_t by_bytes = seg_bytes / ((int64_t)3 << 30) + 1;
+        if ((n + chunk - 1) / chunk < by_bytes) chunk = (n + by_bytes - 1) / by_bytes;
+    }
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    const int L = (int)(n_chunks < c->stream_lanes ? n_chunks : c->stream_lanes);
+    while ((int)c->lanes.size() < L) {
+        Lane *l = nullptr;
+        if (int rc = lane_create(&l)) return rc;
+        c->lanes.push_back(l);
+    }
+    c->last_ms.clear();
+    memset(c->stats, 0, sizeof(c->stats));
+    for (int i = 0; i < L; i++) {
+        c->lanes[i]->timed.clear();
+        c->lanes[i]->pool_used = 0;
+    }
+    if (int rc = ensure_host_hits(c, (size_t)(n < (1 << 18) ? (1 << 18) : n + n / 4))) return rc;
+    // a call of one chunk lets the fill kernel write the hits into the page-locked result buffer itself
+    uint32_t *zc_hits = n_chunks == 1 ? (uint32_t *)device_view(c->h_hits) : nullptr;
+    std::vector<ChunkPlan> plan((size_t)n_chunks);
+    const size_t isz = index_entry_size(index_format);
+    int64_t bytes_seen = 0;   // lengths formats: running sum of the row lengths
+    int64_t hit_base = 0;
+    int rc_all = SCT_OK;
+    auto drain = [&]() {
+        for (Lane *l : c->lanes) (void)hipStreamSynchronize(l->stream);
+    };
+
+    // phase A of chunk k: everything that can be queued without knowing any result
+    auto phase_a = [&](int64_t k) -> int {
+        Lane &l = *c->lanes[(size_t)(k % L)];
+        ChunkPlan &cp = plan[(size_t)k];
+        cp.r0 = k * chunk;
+        cp.r1 = cp.r0 + chunk < n ? cp.r0 + chunk : n;
+        const int64_t m = cp.r1 - cp.r0;
+        if (by_offs) {
+            cp.b0 = offs_at(cp.r0);
+            cp.b1 = offs_at(cp.r1);
+        } else if (n_chunks == 1) {
+            cp.b0 = 0;   // the device checks that the lengths add up to seg_bytes (k_index_lens); the host need not read them
+            cp.b1 = seg_bytes;
+            bytes_seen = seg_bytes;
+        } else {
+            cp.b0 = bytes_seen;
+            int64_t s = 0;
+            if (index_format == SCT_IDX_LEN8) {
+                const uint8_t *p = (const uint8_t *)index + cp.r0;
+                for (int64_t i = 0; i < m; i++) s += p[i];
+            } else {
+                const uint16_t *p = (const uint16_t *)index + cp.r0;
+                for (int64_t i = 0; i < m; i++) s += p[i];
+            }
+            cp.b1 = cp.b0 + s;
+            bytes_seen = cp.b1;
+        }
+        if (cp.b0 < 0 || cp.b1 < cp.b0 || cp.b1 > seg_bytes)
+            return fail(SCT_E_ARG, "the row index runs outside segs (rows %lld..%lld: bytes %lld..%lld of %lld)", (long long)cp.r0, (long long)cp.r1,
+                        (long long)cp.b0, (long long)cp.b1, (long long)seg_bytes);
+        const int64_t bytes = cp.b1 - cp.b0;
+        if (bytes >= 0xFFFFFFF0ll) return fail(SCT_E_ARG, "a chunk of %lld rows holds %lld bytes: lower the chunk_rows option", (long long)m, (long long)bytes);
+        l.bp = bp;
+        l.n_seg = m;
+        l.seg_bytes = bytes;
+        l.wide = false;
+        l.have_offs64 = false;
+        if (int rc = lane_ensure(l, m, bp)) return rc;
+        if (zc_min_e) {
+            l.min_e_ptr = zc_min_e + cp.r0;
+            l.direct_min_e = true;
+        }
+        if (zc_counts) {
+            if (count_format == SCT_CNT_U8) l.cnt8_ptr = (uint8_t *)zc_counts + cp.r0;
+            else l.cnt32_ptr = (uint32_t *)zc_counts + cp.r0;
+            l.direct_cnt = true;
+        }
+        if (zc_hits) {
+            l.hits_ptr = zc_hits;
+            l.hits_cap = c->h_hits_cap;
+            l.direct_hits = true;
+        }
+        if (l.offs32.ensure(4 * (size_t)(m + 1))) return SCT_E_HIP;
+        if (!zc_segs && l.segs.ensure((size_t)bytes + 64)) return SCT_E_HIP;
+        if ((!zc_index || !by_offs) && l.index_in.ensure(isz * (size_t)(m + 1) + 16)) return SCT_E_HIP;
+        hipStream_t st = l.stream;
+        if (int rc = reset_counters(l)) return rc;
+        const void *idx_dev = zc_index ? (const void *)(zc_index + isz * (size_t)cp.r0) : l.index_in.p;
+        if (zc_segs) {
+            l.segs_ptr = zc_segs + cp.b0;
+            l.host_segs = segs + cp.b0;
+        } else {
+            l.segs_ptr = l.segs.as<uint8_t>();
+            l.host_segs = nullptr;
+        }
+        if (!zc_segs || !zc_index) {
+            Timer t(c, l, "copy_h2d");
+            if (!zc_segs && bytes) HIPCHK(hipMemcpyAsync(l.segs.p, segs + cp.b0, (size_t)bytes, hipMemcpyHostToDevice, st));
+            if (!zc_index)
+                HIPCHK(hipMemcpyAsync(l.index_in.p, (const char *)index + isz * (size_t)cp.r0, isz * (size_t)(by_offs ? m + 1 : m), hipMemcpyHostToDevice, st));
+        }
+        {
+            Timer t(c, l, "k_index");
+            unsigned long long *bad = reinterpret_cast<unsigned long long *>(l.ctr() + CTR_BAD_ROW);
+            if (index_format == SCT_IDX_OFFS64)
+                k_index_offs<int64_t><<<blocks_for(m + 1, 256), 256, 0, st>>>((const int64_t *)idx_dev, m, bytes, l.offs32.as<uint32_t>(), bad);
+            else if (index_format == SCT_IDX_OFFS32)
+                k_index_offs<int32_t><<<blocks_for(m + 1, 256), 256, 0, st>>>((const int32_t *)idx_dev, m, bytes, l.offs32.as<uint32_t>(), bad);
+            else {
+                const int64_t nb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
+                uint64_t *total = reinterpret_cast<uint64_t *>(l.ctr() + CTR_TOTAL);  // free until the hit counts are summed
+                // a zero-copy index crosses the link once: the first pass leaves a copy on the device for the second
+                if (index_format == SCT_IDX_LEN8) {
+                    uint8_t *keep = zc_index ? l.index_in.as<uint8_t>() : nullptr;
+                    k_sum_blocks<uint8_t><<<(unsigned)nb, 256, 0, st>>>((const uint8_t *)idx_dev, m, l.sums.as<uint64_t>(), keep);
+                    k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
+                    k_index_lens<uint8_t><<<(unsigned)nb, 256, 0, st>>>(keep ? keep : (const uint8_t *)idx_dev, m, l.sums.as<uint64_t>(), total, bytes,
+                                                                       l.offs32.as<uint32_t>(), bad);
+                } else {
+                    uint16_t *keep = zc_index ? l.index_in.as<uint16_t>() : nullptr;
+                    k_sum_blocks<uint16_t><<<(unsigned)nb, 256, 0, st>>>((const uint16_t *)idx_dev, m, l.sums.as<uint64_t>(), keep);
+                    k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
+                    k_index_lens<uint16_t><<<(unsigned)nb, 256, 0, st>>>(keep ? keep : (const uint16_t *)idx_dev, m, l.sums.as<uint64_t>(), total, bytes,
+                                                                        l.offs32.as<uint32_t>(), bad);
+                }
+            }
+        }
+        if (int rc = queue_batch(c, l)) return rc;
+        if (!l.direct_min_e || (!l.direct_cnt && count_format != SCT_CNT_OFFS64)) {
+            Timer t(c, l, "copy_d2h");
+            if (!l.direct_min_e) HIPCHK(hipMemcpyAsync(min_e + cp.r0, l.min_e.p, (size_t)m, hipMemcpyDeviceToHost, st));
+            if (!l.direct_cnt) {
+                if (count_format == SCT_CNT_U8) HIPCHK(hipMemcpyAsync((uint8_t *)counts + cp.r0, l.cnt_out.p, (size_t)m, hipMemcpyDeviceToHost, st));
+                else if (count_format == SCT_CNT_U32)
+                    HIPCHK(hipMemcpyAsync((uint32_t *)counts + cp.r0, l.cnt_out.p, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
+            }
+        }
+        HIPCHK(hipEventRecord(l.done, st));
+        return SCT_OK;
+    };
+
+    // phase B of chunk k: wait for phase A, look at its counters, bring the hits home
+    auto phase_b = [&](int64_t k) -> int {
+        Lane &l = *c->lanes[(size_t)(k % L)];
+        ChunkPlan &cp = plan[(size_t)k];
+        const int64_t m = cp.r1 - cp.r0;
+        hipStream_t st = l.stream;
+        HIPCHK(hipEventSynchronize(l.done));
+        bool slow = false;
+        if (int rc = finish_batch(c, l, cp.r0, &slow)) return rc;
+        cp.hit_base = hit_base;
+        if (int rc = ensure_host_hits(c, (size_t)(hit_base + l.n_hits + 1))) return rc;
+        {
+            Timer t(c, l, "copy_d2h");
+            if (slow) {  // what phase A copied was not final
+                if (!l.direct_min_e) HIPCHK(hipMemcpyAsync(min_e + cp.r0, l.min_e.p, (size_t)m, hipMemcpyDeviceToHost, st));
+                if (!l.direct_cnt) {
+                    if (count_format == SCT_CNT_U8) HIPCHK(hipMemcpyAsync((uint8_t *)counts + cp.r0, l.cnt_out.p, (size_t)m, hipMemcpyDeviceToHost, st));
+                    else if (count_format == SCT_CNT_U32)
+                        HIPCHK(hipMemcpyAsync((uint32_t *)counts + cp.r0, l.cnt_out.p, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
+                }
+            }
+            if (count_format == SCT_CNT_OFFS64) {
+                // the chunk's offsets start at 0: add the hits of the chunks before it, then copy (the last entry of a chunk
+                // and the first of the next are the same element of the caller's array, with the same value)
+                if (hit_base) k_rebase<<<blocks_for(m + 1, 256), 256, 0, st>>>(l.hit_offs.as<int64_t>(), m + 1, hit_base);
+                HIPCHK(hipMemcpyAsync((int64_t *)counts + cp.r0, l.hit_offs.p, 8 * (size_t)(m + 1), hipMemcpyDeviceToHost, st));
+            }
+            if (l.n_hits && !l.direct_hits)
+                HIPCHK(hipMemcpyAsync(c->h_hits + hit_base, l.hits_ptr, 4 * (size_t)l.n_hits, hipMemcpyDeviceToHost, st));
+        }
+        hit_base += l.n_hits;
+        for (int i = 0; i < 5; i++) c->stats[i] += l.stats[i];
+        return SCT_OK;
+    };
+
+    // host time spent queueing (phase A) and waiting + collecting (phase B), reported beside the device spans
+    double host_a = 0, host_b = 0;
+    auto clk = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    for (int64_t k = 0; k < n_chunks + (L - 1) && rc_all == SCT_OK; k++) {
+        const double t0 = clk();
+        if (k < n_chunks) rc_all = phase_a(k);
+        const double t1 = clk();
+        const int64_t j = k - (L - 1);
+        if (rc_all == SCT_OK && j >= 0) rc_all = phase_b(j);
+        host_a += t1 - t0;
+        host_b += clk() - t1;
+    }
+    if (rc_all != SCT_OK) {
+        const std::string keep = g_err;
+        drain();
+        (void)hipGetLastError();
+        g_err = keep;
+        return rc_all;
+    }
+    for (int i = 0; i < L; i++) HIPCHK(hipStreamSynchronize(c->lanes[(size_t)i]->stream));
+    HIPCHK(hipGetLastError());
+    if (!by_offs && bytes_seen != seg_bytes)
+        return fail(SCT_E_ARG, "the row lengths add up to %lld but segs holds %lld bytes", (long long)bytes_seen, (long long)seg_bytes);
+    for (int i = 0; i < L; i++) collect_timing(c, *c->lanes[(size_t)i]);
+    c->last_ms.emplace_back("host_queue", sct_ctx::Span{host_a, (int)n_chunks});
+    c->last_ms.emplace_back("host_wait", sct_ctx::Span{host_b, (int)n_chunks});
+    c->lane0().have_result = false;  // lane 0 no longer holds a resident upload's result
+    c->lane0().n_seg = -1;
+    *hits_out = c->h_hits;
+    *n_hits_out = hit_base;
     return SCT_OK;
 }
 
@@ -640,34 +1219,33 @@ extern "C" int sct_match(sct_ctx *c, const char *segs, const int64_t *offs, int6
     if (!hits || !n_hits || !min_e || !hit_offs) return fail(SCT_E_ARG, "sct_match: NULL output pointer");
     *hits = nullptr;
     *n_hits = 0;
-    int rc = sct_upload_segments(c, segs, offs, n);
-    if (rc) return rc;
+    if (n < 0 || !offs) return fail(SCT_E_ARG, "sct_match: bad offsets");
+    const uint32_t *h = nullptr;
     int64_t total = 0;
-    rc = sct_run(c, max_err, threads, &total);
+    int rc = sct_match_stream(c, segs, offs[n], offs, SCT_IDX_OFFS64, n, max_err, threads, min_e, hit_offs, SCT_CNT_OFFS64, &h, &total);
     if (rc) return rc;
-    uint32_t *h = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(total ? total : 1));
-    if (!h) return fail(SCT_E_ARG, "out of host memory for %lld hits", (long long)total);
-    rc = sct_download(c, min_e, hit_offs, h);
-    if (rc) {
-        free(h);
-        return rc;
-    }
-    *hits = h;
+    uint32_t *out = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(total ? total : 1));
+    if (!out) return fail(SCT_E_ARG, "out of host memory for %lld hits", (long long)total);
+    if (total) memcpy(out, h, sizeof(uint32_t) * (size_t)total);
+    *hits = out;
     *n_hits = total;
     return SCT_OK;
 }
 
 extern "C" void sct_free_hits(sct_ctx *, uint32_t *hits) { free(hits); }
 
-extern "C" int sct_last_timing(sct_ctx *c, const char **names, float *ms, int cap) {
+extern "C" int sct_last_timing_ex(sct_ctx *c, const char **names, float *ms, int32_t *launches, int cap) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
     const int k = (int)c->last_ms.size();
     for (int i = 0; i < k && i < cap; i++) {
         if (names) names[i] = c->last_ms[i].first;
-        if (ms) ms[i] = c->last_ms[i].second;
+        if (ms) ms[i] = (float)c->last_ms[i].second.ms;
+        if (launches) launches[i] = c->last_ms[i].second.launches;
     }
     return k;
 }
+
+extern "C" int sct_last_timing(sct_ctx *c, const char **names, float *ms, int cap) { return sct_last_timing_ex(c, names, ms, nullptr, cap); }
 
 extern "C" int sct_last_stats(sct_ctx *c, int64_t *out, int cap) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
@@ -732,9 +1310,10 @@ extern "C" int sct_wl_set(sct_ctx *c, const char *keys, const int32_t *key_lens,
             len_set |= 1u << L;
         }
     }
+    hipStream_t st = c->lane0().stream;
     if (c->wl_table.ensure(tab.size() * sizeof(SctWlSlot))) return SCT_E_HIP;
-    HIPCHK(hipMemcpyAsync(c->wl_table.p, tab.data(), tab.size() * sizeof(SctWlSlot), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(c->wl_table.p, tab.data(), tab.size() * sizeof(SctWlSlot), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
     c->wl_mask = mask;
     c->wl_len_set = len_set;
     c->wl_n = n;
@@ -748,30 +1327,30 @@ extern "C" int sct_wl_count(sct_ctx *c, const char *segs, const int64_t *offs, c
     if (!counts || !first_seen || (n > 0 && !skip)) return fail(SCT_E_ARG, "sct_wl_count: NULL argument");
     int rc = sct_upload_segments(c, segs, offs, n);
     if (rc) return rc;
+    Lane &l = c->lane0();
     const size_t nk = (size_t)(c->wl_n > 0 ? c->wl_n : 1);
     if (c->wl_counts.ensure(4 * nk) || c->wl_first.ensure(4 * nk) || c->wl_skip.ensure((size_t)(n ? n : 1))) return SCT_E_HIP;
-    hipStream_t st = c->stream;
-    c->timed.clear();
-    c->pool_used = 0;
+    hipStream_t st = l.stream;
+    c->last_ms.clear();
+    l.timed.clear();
+    l.pool_used = 0;
     HIPCHK(hipMemsetAsync(c->wl_counts.p, 0, 4 * nk, st));
     HIPCHK(hipMemsetAsync(c->wl_first.p, 0xFF, 4 * nk, st));
     if (n > 0) {
         HIPCHK(hipMemcpyAsync(c->wl_skip.p, skip, (size_t)n, hipMemcpyHostToDevice, st));
-        Timer t(c, "k_wl_count");
-        k_wl_count<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), c->wl_skip.as<uint8_t>(), n,
+        Timer t(c, l, "k_wl_count");
+        k_wl_count<<<blocks_for(n, 256), 256, 0, st>>>(l.segs.as<uint8_t>(), l.offs64.as<int64_t>(), c->wl_skip.as<uint8_t>(), n,
                                                       c->wl_table.as<SctWlSlot>(), c->wl_mask, c->wl_len_set,
                                                       c->wl_counts.as<uint32_t>(), c->wl_first.as<uint32_t>());
     }
     std::vector<uint32_t> hc(nk), hf(nk);
-    HIPCHK(hipMemcpyAsync(hc.data(), c->wl_counts.p, 4 * nk, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(hf.data(), c->wl_first.p, 4 * nk, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipGetLastError());
-    c->last_ms.clear();
-    for (const TimedKernel &t : c->timed) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) c->last_ms.emplace_back(t.name, ms);
-    }
+    hipError_t e = hipMemcpyAsync(hc.data(), c->wl_counts.p, 4 * nk, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hf.data(), c->wl_first.p, 4 * nk, hipMemcpyDeviceToHost, st);
+    const hipError_t es = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = es;
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail(SCT_E_HIP, "whitelist counting failed: %s", hipGetErrorString(e));
+    collect_timing(c, l);
     for (int32_t i = 0; i < c->wl_n; i++) {
         counts[i] = hc[(size_t)i];
         first_seen[i] = hf[(size_t)i] == 0xFFFFFFFFu ? -1 : (int64_t)hf[(size_t)i];
@@ -794,6 +1373,7 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
         if ((uint8_t)adapter[i] >= 128) return fail(SCT_E_ARG, "adapter contains a byte >= 128");
     int rc = sct_upload_segments(c, reads, offs, n);
     if (rc) return rc;
+    Lane &l = c->lane0();
     // match masks: adapter, its reverse complement (rev_compl, scTagger.py:148-156, :365), and that one reversed
     std::vector<uint32_t> peq(3 * 256, 0u);
     std::vector<uint8_t> a2((size_t)m);
@@ -804,63 +1384,73 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
         peq[512 + a2[m - 1 - i]] |= 1u << i;
     }
     const size_t n1 = (size_t)(n ? n : 1);
-    if (c->ad_peq.ensure(peq.size() * 4) || c->ad_strand.ensure(n1) || c->ad_dist.ensure(4 * n1) || c->cnt.ensure(4 * n1) ||
-        c->ad_first.ensure(8 * n1) || c->ad_last.ensure(8 * n1) ||
-        c->hit_offs.ensure(8 * (n1 + 1)) || c->total.ensure(8))
+    if (c->ad_peq.ensure(peq.size() * 4) || c->ad_strand.ensure(n1) || c->ad_dist.ensure(4 * n1) || l.cnt.ensure(4 * n1) ||
+        c->ad_first.ensure(8 * n1) || c->ad_last.ensure(8 * n1) || l.hit_offs.ensure(8 * (n1 + 1)) ||
+        l.counters.ensure(sizeof(uint32_t) * CTR_WORDS))
         return SCT_E_HIP;
     const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    if (c->sums.ensure(8 * (size_t)(nb ? nb : 1))) return SCT_E_HIP;
-    hipStream_t st = c->stream;
-    c->timed.clear();
-    c->pool_used = 0;
-    c->have_result = false;
-    HIPCHK(hipMemcpyAsync(c->ad_peq.p, peq.data(), peq.size() * 4, hipMemcpyHostToDevice, st));
+    if (l.sums.ensure(8 * (size_t)(nb ? nb : 1))) return SCT_E_HIP;
+    hipStream_t st = l.stream;
+    c->last_ms.clear();
+    l.timed.clear();
+    l.pool_used = 0;
+    l.have_result = false;
+    uint64_t *d_total = reinterpret_cast<uint64_t *>(l.ctr() + CTR_TOTAL);
     uint64_t total = 0;
-    if (n > 0) {
+    int32_t *h = nullptr;
+    // every exit below goes through `done`: the stream is synchronised before peq (a local) goes away and `h` is released on failure
+    hipError_t e = hipMemcpyAsync(c->ad_peq.p, peq.data(), peq.size() * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n > 0) {
         {
-            Timer t(c, "k_adapter_count");
-            k_adapter_count<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), n, c->ad_peq.as<uint32_t>(), m,
-                                                               c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), c->cnt.as<uint32_t>(),
+            Timer t(c, l, "k_adapter_count");
+            k_adapter_count<<<blocks_for(n, 256), 256, 0, st>>>(l.segs.as<uint8_t>(), l.offs64.as<int64_t>(), n, c->ad_peq.as<uint32_t>(), m,
+                                                               c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), l.cnt.as<uint32_t>(),
                                                                c->ad_first.as<int64_t>(), c->ad_last.as<int64_t>());
         }
         {
-            Timer t(c, "k_offsets");
-            k_sum_blocks<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>());
-            k_scan_sums<<<1, 256, 0, st>>>(c->sums.as<uint64_t>(), nb, c->total.as<uint64_t>());
-            k_offsets<<<(unsigned)nb, 256, 0, st>>>(c->cnt.as<uint32_t>(), n, c->sums.as<uint64_t>(), c->total.as<uint64_t>(),
-                                                    c->hit_offs.as<int64_t>());
+            Timer t(c, l, "k_offsets");
+            k_sum_blocks<uint32_t><<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), nullptr);
+            k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, d_total);
+            k_offsets<<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), d_total, l.hit_offs.as<int64_t>(), nullptr,
+                                                    nullptr, l.ctr());
         }
-        HIPCHK(hipMemcpyAsync(&total, c->total.p, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (c->ad_locs.ensure(4 * (size_t)(total ? total : 1))) return SCT_E_HIP;
-        if (total) {
-            Timer t(c, "k_adapter_fill");
-            k_adapter_fill<<<blocks_for(n, 256), 256, 0, st>>>(c->segs.as<uint8_t>(), c->offs.as<int64_t>(), n, c->ad_peq.as<uint32_t>(), m,
-                                                              c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), c->ad_first.as<int64_t>(),
-                                                              c->ad_last.as<int64_t>(), c->hit_offs.as<int64_t>(), c->ad_locs.as<int32_t>());
+        e = hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st);
+    }
+    {
+        const hipError_t es = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = es;
+    }
+    if (e == hipSuccess && n > 0 && total) {
+        if (c->ad_locs.ensure(4 * (size_t)total)) return SCT_E_HIP;
+        Timer t(c, l, "k_adapter_fill");
+        k_adapter_fill<<<blocks_for(n, 256), 256, 0, st>>>(l.segs.as<uint8_t>(), l.offs64.as<int64_t>(), n, c->ad_peq.as<uint32_t>(), m,
+                                                          c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), c->ad_first.as<int64_t>(),
+                                                          c->ad_last.as<int64_t>(), l.hit_offs.as<int64_t>(), c->ad_locs.as<int32_t>());
+    }
+    if (e == hipSuccess) {
+        h = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total ? total : 1));
+        if (!h) {
+            (void)hipStreamSynchronize(st);
+            return fail(SCT_E_ARG, "out of host memory");
         }
-    } else {
-        loc_offs[0] = 0;
     }
-    int32_t *h = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total ? total : 1));
-    if (!h) return fail(SCT_E_ARG, "out of host memory");
-    if (n > 0) {
-        HIPCHK(hipMemcpyAsync(strand, c->ad_strand.p, (size_t)n, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(dist, c->ad_dist.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(loc_offs, c->hit_offs.p, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
-        if (total) HIPCHK(hipMemcpyAsync(h, c->ad_locs.p, 4 * (size_t)total, hipMemcpyDeviceToHost, st));
+    if (n == 0) loc_offs[0] = 0;
+    if (e == hipSuccess && n > 0) {
+        e = hipMemcpyAsync(strand, c->ad_strand.p, (size_t)n, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(dist, c->ad_dist.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(loc_offs, l.hit_offs.p, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && total) e = hipMemcpyAsync(h, c->ad_locs.p, 4 * (size_t)total, hipMemcpyDeviceToHost, st);
     }
-    hipError_t e = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = hipGetLastError();
+    {
+        const hipError_t es = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = es;
+        if (e == hipSuccess) e = hipGetLastError();
+    }
     if (e != hipSuccess) {
         free(h);
         return fail(SCT_E_HIP, "adapter alignment failed: %s", hipGetErrorString(e));
     }
-    c->last_ms.clear();
-    for (const TimedKernel &t : c->timed) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) c->last_ms.emplace_back(t.name, ms);
-    }
+    collect_timing(c, l);
     *locs = h;
     *n_locs = (int64_t)total;
     return SCT_OK;

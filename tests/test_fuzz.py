@@ -80,11 +80,11 @@ def test_gpu_fuzz_all_paths():
             bc, segs, offs = random_case(rng, n_bc, n_seg, bl, int(rng.choice([22, 31, 32, 63, 64, 90])))
             want = trie_oracle.match(bc, segs, offs, e, threads=t, workers=8)
             m.set_barcodes(bc, bl)
-            for opts in ({"force_exhaustive": 0, "filter_mode": 0, "slots": 1}, {"force_exhaustive": 0, "filter_mode": 0, "slots": 0},
-                         {"force_exhaustive": 0, "filter_mode": 1, "slots": -1}, {"force_exhaustive": 1, "filter_mode": 0, "slots": -1}):
+            for opts in ({"force_exhaustive": 0, "chunk_rows": 0, "slots": 1}, {"force_exhaustive": 0, "chunk_rows": 64, "slots": 0},
+                         {"force_exhaustive": 0, "chunk_rows": 7, "slots": -1}, {"force_exhaustive": 1, "chunk_rows": 100, "slots": -1}):
                 for k, v in opts.items():
                     m.set_option(k, v)
                 util.assert_same(m.match(segs, offs, e, t), want, "trial %d bl=%d e=%d t=%d n_bc=%d %s" % (trial, bl, e, t, n_bc, opts))
             m.set_option("force_exhaustive", 0)
-            m.set_option("filter_mode", 0)
+            m.set_option("chunk_rows", 0)
             m.set_option("slots", -1)

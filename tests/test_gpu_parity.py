@@ -24,19 +24,99 @@ def m():
     mm.close()
 
 
-def run_both(m, bc, segs, offs, e, t=1):
+def counts_to_offsets(counts, fmt):
+    if fmt == _native.CNT_OFFS64:
+        return counts
+    o = np.zeros(counts.size + 1, dtype=np.int64)
+    np.cumsum(counts, out=o[1:])
+    return o
+
+
+def check_stream_variants(m, segs, offs, e, t, want, chunk_rows=None):
+    """The pipelined entry (sct_match_stream) in every index / count format, cut into several chunks, against `want`."""
+    n = offs.size - 1
+    lens = np.diff(offs)
+    max_cnt = int(np.diff(want[1]).max()) if n else 0
+    m.set_option("chunk_rows", chunk_rows or max(1, n // 5 + 1))
+    try:
+        idx = [(_native.IDX_OFFS64, offs), (_native.IDX_OFFS32, offs.astype(np.int32))]
+        if n and lens.max() <= 255:
+            idx.append((_native.IDX_LEN8, lens.astype(np.uint8)))
+        if n and lens.max() <= 65535:
+            idx.append((_native.IDX_LEN16, lens.astype(np.uint16)))
+        for k, (ifmt, index) in enumerate(idx):
+            for cfmt in (_native.CNT_OFFS64, _native.CNT_U32, _native.CNT_U8):
+                if k > 1 and cfmt != _native.CNT_U8:
+                    continue                       # the length formats with one count format are enough
+                if cfmt == _native.CNT_U8 and max_cnt > 255:
+                    with pytest.raises(_native.SctError) as ei:
+                        m.match_stream(segs, index, e, t, index_format=ifmt, count_format=cfmt)
+                    assert ei.value.code == _native.E_RANGE
+                    continue
+                me, cnt, hits = m.match_stream(segs, index, e, t, index_format=ifmt, count_format=cfmt)
+                util.assert_same((me, counts_to_offsets(cnt, cfmt), hits), want, "stream idx=%d cnt=%d" % (ifmt, cfmt))
+    finally:
+        m.set_option("chunk_rows", 0)
+
+
+def pinned_copy(m, a):
+    p = m.host_array(max(a.size, 1), a.dtype)[:a.size]
+    p[:] = a
+    return p
+
+
+def check_zero_copy(m, segs, offs, e, t, want, chunk_rows=0):
+    """sct_match_stream on page-locked buffers: the kernels read segs / index in place over the host link and write min_e, the
+    compact counts and (single chunk) the hits straight into page-locked memory."""
+    n = offs.size - 1
+    lens = np.diff(offs)
+    psegs = pinned_copy(m, segs)
+    max_cnt = int(np.diff(want[1]).max()) if n else 0
+    idx = [(_native.IDX_OFFS64, offs), (_native.IDX_OFFS32, offs.astype(np.int32))]
+    if n and lens.max() <= 255:
+        idx.append((_native.IDX_LEN8, lens.astype(np.uint8)))
+    if n and lens.max() <= 65535:
+        idx.append((_native.IDX_LEN16, lens.astype(np.uint16)))
+    m.set_option("chunk_rows", chunk_rows)
+    try:
+        for ifmt, index in idx:
+            pidx = pinned_copy(m, index)
+            for cfmt in (_native.CNT_U8, _native.CNT_U32, _native.CNT_OFFS64):
+                pme = m.host_array(max(n, 1), np.uint8)
+                pcnt = m.host_array(n + 1, _native._CNT_DTYPE[cfmt])
+                pme[:] = 7            # stale contents must not survive
+                pcnt[:] = 9
+                if cfmt == _native.CNT_U8 and max_cnt > 255:
+                    with pytest.raises(_native.SctError) as ei:
+                        m.match_stream(psegs, pidx, e, t, index_format=ifmt, count_format=cfmt, min_e=pme, counts=pcnt)
+                    assert ei.value.code == _native.E_RANGE
+                    continue
+                me, cnt, hits = m.match_stream(psegs, pidx, e, t, index_format=ifmt, count_format=cfmt, min_e=pme, counts=pcnt,
+                                               copy_hits=False)
+                util.assert_same((me, counts_to_offsets(cnt, cfmt), hits), want, "zero copy idx=%d cnt=%d chunk=%d" % (ifmt, cfmt, chunk_rows))
+    finally:
+        m.set_option("chunk_rows", 0)
+        m.sync()
+        del psegs, pidx
+        m.release_host_arrays()
+
+
+def run_both(m, bc, segs, offs, e, t=1, stream=True):
     """-> (filter-path result, exhaustive-path result)"""
     m.set_barcodes(bc)
     m.set_option("force_exhaustive", 0)
-    m.set_option("filter_mode", 0)
     a = m.match(segs, offs, e, t)
     for sl in (0, 1):                       # with and without the bucket slots, whatever the library would pick
         m.set_option("slots", sl)
         util.assert_same(m.match(segs, offs, e, t), a, "slots=%d vs default" % sl)
     m.set_option("slots", -1)
-    m.set_option("filter_mode", 1)          # the one-lane-per-segment variant must agree bit for bit
-    util.assert_same(m.match(segs, offs, e, t), a, "filter_mode 1 vs 0")
-    m.set_option("filter_mode", 0)
+    m.upload_segments(segs, offs)           # the resident three-step API: one batch, int64 offsets on the device
+    m.run(e, t)
+    util.assert_same(m.download(), a, "upload/run/download vs match")
+    if stream:
+        check_stream_variants(m, segs, offs, e, t, a)
+        check_zero_copy(m, segs, offs, e, t, a)
+        check_zero_copy(m, segs, offs, e, t, a, chunk_rows=max(1, (offs.size - 1) // 3 + 1))
     m.set_option("force_exhaustive", 1)
     b = m.match(segs, offs, e, t)
     m.set_option("force_exhaustive", 0)
@@ -279,6 +359,23 @@ def test_error_behaviour(m):
     bad[3] = 200
     with pytest.raises(_native.SctError):          # reference: IndexError on map_char[>=128]
         m.match(bad, offs, 2)
+    pbad, poffs = pinned_copy(m, bad), pinned_copy(m, offs)
+    with pytest.raises(_native.SctError):          # the same through the zero-copy path
+        m.match_stream(pbad, poffs, 2, 1, index_format=_native.IDX_OFFS64, count_format=_native.CNT_U8)
+    lens = np.diff(offs)
+    wrong = lens.astype(np.uint8)
+    wrong[-1] += 1                                 # lengths that do not add up to the bytes given
+    for arr in (wrong, pinned_copy(m, wrong)):
+        with pytest.raises(_native.SctError):
+            m.match_stream(pinned_copy(m, segs) if arr is not wrong else segs, arr, 2, 1, index_format=_native.IDX_LEN8)
+    down = offs.astype(np.int32).copy()
+    down[3], down[4] = down[4], down[3]            # offsets that decrease
+    if down[3] != down[4]:
+        with pytest.raises(_native.SctError):
+            m.match_stream(segs, down, 2, 1, index_format=_native.IDX_OFFS32)
+    with pytest.raises(_native.SctError) as ei:    # -t whose window prefix reaches bl - max_err: not reproduced
+        m.match(segs, offs, 2, 4 ** 14)
+    assert ei.value.code == -5
     with pytest.raises(_native.SctError):
         m.set_barcodes(np.full((2, 33), ord("A"), dtype=np.uint8))
     hi = bc.copy()
@@ -299,8 +396,11 @@ def test_cfg2_full_size_properties(m):
     permutation equivariance; planted exact copies are found at distance 0."""
     bc = synth.make_barcodes(5000, seed=2)
     segs, offs = synth.make_segments(1_000_000, bc, seed=2)
-    a, b = run_both(m, bc, segs, offs, 2)
+    a, b = run_both(m, bc, segs, offs, 2, stream=False)
     util.assert_same(a, b, "filter vs exhaustive at 1M x 5k")
+    check_stream_variants(m, segs, offs, 2, 1, a, chunk_rows=150_000)
+    check_zero_copy(m, segs, offs, 2, 1, a)
+    check_zero_copy(m, segs, offs, 2, 1, a, chunk_rows=300_000)
     n = offs.size - 1
     assert a[1][-1] == a[2].size and (np.diff(a[1]) >= 0).all()
     matched = a[0] != 255
@@ -343,7 +443,7 @@ def test_cfg3_sample_vs_exhaustive_and_oracle(m):
     """BASELINE configs[2] barcode set (25k), 2M-segment batch: filter path == exhaustive path; 10k rows == oracle."""
     bc = synth.make_barcodes(25000, seed=3)
     segs, offs = synth.make_segments(2_000_000, bc, seed=3)
-    a, b = run_both(m, bc, segs, offs, 2, t=16)
+    a, b = run_both(m, bc, segs, offs, 2, t=16, stream=False)
     util.assert_same(a, b, "filter vs exhaustive at 2M x 25k")
     k = 10000
     want = trie_oracle.match(bc, segs[:offs[k]], offs[:k + 1], 2, threads=16, workers=8)
