@@ -1,11 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — LR segments matched/sec on MI355X for the match_trie path (BASELINE.json metric).
 
-A step = one pass of the whole device path (every kernel of sct_run: pack, seed filter, scans, CSR
-assembly) over one batch of synthetic segments that is already resident in HBM.  At N = 1 the batch is
-BASELINE.json configs[2] ("10M LR segments x 25k barcodes, bl=16 e<=2, 1xMI355X"), the configuration the
-metric is quoted on; with N > 1 every rank runs its own batch of the same size (independent rid shards,
-no data-path collective: weak scaling), seeds 40+rank as SURVEY.md §8(d) prescribes for cfg4.
+A step = one pass of the WHOLE seam over one batch of synthetic segments, device end to end (SURVEY.md §8(d) figure
+(ii), the north-star figure): the batch starts in page-locked HOST memory in the caller's format (ASCII bytes + uint8
+row lengths), goes through sct_match_stream — the kernels read it in place over PCIe — and ends with min_e, the hit
+counts and the hit lists back in page-locked host memory.  That is `value`.  The same kernels on a batch already
+resident in HBM (figure (i)) are timed in a second loop and reported as `value_resident`; the roofline object is taken
+from that loop (one launch of the dominant kernel over the whole batch, no link in the way).  `cli_e2e` (figure (iii))
+times the drop-in command itself, gz TSV in -> gz TSV out.
+
+At N = 1 the batch is BASELINE.json configs[2] ("10M LR segments x 25k barcodes, bl=16 e<=2, 1xMI355X"), the
+configuration the metric is quoted on.  With N > 1 every rank runs its own batch (independent rid shards, no data-path
+collective: weak scaling) with seeds 40+rank as SURVEY.md §8(d) prescribes for cfg4; at N = 8 the batch is cfg4's
+shard, 12.5 M segments per GPU.  Every rank reports its own times (`per_rank`): a scaling loss can only come from the
+host side (page-locked memory bandwidth shared by the ranks, NUMA placement) and shows there.
 
 Launch: `python bench.py` (N=1) or
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -30,12 +38,18 @@ WORKLOADS = {
     # name: (segments per GPU, barcodes, bl, max_err)
     "cfg2": (1_000_000, 5_000, 16, 2),
     "cfg3": (10_000_000, 25_000, 16, 2),
+    "cfg4": (12_500_000, 25_000, 16, 2),   # one GPU's shard of the 100 M-segment configuration
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Non-packed 32-bit integer VALU ops issue one wave64 instruction per 4 cycles per SIMD (SQ_ACTIVE_INST_VALU counts
-# one quad-cycle per instruction; SURVEY.md §7: 256 CU x 64 lanes x 2.4 GHz = 3.9e13 lane-ops/s):
-VALU_PEAK_WINST_S = 256 * 4 * 2.4e9 / 4
+PCIE_PEAK_GBS = 63.0   # MI355X_MICROARCH.md: PCIe Gen5 x16 (spec); 57 GB/s measured (profiles/r02_pcie_probe.json)
+# Integer VALU ceiling, measured (tools/valu_peak.hip -> profiles/r02_valu_issue_rates.md): shifts, three-operand and
+# packed 16-bit integer ops — what the verification automaton is made of — issue one wave64 instruction per ~4.1 cycles per
+# SIMD whatever the occupancy (5.9e11 wave-instructions/s for the chip); plain and / xor / add issue every ~2.2 cycles.
+VALU_PEAK_WINST_S = 5.9e11
+VALU_PEAK_FULL_RATE_WINST_S = 1.1e12
 L2_PEAK_REQ_S = 8 * 16 * 2.4e9   # L2: 16 channels per XCD, one 128-byte request per channel and clock (MI355X_MICROARCH.md: 34.5 TB/s)
+IDX = {"len8": _native.IDX_LEN8, "len16": _native.IDX_LEN16, "offs32": _native.IDX_OFFS32, "offs64": _native.IDX_OFFS64}
+CNT = {"u8": _native.CNT_U8, "u32": _native.CNT_U32, "offs64": _native.CNT_OFFS64}
 
 
 def baseline_metric():
@@ -68,6 +82,17 @@ def make_batch(n, bc, seed, chunk=1_000_000, seg_len=22):
     return np.concatenate(segs), np.concatenate(offs)
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(bc, segs, offs, max_err, sample):
     """The oracle (C restatement of the reference's trie + prefix tasks) timed on this host's cores on a
     bounded sample of the same workload.  A reported baseline; never the product path."""
@@ -82,7 +107,7 @@ def cpu_baseline(bc, segs, offs, max_err, sample):
     t0 = time.perf_counter()
     trie_oracle.match(bc, segs[:offs[n]], offs[:n + 1], max_err, threads=16, workers=min(cores, 16))
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "segments/s", "cores": min(cores, 16), "kind": "port",
+    return {"value": n / dt, "unit": "segments/s", "cores": min(cores, 16), "cpu": cpu_model(), "kind": "port",
             "sample": "first %d segments of the batch x %d barcodes, e<=%d, reference -t 16 (16 prefix tasks)" % (
                 n, bc.shape[0], max_err), "seconds": round(dt, 2)}
 
@@ -92,23 +117,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: cfg3, or cfg4's shard when --gpus is 8")
     ap.add_argument("--segments", type=int, default=None, help="override segments per GPU")
     ap.add_argument("--barcode-length", type=int, default=None, help="override the workload's barcode length (exploration)")
     ap.add_argument("--barcodes", type=int, default=None, help="override the workload's barcode count (exploration)")
     ap.add_argument("--max-err", type=int, default=None, help="override the workload's max_err (exploration)")
     ap.add_argument("--slots", type=int, default=-1, help="bucket slots of the seed tables: -1 = library default, 0 = off, 1 = on (exploration)")
     ap.add_argument("--seg-len", type=int, default=22, help="segment length of the synthetic rows (22 = the reference's nominal length)")
+    ap.add_argument("--index-format", default="len8", choices=sorted(IDX), help="row index handed to the seam (len8 = one byte per row)")
+    ap.add_argument("--count-format", default="u8", choices=sorted(CNT), help="hit counts taken from the seam (u8 = one byte per row)")
+    ap.add_argument("--chunk-rows", type=int, default=0, help="sct_match_stream's chunk_rows option (0 = library default)")
+    ap.add_argument("--zero-copy", type=int, default=1, help="0 = upload the page-locked buffers instead of reading them in place")
+    ap.add_argument("--mode", default="both", choices=["both", "e2e", "resident"], help="which loops to run (profiling passes use one)")
     ap.add_argument("--cpu-sample", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cli", action="store_true", help="skip the CLI end-to-end timing (figure (iii))")
+    ap.add_argument("--cli-rows", type=int, default=10_000_000)
     ap.add_argument("--force-exhaustive", action="store_true", help="time the all-barcodes scan instead of the seed filter")
-    ap.add_argument("--filter-mode", type=int, default=0, help="0 = wave-cooperative filter kernel (default), 1 = lane-per-segment variant")
     args = ap.parse_args()
 
     rank, local_rank, world = shard.rank_info()
     dist = shard.init_dist()
 
-    n_seg, n_bc, bl, max_err = WORKLOADS[args.workload]
+    wl = args.workload or ("cfg4" if world == 8 else "cfg3")
+    n_seg, n_bc, bl, max_err = WORKLOADS[wl]
     if args.segments:
         n_seg = args.segments
     if args.barcode_length:
@@ -117,26 +149,28 @@ def main():
         n_bc = args.barcodes
     if args.max_err is not None:
         max_err = args.max_err
+    # one rank per GPU; with fewer visible devices than ranks (rehearsing N > 1 on a one-GPU box) ranks share devices
+    ndev = max(1, _native.device_count())
+    device = local_rank % ndev
+    numa = shard.bind_to_device_numa(device) if world > 1 else None
     bc = synth.make_barcodes(n_bc, bl=bl, seed=3)
     seed = 3 if world == 1 else 40 + rank
     segs, offs = make_batch(n_seg, bc, seed, seg_len=args.seg_len)
 
-    # one rank per GPU; with fewer visible devices than ranks (rehearsing N > 1 on a one-GPU box) ranks share devices
-    ndev = max(1, _native.device_count())
-    m = _native.Matcher(local_rank % ndev)
+    m = _native.Matcher(device)
     m.set_barcodes(bc)
     if args.force_exhaustive:
         m.set_option("force_exhaustive", 1)
-    m.set_option("filter_mode", args.filter_mode)
     if args.slots >= 0:
         m.set_option("slots", args.slots)
-    m.upload_segments(segs, offs)
+    m.set_option("chunk_rows", args.chunk_rows)
+    m.set_option("zero_copy", args.zero_copy)
 
     def barrier():
         shard.barrier(dist)
 
     def device_sync():
-        m.sync()                      # the library's own stream (torch.cuda.synchronize would not see it)
+        m.sync()                      # the library's own streams (torch.cuda.synchronize would not see them)
         if dist is not None:
             try:
                 import torch
@@ -145,24 +179,105 @@ def main():
             except Exception:
                 pass
 
-    for _ in range(args.warmup):
-        m.run(max_err, threads=1)
-    device_sync()
-    barrier()
-    per_kernel = {}
-    t0 = time.perf_counter()
+    # ---- figure (ii): the seam, page-locked host memory -> device -> page-locked host memory -----------------------
+    ifmt, cfmt = IDX[args.index_format], CNT[args.count_format]
+    lens = np.diff(offs)
+    index = {"len8": lambda: lens.astype(np.uint8), "len16": lambda: lens.astype(np.uint16),
+             "offs32": lambda: offs.astype(np.int32), "offs64": lambda: offs}[args.index_format]()
+    psegs = m.host_array(segs.size, np.uint8)
+    psegs[:] = segs
+    pidx = m.host_array(index.size, index.dtype)
+    pidx[:] = index
+    pme = m.host_array(n_seg, np.uint8)
+    pcnt = m.host_array(n_seg + 1, _native._CNT_DTYPE[cfmt])
+    e2e = None
+    e2e_elapsed = None
     hits = 0
-    for _ in range(args.steps):
-        hits = m.run(max_err, threads=1)
-        for name, ms in m.last_timing():
-            per_kernel.setdefault(name, []).append(ms)
-    device_sync()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    elapsed, total_segments = shard.reduce_timing(dist, elapsed, n_seg)
+    if args.mode in ("both", "e2e"):
+        def step():
+            return m.match_stream(psegs, pidx, max_err, 1, index_format=ifmt, count_format=cfmt, min_e=pme, counts=pcnt, copy_hits=False)
+        for _ in range(args.warmup):
+            step()
+        device_sync()
+        barrier()
+        spans = {}
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r = step()
+            for name, ms, k in m.last_timing_ex():
+                spans.setdefault(name, []).append((ms, k))
+        device_sync()
+        e2e_elapsed = time.perf_counter() - t0
+        barrier()
+        hits = int(r[2].size)
+        h2d_bytes = int(segs.size + index.nbytes)
+        d2h_bytes = int(n_seg + pcnt[:n_seg + (1 if cfmt == _native.CNT_OFFS64 else 0)].nbytes + 4 * hits)
+        avg = {k: float(np.mean([x[0] for x in v])) for k, v in spans.items()}
+        launches = {k: int(v[-1][1]) for k, v in spans.items()}
+        e2e = {"ms_per_step": 1e3 * e2e_elapsed / max(args.steps, 1), "index_format": args.index_format, "count_format": args.count_format,
+               "host_to_device_bytes": h2d_bytes, "device_to_host_bytes": d2h_bytes,
+               "zero_copy": bool(args.zero_copy), "chunks": launches.get("k_filter", 0),
+               "spans_ms": {k: round(v, 4) for k, v in avg.items()},
+               "spans_note": "device time per step by kernel name (HIP events on the kernel's stream, summed over the step's launches). "
+                             "With zero_copy the input crosses PCIe INSIDE k_index (row lengths) and k_filter (segment bytes), min_e is "
+                             "written to host memory by k_filter, the counts by k_offsets and the hit lists by k_fill: there are no "
+                             "separate copies to time; host_queue / host_wait are the calling thread's own time"}
+        if args.zero_copy and "k_filter" in avg:
+            e2e["k_filter_input_GBps"] = round(segs.size / (avg["k_filter"] * 1e-3) / 1e9, 1)
+            e2e["pcie_peak_GBps"] = PCIE_PEAK_GBS
+
+    # ---- figure (i): the same kernels on a batch that is resident in HBM (roofline of the dominant kernel) -------------
+    res = None
+    per_kernel = {}
+    if args.mode in ("both", "resident"):
+        m.upload_segments(psegs, offs)
+        for _ in range(max(1, min(args.warmup, 2))):
+            m.run(max_err, threads=1)
+        device_sync()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hits = m.run(max_err, threads=1)
+            for name, ms in m.last_timing():
+                per_kernel.setdefault(name, []).append(ms)
+        device_sync()
+        res_elapsed = time.perf_counter() - t0
+        barrier()
+        res = {"ms_per_step": 1e3 * res_elapsed / max(args.steps, 1)}
+
+    # ---- the serial three-step path beside it (upload / kernels / download as separate, synchronised steps) --------------
+    serial = None
+    if args.mode == "both" and rank == 0:
+        pho = m.host_array(n_seg + 1, np.int64)
+        phi = m.host_array(max(hits, 1) + 1024, np.uint32)
+        poffs = m.host_array(offs.size, np.int64)
+        poffs[:] = offs
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter(); m.upload_segments(psegs, poffs); t1 = time.perf_counter()
+            m.run(max_err, threads=1); t2 = time.perf_counter()
+            m.download_into(pme, pho, phi); t3 = time.perf_counter()
+            cur = (t1 - t0, t2 - t1, t3 - t2)
+            best = cur if best is None or sum(cur) < sum(best) else best
+        serial = {"h2d_ms": round(1e3 * best[0], 3), "kernels_ms": round(1e3 * best[1], 3), "d2h_ms": round(1e3 * best[2], 3),
+                  "h2d_bytes": int(segs.size + offs.nbytes), "d2h_bytes": int(n_seg + 8 * (n_seg + 1) + 4 * hits),
+                  "what": "sct_upload_segments (bytes + int64 offsets, validated on the device) / sct_run / sct_download "
+                          "(min_e + int64 offsets + hits), page-locked buffers, each step synchronised: the three-step API"}
+
+    headline_elapsed = e2e_elapsed if e2e_elapsed is not None else res_elapsed
+    headline_elapsed, total_segments = shard.reduce_timing(dist, headline_elapsed, n_seg)
+    mine = {"rank": rank, "device": device, "numa_node": numa, "segments": n_seg,
+            "e2e_ms_per_step": round(e2e["ms_per_step"], 4) if e2e else None,
+            "resident_ms_per_step": round(res["ms_per_step"], 4) if res else None,
+            "e2e_spans_ms": e2e["spans_ms"] if e2e else None}
+    per_rank = shard.gather_objects(dist, mine)
+    res_all = None
+    if res is not None:
+        res_max, _ = shard.reduce_timing(dist, res["ms_per_step"], n_seg)
+        res_all = res_max
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+        ms_per_step = 1e3 * headline_elapsed / max(args.steps, 1)
         value = total_segments / (ms_per_step / 1e3)
         avg = {k: float(np.mean(v)) for k, v in per_kernel.items()}
         dominant = max(avg, key=avg.get) if avg else None
@@ -170,58 +285,78 @@ def main():
         bytes_per_seg = (float(offs[-1]) / n_seg + 4) + (1 + 4 + 4 * h)   # in L+4, out 1+4+4h
         alg_bytes = bytes_per_seg * n_seg + bc.size                   # + barcode set read once per launch
         roof = None
+        workload_desc = "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, %d-bp segments (SURVEY 8(d))" % (
+            wl, n_seg, n_bc, bl, max_err, args.seg_len)
         if dominant:
             achieved = alg_bytes / (avg[dominant] * 1e-3) / 1e9
+            cells = synth_seg_len(offs) * bl * n_bc * 2
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                     "kernel_ms": round(avg[dominant], 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                     "bytes_per_segment": round(bytes_per_seg, 2),
+                    "measured_in": "the resident loop: one launch of the kernel over the whole batch (k_filter<..., long>), HIP events on its stream",
                     # the binding resource is integer VALU issue, not HBM: all-pairs DP cells credited
-                    "dp_cells_per_segment": int(synth_seg_len(offs) * bl * n_bc * 2),
-                    "gcups_equivalent": round(n_seg * synth_seg_len(offs) * bl * n_bc * 2 / (avg[dominant] * 1e-3) / 1e9, 1)}
-        workload_desc = "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, %d-bp segments (SURVEY 8(d))" % (
-            args.workload, n_seg, n_bc, bl, max_err, args.seg_len)
-        q = pmc_quote(workload_desc) if (roof and not args.force_exhaustive and args.filter_mode == 0) else None
-        if q and q.get("kernel_ms_at_profile") and abs(avg[dominant] / q["kernel_ms_at_profile"] - 1.0) > 0.15:
-            q = None   # the committed counters belong to a different build of the kernel: do not quote them
-        if q:
-            # FETCH_SIZE is taken as read: this kernel streams 24 B per segment of packed input with 4- and 8-byte
-            # loads per lane (240 MB at 10 M segments) and the counter reports 248 MB, so the x2 rule of the guide
-            # (calibrated for 16-byte-per-lane streams) does not apply to it
-            rd = q.get("hbm_read_bytes_raw") or 0
-            roof["traffic"] = int(rd + (q.get("hbm_write_bytes") or 0))
-            roof["traffic_source"] = q["source"] + (
-                "; FETCH_SIZE + WRITE_SIZE as read.  Reads = 24 B/segment of packed input streamed once + the L2 misses of "
-                "the pattern-id resolution (one read per hit into a 4.7 MB id table beside 3.1 MB of slots, against a 4 MB L2; FETCH_SIZE counts "
-                "Infinity-Cache hits too); writes = the result arrays")
-            if q.get("l2_requests_per_launch"):
-                # the seed lookups are random 8-byte reads: one 128-byte L2 request each, whatever the bytes used
-                r = q["l2_requests_per_launch"] / (avg[dominant] * 1e-3)
-                roof["l2"] = {"requests_per_segment": round(q["l2_requests_per_launch"] / q["segments_per_launch"], 1),
-                              "achieved_requests_per_s": r, "peak_requests_per_s": L2_PEAK_REQ_S,
-                              "frac": round(r / L2_PEAK_REQ_S, 3), "hit_rate": q.get("l2_hit_rate"),
-                              "note": "peak = 16 channels x 8 XCDs x 1 request/clk at 2.4 GHz (34.5 TB/s / 128 B lines)"}
-            if q.get("valu_insts_per_launch"):
-                w = q["valu_insts_per_launch"] / (avg[dominant] * 1e-3)
-                roof["valu"] = {"insts_per_segment": round(q["valu_insts_per_launch"] / q["segments_per_launch"], 1),
-                                "achieved_wave_insts_per_s": w, "peak_wave_insts_per_s": VALU_PEAK_WINST_S,
-                                "frac": round(w / VALU_PEAK_WINST_S, 3),
-                                "note": "instruction count from the PMC pass, duration measured live; this is the binding resource"}
+                    "dp_cells_per_segment": int(cells),
+                    "gcups_equivalent": round(n_seg * cells / (avg[dominant] * 1e-3) / 1e9, 1)}
+            q = pmc_quote(workload_desc) if not args.force_exhaustive else None
+            if q and q.get("kernel_ms_at_profile") and abs(avg[dominant] / q["kernel_ms_at_profile"] - 1.0) > 0.15:
+                q = None   # the committed counters belong to a different build of the kernel: do not quote them
+            if q:
+                roof["traffic"] = int((q.get("hbm_read_bytes") or 0) + (q.get("hbm_write_bytes") or 0))
+                roof["traffic_quoted"] = {"source": q["source"], "hbm_read_bytes": q.get("hbm_read_bytes"),
+                                          "hbm_write_bytes": q.get("hbm_write_bytes"), "note": q.get("note")}
+                if q.get("l2_requests_per_launch"):
+                    # the seed lookups are random 8-byte reads: one 128-byte L2 request each, whatever the bytes used
+                    r = q["l2_requests_per_launch"] / (avg[dominant] * 1e-3)
+                    roof["l2_quoted"] = {"requests_per_segment": round(q["l2_requests_per_launch"] / q["segments_per_launch"], 1),
+                                         "achieved_requests_per_s": r, "peak_requests_per_s": L2_PEAK_REQ_S,
+                                         "frac": round(r / L2_PEAK_REQ_S, 3), "hit_rate": q.get("l2_hit_rate"),
+                                         "note": "peak = 16 channels x 8 XCDs x 1 request/clk at 2.4 GHz (34.5 TB/s / 128 B lines)"}
+                if q.get("valu_insts_per_launch"):
+                    w = q["valu_insts_per_launch"] / (avg[dominant] * 1e-3)
+                    roof["valu_quoted"] = {"insts_per_segment": round(q["valu_insts_per_launch"] / q["segments_per_launch"], 1),
+                                           "achieved_wave_insts_per_s": w, "peak_wave_insts_per_s": VALU_PEAK_WINST_S,
+                                           "frac": round(w / VALU_PEAK_WINST_S, 3),
+                                           "peak_if_all_full_rate_ops": VALU_PEAK_FULL_RATE_WINST_S,
+                                           "note": "instruction count from the PMC pass, duration measured live; peak = the measured issue "
+                                                   "rate of shifts / 3-operand / packed 16-bit integer ops (profiles/r02_valu_issue_rates.md), "
+                                                   "the class the automaton is made of; this is the binding resource"}
         out = {
-            "metric": baseline_metric() if args.workload == "cfg3" else "LR segments matched/sec (whole node)",
+            "metric": baseline_metric() if wl in ("cfg3", "cfg4") and not args.segments else "LR segments matched/sec (whole node)",
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload_desc, "segments_per_gpu": n_seg, "barcodes": n_bc, "max_err": max_err,
-                "path": "exhaustive" if args.force_exhaustive else "seed-filter", "paths": m.last_stats()},
+                       "path": "exhaustive" if args.force_exhaustive else "seed-filter", "paths": m.last_stats(),
+                       "seam": "sct_match_stream: %s index in, %s counts + hit lists out, page-locked host buffers" % (args.index_format, args.count_format)},
+            "value_is": ("device_e2e: SURVEY 8(d) figure (ii) — the batch starts and ends in page-locked host memory (PCIe both ways inside "
+                         "the timed region)") if e2e else "resident: SURVEY 8(d) figure (i) — inputs already in HBM",
+            "value_device_e2e": (total_segments / (ms_per_step / 1e3)) if e2e else None,
+            "value_resident": (total_segments / (res_all / 1e3)) if res_all else None,
+            "ms_per_step_resident": res_all,
             "hits_per_segment": round(h, 4),
+            "device_e2e": e2e,
+            "three_step_serial": serial,
             "kernels_ms": {k: round(v, 4) for k, v in avg.items()},
             "roofline": roof,
+            "per_rank": per_rank,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(bc, segs, offs, max_err, args.cpu_sample)
+        if world == 1 and not args.no_cli and args.mode == "both":
+            m.close()
+            m = None
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import cli_e2e
+                k = min(args.cli_rows, n_seg)
+                out["cli_e2e"] = cli_e2e.run(k, work=os.environ.get("SCT_BENCH_TMP", "/tmp/sct_bench_cli"), bc=bc,
+                                             segs=segs[:offs[k]], offs=offs[:k + 1], quiet=True)
+            except Exception as e:   # the figure is informative; the bench line must come out
+                out["cli_e2e"] = {"error": repr(e)}
         print(json.dumps(out))
-    m.close()
+    if m is not None:
+        m.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -42,6 +42,10 @@ enum {
 /* Number of visible HIP devices (0 if none / runtime unusable). */
 int sct_device_count(void);
 
+/* PCI bus id of `device` ("0000:c1:00.0") into buf (len >= 16), for callers that want to place their threads and their
+ * page-locked buffers on the NUMA node the device hangs off (/sys/bus/pci/devices/<id>/numa_node). */
+int sct_device_pci_bus_id(int device, char *buf, int len);
+
 /* Create / destroy a context bound to `device`. */
 int sct_create(int device, sct_ctx **out);
 void sct_destroy(sct_ctx *ctx);

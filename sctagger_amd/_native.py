@@ -20,7 +20,7 @@ EXPORTS = (
     "sct_device_count", "sct_create", "sct_destroy", "sct_last_error", "sct_prefix_len", "sct_set_barcodes",
     "sct_match", "sct_free_hits", "sct_upload_segments", "sct_run", "sct_download", "sct_sync", "sct_set_option",
     "sct_last_timing", "sct_last_stats", "sct_wl_set", "sct_wl_count", "sct_adapter_align", "sct_free_locs",
-    "sct_host_alloc", "sct_host_free", "sct_match_stream", "sct_last_timing_ex",
+    "sct_host_alloc", "sct_host_free", "sct_match_stream", "sct_last_timing_ex", "sct_device_pci_bus_id",
 )
 
 # index / count formats of sct_match_stream (include/sctagger_hip.h)
@@ -52,6 +52,7 @@ def load():
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.sct_device_count.restype = ctypes.c_int
     lib.sct_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    lib.sct_device_pci_bus_id.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
     lib.sct_destroy.argtypes = [vp]
     lib.sct_destroy.restype = None
     lib.sct_last_error.restype = ctypes.c_char_p
@@ -84,6 +85,14 @@ def load():
 
 def device_count():
     return int(load().sct_device_count())
+
+
+def device_pci_bus_id(device):
+    """-> e.g. '0000:c1:00.0', or None if the runtime does not tell."""
+    buf = ctypes.create_string_buffer(64)
+    if load().sct_device_pci_bus_id(int(device), buf, 64) != 0:
+        return None
+    return buf.value.decode().lower() or None
 
 
 def prefix_len(threads):

@@ -289,6 +289,16 @@ extern "C" int sct_device_count(void) {
     return n;
 }
 
+extern "C" int sct_device_pci_bus_id(int device, char *buf, int len) {
+    if (!buf || len < 16) return fail(SCT_E_ARG, "sct_device_pci_bus_id: buffer of at least 16 bytes needed");
+    buf[0] = 0;
+    if (hipDeviceGetPCIBusId(buf, len, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(SCT_E_ARG, "no PCI bus id for device %d", device);
+    }
+    return SCT_OK;
+}
+
 extern "C" int sct_create(int device, sct_ctx **out) {
     if (!out) return fail(SCT_E_ARG, "sct_create: out is NULL");
     *out = nullptr;

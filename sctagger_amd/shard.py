@@ -37,3 +37,39 @@ def reduce_timing(dist, elapsed_s, units):
     u = torch.tensor([float(units)], dtype=torch.float64)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t[0]), float(u[0])
+
+
+def gather_objects(dist, obj):
+    """-> list with every rank's `obj` (on every rank); [obj] for a single process."""
+    if dist is None:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def bind_to_device_numa(device):
+    """Best effort: restrict this process to the CPUs of the NUMA node the GPU hangs off, BEFORE it allocates page-locked
+    buffers (they are placed on the node of the allocating thread).  With eight ranks streaming 57 GB/s each out of host
+    memory, buffers on the far socket would cross the inter-socket link.  -> the node number or None."""
+    from . import _native
+    try:
+        bus = _native.device_pci_bus_id(device)
+        if not bus:
+            return None
+        with open("/sys/bus/pci/devices/%s/numa_node" % bus) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            return node
+    except Exception:
+        pass
+    return None

@@ -28,6 +28,7 @@ WORKER = textwrap.dedent("""
     shard.barrier(dist)
     t, units = shard.reduce_timing(dist, 1.0 + rank, hi - lo)
     assert t == 2.0 and units == 3001.0, (t, units)
+    assert shard.gather_objects(dist, {"rank": rank}) == [{"rank": 0}, {"rank": 1}]
     parts = [None, None] if rank == 0 else None
     dist.gather_object(mine, parts, dst=0)
     if rank == 0:
@@ -56,3 +57,27 @@ def test_two_rank_gloo_shards(tmp_path):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e.decode()[-2000:]
     assert b"DIST-OK" in outs[0][0]
+
+
+import json
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_device(tmp_path):
+    """bench.py's N = 2 path with the DEVICE in both ranks (they share GPU 0 on a one-GPU box): torchrun launch, gloo
+    barrier / reductions, one context per process, every rank its own seeded shard; the line carries both ranks' times."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--segments", "300000"], capture_output=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["value_resident"] > 0
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1] and all(r["e2e_ms_per_step"] > 0 for r in d["per_rank"])
+    assert d["config"]["paths"]["filter"] == 300000
