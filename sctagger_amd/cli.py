@@ -30,6 +30,7 @@ def parse_args(argv=None):
     p.add_argument("-o", "--outfile", type=str, default=None,
                    help="Path to output file; gzipped if it ends with 'gz'. Default: stdout")
     p.add_argument("--devices", type=int, nargs="+", default=None, help="GPU ids to shard the segments over. Default: 0")
+    p.add_argument("--no-stream", action="store_true", help="read the whole -lr file before matching, as the reference does, instead of streaming it in blocks")
     p.add_argument("--gzip-level", type=int, default=4, help="gzip level of the output (the reference writes level 9; the bytes after decompression are identical). Default: 4")
     l = subparsers.add_parser("extract_lr_bc")             # reference scTagger.py:25-49
     l.add_argument("-r", "--reads", nargs="+", type=str, required=True, help="Space separated paths to reads in FASTQ")

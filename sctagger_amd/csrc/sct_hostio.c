@@ -202,3 +202,91 @@ int64_t sctio_render_lr(const uint8_t *names, const int64_t *name_offs, const ui
     }
     return out ? (int64_t)(o - out) : size;
 }
+
+/* ---- block-wise helpers of the streaming match_trie command (sctagger_amd/fastio.py: stream_match_trie) ---- */
+
+/*
+ * The -lr reader (scTagger.py:611-614) on one BLOCK of the file: every complete line of buf[0..len) — and, if `final`, a last
+ * line without '\n' — up to max_rows lines and seg_cap segment bytes.  Column 0 -> name spans (relative to buf), column 3 ->
+ * segs / offs (int32, the reference's own index type, n + 1 entries) / lens8 (min(length, 255)).
+ * info[0] = lines parsed, info[1] = bytes of buf consumed (a multiple of whole lines), info[2] = longest segment,
+ * info[3] = 0-based number (within the block) of the first line with fewer than 4 fields, or -1,
+ * info[4] = 1 if the block holds a byte >= 128 or a '\r' (the caller then falls back to the reference's text-mode reader).
+ */
+void sctio_parse_block(const uint8_t *buf, int64_t len, int32_t final, int64_t max_rows, int64_t seg_cap, int64_t *name_start,
+                       int64_t *name_end, uint8_t *segs, int32_t *offs, uint8_t *lens8, int64_t *info) {
+    int64_t out = 0, p = 0, i = 0, longest = 0;
+    info[3] = -1;
+    info[4] = 0;
+    for (; i < max_rows && p < len; i++) {
+        const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', (size_t)(len - p));
+        if (!nl && !final) break;
+        const int64_t q = nl ? (int64_t)(nl - buf) : len;
+        int64_t tab[4] = {-1, -1, -1, -1};
+        int nt = 0;
+        uint8_t hi = 0;
+        for (int64_t k = p; k < q; k++) {
+            const uint8_t c = buf[k];
+            hi |= (uint8_t)(c & 0x80) | (uint8_t)(c == '\r' ? 0x80 : 0);
+            if (c == '\t' && nt < 4) tab[nt++] = k;
+        }
+        if (hi) info[4] = 1;
+        if (nt < 3) {
+            if (info[3] < 0) info[3] = i;
+            break;
+        }
+        const int64_t s = tab[2] + 1, e = nt >= 4 ? tab[3] : q, ls = e - s;
+        if (out + ls > seg_cap) break;
+        name_start[i] = p;
+        name_end[i] = tab[0];
+        offs[i] = (int32_t)out;
+        lens8[i] = (uint8_t)(ls < 255 ? ls : 255);
+        if (ls > longest) longest = ls;
+        memcpy(segs + out, buf + s, (size_t)ls);
+        out += ls;
+        p = q + 1;
+    }
+    offs[i] = (int32_t)out;
+    info[0] = i;
+    info[1] = p < len ? p : len;
+    info[2] = longest;
+}
+
+/*
+ * sctio_render for a block whose hits come as per-row COUNTS (uint8 if cnt_bytes == 1, else uint32) and int32 segment offsets:
+ * the hit list of row r starts where the counts of the rows before it end.  With out == NULL only the size is returned.
+ */
+int64_t sctio_render_block(const uint8_t *namebuf, const int64_t *name_start, const int64_t *name_end, const uint8_t *segs,
+                           const int32_t *offs, const uint8_t *min_e, const void *cnt, int32_t cnt_bytes, const uint32_t *hits,
+                           const uint8_t *pattern_text, int32_t bl, int64_t n, uint8_t *out) {
+    int64_t size = 0, pos = 0;
+    uint8_t *o = out;
+    for (int64_t r = 0; r < n; r++) {
+        const int64_t c = cnt_bytes == 1 ? (int64_t)((const uint8_t *)cnt)[r] : (int64_t)((const uint32_t *)cnt)[r];
+        if (min_e[r] == 0xFF) {
+            pos += c;
+            continue;
+        }
+        const int64_t ln = name_end[r] - name_start[r], ls = (int64_t)offs[r + 1] - offs[r];
+        if (!out) {
+            size += ln + ndigits(min_e[r]) + ndigits((uint64_t)c) + ls + c * bl + (c > 0 ? c - 1 : 0) + 5;
+            pos += c;
+            continue;
+        }
+        memcpy(o, namebuf + name_start[r], (size_t)ln); o += ln;
+        *o++ = '\t';
+        o = put_num(o, min_e[r]);
+        *o++ = '\t';
+        o = put_num(o, (uint64_t)c);
+        *o++ = '\t';
+        memcpy(o, segs + offs[r], (size_t)ls); o += ls;
+        *o++ = '\t';
+        for (int64_t k = 0; k < c; k++) {
+            if (k) *o++ = ',';
+            memcpy(o, pattern_text + (int64_t)hits[pos + k] * bl, (size_t)bl); o += bl;
+        }
+        pos += c;
+        *o++ = '\n';
+    }
+    return out ? (int64_t)(o - out) : size;
+}

@@ -14,6 +14,7 @@ returning flat arrays (what the writer consumes; a Python dict of 10^7 rows is o
 Diagnostics go to stderr (the reference prints them to stdout).
 """
 import gzip
+import os
 import sys
 import threading
 
@@ -194,20 +195,49 @@ def write_matches(outfile, min_e, hit_offs, hits, chunk=200_000):
         outfile.write("".join(lines))
 
 
+def _match_trie_streaming(args, devices, level):
+    from . import streamcli
+    _log("Reading long reads barcodes")
+    bc = _barcode_matrix(args.barcode_length)
+    table = fastio.pattern_text_table(barcodes, barcodes_rc)
+    want_plot = getattr(args, "plotfile", None) is not None
+    if args.outfile.endswith("gz"):
+        sink = fastio.GzipChunkWriter(args.outfile, level, threads=min(32, max(4, (os.cpu_count() or 8) // 2)))
+    else:
+        sink = open(args.outfile, "wb")
+    try:
+        rows, min_es = streamcli.run_pipeline(args.long_read_segments, bc, args.barcode_length, args.max_error, args.threads, table, sink,
+                                              devices=tuple(devices), want_min_e=want_plot)
+    finally:
+        sink.close()
+    _log("There are {:,} LRs".format(rows))
+    if want_plot:
+        from . import plots
+        plots.plot_match_trie(np.concatenate(min_es) if min_es else np.empty(0, np.uint8), args.plotfile, _native.NO_HIT)
+
+
 def match_trie(args):
     """reference :758-790. args: long_read_segments, short_read_barcodes, max_error, barcode_length,
     threads, outfile; mem is accepted and unused as in the reference; plotfile draws the distance histogram."""
     read_sr_barcodes(args.short_read_barcodes)
     barcode_lens = {len(b) for b in barcodes}
     assert barcode_lens == {args.barcode_length}, barcode_lens
-    read_long_reads(args.long_read_segments)
     devices = getattr(args, "devices", None) or (0,)
+    level = getattr(args, "gzip_level", 4)
+    if args.outfile and not getattr(args, "no_stream", False):
+        # the pipelined command (streamcli.py): read || parse + match + render || compress, block by block
+        from . import streamcli
+        try:
+            _match_trie_streaming(args, devices, level)
+            return
+        except streamcli.NeedPlainReader:
+            pass    # bytes the block parser cannot represent exactly: the reference's own procedure on the whole file, below
+    read_long_reads(args.long_read_segments)
     min_e, hit_offs, hits = run_get_matches_prefix_arrays(
         max_error=args.max_error, threads=args.threads, devices=devices, barcode_length=args.barcode_length)
     if getattr(args, "plotfile", None) is not None:
         from . import plots
         plots.plot_match_trie(min_e, args.plotfile, _native.NO_HIT)
-    level = getattr(args, "gzip_level", 4)
     if isinstance(lr_names, fastio.LazyNames):
         table = fastio.pattern_text_table(barcodes, barcodes_rc)
         sink = args.outfile if args.outfile else sys.stdout.buffer

@@ -1,0 +1,256 @@
+"""The `match_trie` command as a pipeline (reference scTagger.py:602-628 reader, :758-790 driver).
+
+The reference reads the whole -lr file, matches, then writes.  At 10^7 rows the matching takes 6 ms on an MI355X and
+everything around it seconds, most of it in one place: inflating the input (a gzip stream decodes serially, ~0.4 GB/s).
+So the command is organised around that one serial stage and hides the rest behind it:
+
+    reader thread     gunzip / read the file in blocks of ~32 MB that end at a line end
+    worker thread(s)  one per device: parse the block's columns 0 and 3 straight into page-locked buffers (C helper),
+                      sct_match_stream on them in place (uint8 lengths in, uint8 counts + hit lists out),
+                      render the block's output rows (C helper)
+    main thread       hands the rendered rows, in block order, to a pool that gzips them as consecutive gzip members
+
+Blocks are dealt round-robin to the devices (`--devices`), so several GPUs need no sharding step.  The bytes written are
+exactly the reference's (after decompression).  Input the C parser cannot represent exactly — bytes >= 128, '\\r' —
+raises NeedPlainReader and the caller falls back to the reference's own text-mode procedure on the whole file.
+"""
+import ctypes
+import os
+import queue
+import sys
+import threading
+import zlib
+
+import numpy as np
+
+from . import _native, fastio
+
+BLOCK_BYTES = int(os.environ.get("SCT_STREAM_BLOCK_BYTES", 32 << 20))   # the environment variable is for tests (many small blocks)
+ROWS_PER_PASS = 1 << 21
+PIECE_BYTES = 4 << 20
+
+
+class NeedPlainReader(Exception):
+    """The input needs Python's text-mode semantics (non-ASCII bytes, carriage returns)."""
+
+
+def _iolib():
+    lib = fastio._iolib()
+    if not getattr(lib, "_stream_ready", False):
+        vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+        lib.sctio_parse_block.argtypes = [vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp]
+        lib.sctio_parse_block.restype = None
+        lib.sctio_render_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i64, vp]
+        lib.sctio_render_block.restype = i64
+        lib._stream_ready = True
+    return lib
+
+
+def iter_blocks(path, block_bytes=BLOCK_BYTES):
+    """Yield (bytes, final) pieces of the file's (decompressed) contents, each ending at a line end except possibly the
+    last.  gzip iff the name ends with '.gz' (the reference's rule, :605); multi-member gzip files are read through."""
+    gz = path.endswith(".gz")
+    pend, size = [], 0
+    with open(path, "rb") as f:
+        d = zlib.decompressobj(31) if gz else None
+        while True:
+            raw = f.read(1 << 20 if gz else block_bytes)
+            if not raw:
+                break
+            while raw:
+                if gz:
+                    out = d.decompress(raw)
+                    raw = b""
+                    if d.eof:                      # end of a member: whatever follows is the next member
+                        raw = d.unused_data
+                        d = zlib.decompressobj(31)
+                else:
+                    out, raw = raw, b""
+                if out:
+                    pend.append(out)
+                    size += len(out)
+                if size >= block_bytes:
+                    buf = b"".join(pend)
+                    k = buf.rfind(b"\n")
+                    if k < 0:
+                        pend, size = [buf], len(buf)
+                    else:
+                        pend = [buf[k + 1:]] if k + 1 < len(buf) else []
+                        size = len(buf) - (k + 1)
+                        yield buf[:k + 1], False
+    buf = b"".join(pend)
+    if buf:
+        yield buf, True
+
+
+class _Worker(threading.Thread):
+    """One device: parse -> match -> render, block after block."""
+
+    def __init__(self, device, bc, bl, max_err, threads, table, want_min_e):
+        super().__init__(daemon=True)
+        self.device, self.bc, self.bl, self.max_err, self.threads = device, bc, bl, max_err, threads
+        self.table, self.want_min_e = table, want_min_e
+        self.inq = queue.Queue(maxsize=2)
+        self.outq = None          # set by run_pipeline
+        self.error = None
+        self.rows = 0
+        self.cap_rows = self.cap_bytes = 0
+
+    def _ensure(self, m, nbytes):
+        if nbytes <= self.cap_bytes:
+            return
+        m.sync()
+        m.release_host_arrays()
+        self.cap_bytes = max(nbytes, BLOCK_BYTES + (1 << 20))
+        self.cap_rows = ROWS_PER_PASS
+        self.segs = m.host_array(self.cap_bytes, np.uint8)
+        self.offs = m.host_array(self.cap_rows + 1, np.int32)
+        self.lens = m.host_array(self.cap_rows, np.uint8)
+        self.min_e = m.host_array(self.cap_rows, np.uint8)
+        self.cnt = m.host_array(self.cap_rows, np.uint32)     # viewed as uint8 for the one-byte counts
+        self.ns = np.empty(self.cap_rows, dtype=np.int64)
+        self.ne = np.empty(self.cap_rows, dtype=np.int64)
+        self.info = np.zeros(8, dtype=np.int64)
+
+    def _block(self, m, lib, buf, final):
+        """-> (list of rendered byte strings, list of min_e copies, rows)"""
+        self._ensure(m, len(buf))
+        base = ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p).value
+        at, n_rows, out, keep = 0, 0, [], []
+        cnt8 = self.cnt.view(np.uint8)
+        while at < len(buf):
+            lib.sctio_parse_block(base + at, len(buf) - at, 1 if final else 0, self.cap_rows, self.cap_bytes, self.ns.ctypes.data,
+                                  self.ne.ctypes.data, self.segs.ctypes.data, self.offs.ctypes.data, self.lens.ctypes.data,
+                                  self.info.ctypes.data)
+            n, used, longest, bad, odd = (int(x) for x in self.info[:5])
+            if odd:
+                raise NeedPlainReader()
+            if bad >= 0:
+                raise IndexError("list index out of range")      # fewer than 4 columns: `l[3]` in the reference (:612-614)
+            if n == 0:
+                break
+            nbytes = int(self.offs[n])
+            if longest <= 255:
+                index, ifmt = self.lens[:n], _native.IDX_LEN8
+            else:
+                index, ifmt = self.offs[:n + 1], _native.IDX_OFFS32
+            try:
+                me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
+                                               count_format=_native.CNT_U8, min_e=self.min_e, counts=cnt8, copy_hits=False)
+                cbytes = 1
+            except _native.SctError as e:
+                if e.code != _native.E_RANGE:
+                    raise
+                me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
+                                               count_format=_native.CNT_U32, min_e=self.min_e, counts=self.cnt, copy_hits=False)
+                cbytes = 4
+            hp = hits.ctypes.data if hits.size else None
+            args = [base + at, self.ns.ctypes.data, self.ne.ctypes.data, self.segs.ctypes.data, self.offs.ctypes.data, me.ctypes.data,
+                    cnt.ctypes.data, cbytes, hp, self.table.ctypes.data, self.table.shape[1] if self.table.ndim == 2 else 0, n]
+            size = lib.sctio_render_block(*args, None)
+            o = np.empty(size, dtype=np.uint8)
+            got = lib.sctio_render_block(*args, o.ctypes.data)
+            assert got == size
+            out.append(o)
+            if self.want_min_e:
+                keep.append(me.copy())
+            n_rows += n
+            at += used
+        return out, keep, n_rows
+
+    def run(self):
+        try:
+            lib = _iolib()
+            with _native.Matcher(self.device) as m:
+                m.set_barcodes(self.bc, self.bl)
+                while True:
+                    item = self.inq.get()
+                    if item is None:
+                        break
+                    idx, buf, final = item
+                    out, keep, n = self._block(m, lib, buf, final)
+                    self.rows += n
+                    self.outq.put((idx, out, keep))
+                m.sync()
+                m.release_host_arrays()
+        except BaseException as e:          # handed to the main thread
+            self.error = e
+            self.outq.put((-1, None, None))
+
+
+def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), want_min_e=False, block_bytes=BLOCK_BYTES):
+    """Stream `lr_path` through the devices into `sink` (an object with write(bytes-like)); -> (rows read, list of min_e
+    arrays in row order if want_min_e).  Raises NeedPlainReader / IndexError like the whole-file readers."""
+    workers = [_Worker(d, bc, bl, max_err, threads, table, want_min_e) for d in devices]
+    outq = queue.Queue()
+    for w in workers:
+        w.outq = outq
+        w.start()
+    state = {"blocks": 0, "error": None}
+    stop = threading.Event()
+
+    def feed():
+        try:
+            for i, (buf, final) in enumerate(iter_blocks(lr_path, block_bytes)):
+                if stop.is_set():
+                    break
+                workers[i % len(workers)].inq.put((i, buf, final))
+                state["blocks"] = i + 1
+        except BaseException as e:
+            state["error"] = e
+        finally:
+            outq.put((-2, None, None))      # the reader is done
+
+    reader = threading.Thread(target=feed, daemon=True)
+    reader.start()
+    done, nxt, fed = {}, 0, False
+    min_es = []
+    failure = None
+    while True:
+        if fed and nxt >= state["blocks"]:
+            break
+        idx, out, keep = outq.get()
+        if idx == -2:
+            fed = True
+            if state["error"] is not None:
+                failure = state["error"]
+                break
+            continue
+        if idx == -1:
+            failure = next(w.error for w in workers if w.error is not None)
+            break
+        done[idx] = (out, keep)
+        while nxt in done:
+            out, keep = done.pop(nxt)
+            for o in out:
+                mv = memoryview(o)
+                for a in range(0, len(mv), PIECE_BYTES):
+                    sink.write(mv[a:a + PIECE_BYTES])
+            min_es.extend(keep)
+            nxt += 1
+    # wind down: on failure the reader may be blocked on a full queue of a worker that is gone — empty the queues until it
+    # has left, then tell the workers that are still there to stop
+    stop.set()
+    while reader.is_alive():
+        if failure is not None:
+            for w in workers:
+                try:
+                    w.inq.get_nowait()
+                except queue.Empty:
+                    pass
+        reader.join(timeout=0.02)
+    for w in workers:
+        while w.is_alive():
+            try:
+                w.inq.put(None, timeout=0.02)
+                break
+            except queue.Full:
+                try:
+                    w.inq.get_nowait()
+                except queue.Empty:
+                    pass
+    for w in workers:
+        w.join()
+    if failure is not None:
+        raise failure
+    return sum(w.rows for w in workers), min_es

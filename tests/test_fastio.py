@@ -112,3 +112,75 @@ def test_empty_result_gzip_is_valid(tmp_path):
     fastio.write_matches_fast(p, names, mt.lr_segs, mt.lr_segs_idxs, np.empty(0, np.uint8), np.zeros(1, np.int64),
                               np.empty(0, np.uint32), fastio.pattern_text_table(mt.barcodes, mt.barcodes_rc))
     assert gzip.open(p, "rb").read() == b""
+
+
+def test_iter_blocks_cuts_at_line_ends(tmp_path):
+    """The streaming command's block reader: plain and gzip (also multi-member), blocks end at line ends, nothing is lost."""
+    from sctagger_amd import streamcli
+    rng = np.random.default_rng(3)
+    lines = [b"r%d\t1\t2\t" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, 60)))) for i in range(5000)]
+    data = b"\n".join(lines)                                   # no final newline
+    plain = tmp_path / "x.tsv"
+    plain.write_bytes(data)
+    gz1 = tmp_path / "x.tsv.gz"
+    with gzip.open(gz1, "wb") as f:
+        f.write(data)
+    gzm = tmp_path / "m.tsv.gz"                                # three members, cut in the middle of lines
+    with open(gzm, "wb") as f:
+        for a, b in ((0, 70_001), (70_001, 70_002), (70_002, len(data))):
+            f.write(gzip.compress(data[a:b]))
+    for path in (plain, gz1, gzm):
+        for bb in (1 << 10, 50_000, 1 << 30):
+            blocks = list(streamcli.iter_blocks(str(path), bb))
+            assert b"".join(b for b, _ in blocks) == data
+            assert all(b.endswith(b"\n") for b, _ in blocks[:-1]) and [f for _, f in blocks][:-1] == [False] * (len(blocks) - 1)
+    empty = tmp_path / "e.tsv.gz"
+    with gzip.open(empty, "wb"):
+        pass
+    assert list(streamcli.iter_blocks(str(empty))) == []
+
+
+@pytest.mark.parametrize("name,e,t", [("g3", 2, 1), ("g7", 2, 16), ("g1", 1, 4)])
+def test_block_parser_and_renderer_reproduce_reference_bytes(name, e, t):
+    """sctio_parse_block + sctio_render_block (the streaming command's C helpers) on a golden file cut into small passes,
+    with one-byte and four-byte counts, against the reference's output bytes."""
+    import ctypes
+    from sctagger_amd import streamcli
+    lib = streamcli._iolib()
+    case = [c for c in util.golden_cases() if c[0] == name and c[3] == e and c[4] == t][0]
+    _, lr, sr, _, _, bl, exp = case
+    mt.read_sr_barcodes(sr)
+    table = fastio.pattern_text_table(mt.barcodes, mt.barcodes_rc)
+    with open(lr, "rb") as f:
+        buf = f.read()
+    with open(exp, "rb") as f:
+        want = f.read()
+    for cap_rows, cbytes in ((7, 1), (1000, 4)):
+        ns, ne = np.empty(cap_rows, np.int64), np.empty(cap_rows, np.int64)
+        segs, offs, lens = np.empty(len(buf) + 1, np.uint8), np.empty(cap_rows + 1, np.int32), np.empty(cap_rows, np.uint8)
+        info = np.zeros(8, np.int64)
+        base = ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p).value
+        at, out = 0, []
+        while at < len(buf):
+            lib.sctio_parse_block(base + at, len(buf) - at, 1, cap_rows, segs.size, ns.ctypes.data, ne.ctypes.data, segs.ctypes.data,
+                                  offs.ctypes.data, lens.ctypes.data, info.ctypes.data)
+            n, used = int(info[0]), int(info[1])
+            assert n > 0 and info[3] == -1 and info[4] == 0
+            assert np.array_equal(np.minimum(np.diff(offs[:n + 1]), 255), lens[:n])
+            o64 = offs[:n + 1].astype(np.int64)
+            me, ho, hits = trie_oracle.match(util.bc_matrix(mt.barcodes, bl), segs[:o64[-1]].copy(), o64, e, threads=t)
+            cnt = np.diff(ho).astype(np.uint8 if cbytes == 1 else np.uint32)
+            hits = np.ascontiguousarray(hits, dtype=np.uint32)
+            args = [base + at, ns.ctypes.data, ne.ctypes.data, segs.ctypes.data, offs.ctypes.data, me.ctypes.data, cnt.ctypes.data, cbytes,
+                    hits.ctypes.data if hits.size else None, table.ctypes.data, bl, n]
+            size = lib.sctio_render_block(*args, None)
+            o = np.empty(size, np.uint8)
+            assert lib.sctio_render_block(*args, o.ctypes.data) == size
+            out.append(o.tobytes())
+            at += used
+        assert b"".join(out) == want
+    # a line with fewer than four fields, a non-ASCII byte and a carriage return are reported, not parsed
+    for bad, slot in ((b"a\t1\t2\tAC\nb\t1\n", 3), (b"a\t1\t2\tA\xc3\xa9\n", 4), (b"a\t1\t2\tAC\r\n", 4)):
+        lib.sctio_parse_block(ctypes.cast(ctypes.c_char_p(bad), ctypes.c_void_p).value, len(bad), 1, 7, 64, ns.ctypes.data, ne.ctypes.data,
+                              segs.ctypes.data, offs.ctypes.data, lens.ctypes.data, info.ctypes.data)
+        assert (info[3] == 1) if slot == 3 else (info[4] == 1)

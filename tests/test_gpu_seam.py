@@ -236,3 +236,40 @@ def test_cfg5_full_size(m):
     k = 1000
     want = trie_oracle.match(bc, segs[:offs[k]], offs[:k + 1], 1, threads=16, workers=16)
     assert np.array_equal(a[0][:k], want[0]) and np.array_equal(a[2][:a[1][k]], want[2])
+
+
+def test_streaming_command_small_blocks_devices_and_fallback(tmp_path):
+    """The pipelined command with blocks of 4 KB (hundreds of blocks, reordered across three worker threads), against the
+    reference's bytes; --no-stream gives the same file; input with carriage returns falls back to the text-mode reader."""
+    g = util.GOLDEN
+    env = dict(os.environ, SCT_STREAM_BLOCK_BYTES="4096")
+    for name, e, t, exp in (("g12", 2, 16, "g12.e2.t16.expected.tsv"), ("g7", 2, 16, "g7.e2.t16.expected.tsv"), ("g5", 2, 8, "g5.e2.t8.expected.tsv")):
+        sr = os.path.join(g, name + ".sr.tsv")
+        if not os.path.exists(sr):
+            sr += ".gz"
+        with open(os.path.join(g, exp), "rb") as f:
+            want = f.read()
+        lrgz = tmp_path / (name + ".lr.tsv.gz")
+        with open(os.path.join(g, name + ".lr.tsv"), "rb") as f, gzip.open(lrgz, "wb") as z:
+            z.write(f.read())
+        for extra in (["--devices", "0", "0", "0"], [], ["--no-stream"]):
+            o = tmp_path / (name + ".out.tsv.gz")
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", str(lrgz), "-sr", sr, "-mr", str(e),
+                                   "-t", str(t), "-o", str(o)] + extra, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+            assert gzip.open(o, "rb").read() == want, (name, extra)
+    # CRLF input: Python's text mode turns \r\n into \n; the block parser declines and the whole-file reader takes over
+    with open(os.path.join(g, "g1.lr.tsv"), "rb") as f:
+        crlf = f.read().replace(b"\n", b"\r\n")
+    p = tmp_path / "crlf.tsv"
+    p.write_bytes(crlf)
+    o = tmp_path / "crlf.out.tsv"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", str(p), "-sr", os.path.join(g, "g1.sr.tsv"),
+                           "-mr", "1", "-t", "4", "-o", str(o)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+    with open(os.path.join(g, "g1.e1.t4.expected.tsv"), "rb") as f:
+        assert o.read_bytes() == f.read()
+    # a line with fewer than four columns ends the command with the reference's IndexError
+    bad = tmp_path / "bad.tsv"
+    bad.write_bytes(b"r0\t1\t2\tACGTACGTACGTACGTAC\nr1\t1\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", str(bad), "-sr", os.path.join(g, "g1.sr.tsv"),
+                        "-o", str(tmp_path / "bad.out.tsv")], capture_output=True, env=env)
+    assert r.returncode != 0 and b"IndexError" in r.stderr
