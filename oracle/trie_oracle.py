@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+LIB_PATH = os.environ.get("SCT_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # the variable selects the sanitizer build (tests/test_sanitizers.py)
 _lib = None
 
 

@@ -24,7 +24,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 _CHUNK_BYTES = 64 << 20
-IO_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsctagger_io.so")
+IO_LIB_PATH = os.environ.get("SCT_IO_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsctagger_io.so")
 _io = None
 
 

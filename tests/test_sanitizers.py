@@ -1,0 +1,45 @@
+"""Host-side sanitizers: the plain-C / C++ code that runs on the CPU — the TSV parser / renderer of the command
+line (csrc/sct_hostio.c), the bit-parallel header and the seed-table builder shared with the kernels (sct_core.h,
+sct_tables.h, through tests/host_core_check.cpp) and the oracle — built with AddressSanitizer + UndefinedBehaviorSanitizer
+and driven by the existing suites.  CPU only: the device library cannot be sanitised on this pool."""
+import os
+import subprocess
+import sys
+
+from tests import util
+
+ROOT = os.path.dirname(util.HERE)
+
+
+def _asan_runtime():
+    p = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+def test_c_helpers_and_oracle_under_asan_ubsan():
+    """tests/test_fastio.py, test_oracle.py and the CPU part of test_fuzz.py once more, in a python that has libasan preloaded and loads the
+    sanitizer builds of libsctagger_io / liboracle: any heap overrun, use after free or undefined operation aborts it."""
+    rt = _asan_runtime()
+    assert rt, "gcc's libasan.so not found"
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "sctagger_amd", "csrc"), "asan"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"])
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               SCT_IO_LIB=os.path.join(ROOT, "sctagger_amd", "csrc", "libsctagger_io_asan.so"),
+               SCT_ORACLE_LIB=os.path.join(ROOT, "oracle", "liboracle_asan.so"))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_fastio.py"),
+                        os.path.join(ROOT, "tests", "test_oracle.py"), os.path.join(ROOT, "tests", "test_fuzz.py"), "-m", "not gpu"],
+                       env=env, capture_output=True, cwd=ROOT, timeout=1200)
+    out = r.stdout.decode() + r.stderr.decode()
+    assert r.returncode == 0 and "AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]
+    assert " passed" in out
+
+
+def test_core_header_and_table_builder_under_asan_ubsan():
+    build = os.path.join(util.HERE, "_build")
+    os.makedirs(build, exist_ok=True)
+    exe = os.path.join(build, "host_core_check_asan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-o", exe, os.path.join(util.HERE, "host_core_check.cpp")])
+    r = subprocess.run([exe], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"), timeout=1200)
+    out = r.stdout.decode() + r.stderr.decode()
+    assert r.returncode == 0 and out.startswith("OK") and "runtime error" not in out, out[-4000:]
