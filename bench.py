@@ -50,6 +50,7 @@ VALU_PEAK_FULL_RATE_WINST_S = 1.1e12
 L2_PEAK_REQ_S = 8 * 16 * 2.4e9   # L2: 16 channels per XCD, one 128-byte request per channel and clock (MI355X_MICROARCH.md: 34.5 TB/s)
 IDX = {"len8": _native.IDX_LEN8, "len16": _native.IDX_LEN16, "offs32": _native.IDX_OFFS32, "offs64": _native.IDX_OFFS64}
 CNT = {"u8": _native.CNT_U8, "u32": _native.CNT_U32, "offs64": _native.CNT_OFFS64}
+HITS = {"u16": _native.HITS_U16, "u32": _native.HITS_U32}
 
 
 def baseline_metric():
@@ -126,6 +127,7 @@ def main():
     ap.add_argument("--seg-len", type=int, default=22, help="segment length of the synthetic rows (22 = the reference's nominal length)")
     ap.add_argument("--index-format", default="len8", choices=sorted(IDX), help="row index handed to the seam (len8 = one byte per row)")
     ap.add_argument("--count-format", default="u8", choices=sorted(CNT), help="hit counts taken from the seam (u8 = one byte per row)")
+    ap.add_argument("--hits-format", default="u16", choices=sorted(HITS), help="hit lists taken from the seam (u16 while the barcode set has at most 32768 entries)")
     ap.add_argument("--chunk-rows", type=int, default=0, help="sct_match_stream's chunk_rows option (0 = library default)")
     ap.add_argument("--zero-copy", type=int, default=1, help="0 = upload the page-locked buffers instead of reading them in place")
     ap.add_argument("--mode", default="both", choices=["both", "e2e", "resident"], help="which loops to run (profiling passes use one)")
@@ -181,6 +183,8 @@ def main():
 
     # ---- figure (ii): the seam, page-locked host memory -> device -> page-locked host memory -----------------------
     ifmt, cfmt = IDX[args.index_format], CNT[args.count_format]
+    hits_format = args.hits_format if 2 * n_bc <= 65536 else "u32"
+    hfmt = HITS[hits_format]
     lens = np.diff(offs)
     index = {"len8": lambda: lens.astype(np.uint8), "len16": lambda: lens.astype(np.uint16),
              "offs32": lambda: offs.astype(np.int32), "offs64": lambda: offs}[args.index_format]()
@@ -195,7 +199,8 @@ def main():
     hits = 0
     if args.mode in ("both", "e2e"):
         def step():
-            return m.match_stream(psegs, pidx, max_err, 1, index_format=ifmt, count_format=cfmt, min_e=pme, counts=pcnt, copy_hits=False)
+            return m.match_stream(psegs, pidx, max_err, 1, index_format=ifmt, count_format=cfmt, min_e=pme, counts=pcnt, copy_hits=False,
+                                  hits_format=hfmt)
         for _ in range(args.warmup):
             step()
         device_sync()
@@ -211,16 +216,17 @@ def main():
         barrier()
         hits = int(r[2].size)
         h2d_bytes = int(segs.size + index.nbytes)
-        d2h_bytes = int(n_seg + pcnt[:n_seg + (1 if cfmt == _native.CNT_OFFS64 else 0)].nbytes + 4 * hits)
+        d2h_bytes = int(n_seg + pcnt[:n_seg + (1 if cfmt == _native.CNT_OFFS64 else 0)].nbytes + r[2].itemsize * hits)
         avg = {k: float(np.mean([x[0] for x in v])) for k, v in spans.items()}
         launches = {k: int(v[-1][1]) for k, v in spans.items()}
         e2e = {"ms_per_step": 1e3 * e2e_elapsed / max(args.steps, 1), "index_format": args.index_format, "count_format": args.count_format,
+               "hits_format": hits_format,
                "host_to_device_bytes": h2d_bytes, "device_to_host_bytes": d2h_bytes,
                "zero_copy": bool(args.zero_copy), "chunks": launches.get("k_filter", 0),
                "spans_ms": {k: round(v, 4) for k, v in avg.items()},
                "spans_note": "device time per step by kernel name (HIP events on the kernel's stream, summed over the step's launches). "
                              "With zero_copy the input crosses PCIe INSIDE k_index (row lengths) and k_filter (segment bytes), min_e is "
-                             "written to host memory by k_filter, the counts by k_offsets and the hit lists by k_fill: there are no "
+                             "written to host memory by k_filter together with the one-byte counts and the hit lists by k_fill / k_narrow_hits: there are no "
                              "separate copies to time; host_queue / host_wait are the calling thread's own time"}
         if args.zero_copy and "k_filter" in avg:
             e2e["k_filter_input_GBps"] = round(segs.size / (avg["k_filter"] * 1e-3) / 1e9, 1)
@@ -328,7 +334,8 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload_desc, "segments_per_gpu": n_seg, "barcodes": n_bc, "max_err": max_err,
                        "path": "exhaustive" if args.force_exhaustive else "seed-filter", "paths": m.last_stats(),
-                       "seam": "sct_match_stream: %s index in, %s counts + hit lists out, page-locked host buffers" % (args.index_format, args.count_format)},
+                       "seam": "sct_match_stream: %s index in, %s counts + %s hit lists out, page-locked host buffers" % (
+                           args.index_format, args.count_format, hits_format)},
             "value_is": ("device_e2e: SURVEY 8(d) figure (ii) — the batch starts and ends in page-locked host memory (PCIe both ways inside "
                          "the timed region)") if e2e else "resident: SURVEY 8(d) figure (i) — inputs already in HBM",
             "value_device_e2e": (total_segments / (ms_per_step / 1e3)) if e2e else None,

@@ -107,16 +107,18 @@ void sct_free_hits(sct_ctx *ctx, uint32_t *hits);
  *       SCT_CNT_OFFS64  int64 hit_offs[n+1]  CSR offsets into *hits, exactly sct_match's hit_offs
  *       SCT_CNT_U32     uint32 cnt[n]        hits per row (offsets = their prefix sum, left to the caller)
  *       SCT_CNT_U8      uint8 cnt[n]         the same in one byte; fails with SCT_E_RANGE if a row has more than 255 hits
- *   *hits             all hit lists back to back in row order, (bid << 1 | strand) ascending inside a row.  The array
- *                     is page-locked memory OWNED BY THE CONTEXT: valid until the next sct_match_stream / sct_match /
- *                     sct_destroy on it, not to be freed by the caller.
+ *   *hits             all hit lists back to back in row order, (bid << 1 | strand) ascending inside a row, as
+ *                     uint32 (hits_format SCT_HITS_U32) or uint16 (SCT_HITS_U16; fails with SCT_E_RANGE when the barcode
+ *                     set has more than 32 768 entries).  The array is page-locked memory OWNED BY THE CONTEXT: valid
+ *                     until the next sct_match_stream / sct_match / sct_destroy on it, not to be freed by the caller.
  *   *n_hits           total number of hits
  */
 enum { SCT_IDX_OFFS64 = 0, SCT_IDX_OFFS32 = 1, SCT_IDX_LEN8 = 2, SCT_IDX_LEN16 = 3 };
 enum { SCT_CNT_OFFS64 = 0, SCT_CNT_U32 = 1, SCT_CNT_U8 = 2 };
+enum { SCT_HITS_U32 = 0, SCT_HITS_U16 = 1 };
 int sct_match_stream(sct_ctx *ctx, const char *segs, int64_t seg_bytes, const void *index, int32_t index_format, int64_t n,
-                     int32_t max_err, int32_t threads, uint8_t *min_e, void *counts, int32_t count_format,
-                     const uint32_t **hits, int64_t *n_hits);
+                     int32_t max_err, int32_t threads, uint8_t *min_e, void *counts, int32_t count_format, int32_t hits_format,
+                     const void **hits, int64_t *n_hits);
 
 /*
  * The same path in three steps, for pipelining and for measuring with the inputs resident in HBM:

@@ -26,6 +26,7 @@ EXPORTS = (
 # index / count formats of sct_match_stream (include/sctagger_hip.h)
 IDX_OFFS64, IDX_OFFS32, IDX_LEN8, IDX_LEN16 = 0, 1, 2, 3
 CNT_OFFS64, CNT_U32, CNT_U8 = 0, 1, 2
+HITS_U32, HITS_U16 = 0, 1
 _IDX_DTYPE = {IDX_OFFS64: np.int64, IDX_OFFS32: np.int32, IDX_LEN8: np.uint8, IDX_LEN16: np.uint16}
 _CNT_DTYPE = {CNT_OFFS64: np.int64, CNT_U32: np.uint32, CNT_U8: np.uint8}
 E_RANGE = -6
@@ -68,7 +69,7 @@ def load():
     lib.sct_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     lib.sct_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     lib.sct_last_timing_ex.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32), ctypes.c_int]
-    lib.sct_match_stream.argtypes = [vp, vp, i64, vp, i32, i64, i32, i32, vp, vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    lib.sct_match_stream.argtypes = [vp, vp, i64, vp, i32, i64, i32, i32, vp, vp, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     lib.sct_last_stats.argtypes = [vp, ctypes.POINTER(i64), ctypes.c_int]
     lib.sct_wl_set.argtypes = [vp, vp, vp, i32]
     lib.sct_wl_count.argtypes = [vp, vp, vp, vp, i64, vp, vp]
@@ -212,12 +213,13 @@ class Matcher:
         return min_e, hit_offs, hits
 
     def match_stream(self, segs, index, max_err, threads=1, index_format=IDX_OFFS64, count_format=CNT_U8, min_e=None, counts=None,
-                     copy_hits=True):
+                     copy_hits=True, hits_format=HITS_U32):
         """sct_match_stream: the pipelined seam with compact transfer formats.
 
         segs: uint8 bytes of all rows; index: int64/int32 offsets[n+1] or uint8/uint16 lengths[n] (index_format);
         -> (min_e uint8[n], counts, hits uint32[total]); counts is int64 hit_offs[n+1], uint32 cnt[n] or uint8 cnt[n]
-        (count_format).  min_e / counts may be given (e.g. page-locked arrays from host_array).  With copy_hits=False
+        (count_format); hits_format=HITS_U16 returns the hits as uint16 (barcode sets of at most 32 768 entries).
+        min_e / counts may be given (e.g. page-locked arrays from host_array).  With copy_hits=False
         `hits` is a view of the library's page-locked result buffer, valid until the next match on this Matcher."""
         if isinstance(segs, (bytes, bytearray, memoryview)):
             segs = np.frombuffer(segs, dtype=np.uint8)
@@ -235,14 +237,15 @@ class Matcher:
         hp = ctypes.c_void_p()
         nh = ctypes.c_int64()
         self._check(self._lib.sct_match_stream(self._ctx, _ptr(segs), segs.size, _ptr(index), int(index_format), n, int(max_err),
-                                               int(threads), _ptr(min_e), _ptr(counts), int(count_format), ctypes.byref(hp),
-                                               ctypes.byref(nh)))
+                                               int(threads), _ptr(min_e), _ptr(counts), int(count_format), int(hits_format),
+                                               ctypes.byref(hp), ctypes.byref(nh)))
         if nh.value:
-            hits = np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_uint32)), shape=(nh.value,))
+            ct = ctypes.c_uint16 if hits_format == HITS_U16 else ctypes.c_uint32
+            hits = np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ct)), shape=(nh.value,))
             if copy_hits:
                 hits = hits.copy()
         else:
-            hits = np.empty(0, dtype=np.uint32)
+            hits = np.empty(0, dtype=np.uint16 if hits_format == HITS_U16 else np.uint32)
         self.n_seg = n
         return min_e[:n], counts[:n_counts], hits
 

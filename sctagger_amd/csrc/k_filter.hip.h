@@ -6,10 +6,10 @@
 // Per-lane result of the filter kernels: running minimum distance and up to K_SLOTS distinct pattern ids at
 // that minimum, in registers (static indexing only).  More than K_SLOTS ties defer the segment to the scan path.
 // ------------------------------------------------------------------------------------------------------------
-// The wave's 64 min_e bytes (rows r0 .. r0 + 63, `mine` = this lane's byte) as four 16-byte stores instead of 64 one-byte ones:
-// when min_e is the caller's page-locked array every store instruction crosses the PCIe link as it is, and one-byte writes
-// cost 0.8 ms per 10 M rows.  &min_e[r0] must be 16-byte aligned.
-__device__ __forceinline__ void store_min_e_line(uint8_t *__restrict__ min_e, int64_t r0, uint32_t mine) {
+// The wave's 64 per-row bytes (min_e or the one-byte hit count of rows r0 .. r0 + 63, `mine` = this lane's byte) as four 16-byte
+// stores instead of 64 one-byte ones: when the array is the caller's page-locked one every store instruction crosses the PCIe
+// link as it is, and one-byte writes cost 0.8 ms per 10 M rows.  &min_e[r0] must be 16-byte aligned.
+__device__ __forceinline__ void store_byte_line(uint8_t *__restrict__ min_e, int64_t r0, uint32_t mine) {
     const int lane = threadIdx.x & 63;
     const uint32_t w = mine | (__shfl_down(mine, 1, 64) << 8) | (__shfl_down(mine, 2, 64) << 16) | (__shfl_down(mine, 3, 64) << 24);
     const uint32_t w1 = __shfl_down(w, 4, 64), w2 = __shfl_down(w, 8, 64), w3 = __shfl_down(w, 12, 64);
@@ -55,8 +55,10 @@ struct LaneResult {
     // `slots_cap` = entries the slot array holds: a wave whose lists would run past it defers all its rows (the main
     // launch's array holds K_SLOTS entries for every row and cannot overflow; the retry launch's is sized for the usual case).
     // `line`: the wave's rows are 64 consecutive ones starting at r - lane and their min_e bytes are written as one line
-    // (store_min_e_line; lanes without a result of their own contribute SCT_NO_HIT)
-    __device__ __forceinline__ void store(bool row, int64_t r, bool overflow, bool line, uint8_t *__restrict__ min_e,
+    // (store_byte_line; lanes without a result of their own contribute SCT_NO_HIT)
+    // cnt8 != NULL: the caller's one-byte counts are written here as well (a list never holds more than K_SLOTS entries; rows
+    // without a result of their own get 0 until the launch or the slow path that owns them writes theirs)
+    __device__ __forceinline__ void store(bool row, int64_t r, bool overflow, bool line, uint8_t *__restrict__ min_e, uint8_t *__restrict__ cnt8,
                                           uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots, uint64_t slots_cap,
                                           uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer,
                                           uint32_t *__restrict__ defer_count, unsigned long long *__restrict__ slot_cursor,
@@ -75,7 +77,12 @@ struct LaneResult {
         if (lane == 0 && total) base = atomicAdd(slot_cursor, (unsigned long long)total);
         base = __shfl(base, 0, 64);
         if (base + total > slots_cap) defer = row;  // wave-uniform: no room for this wave's lists
-        if (line) store_min_e_line(min_e, r - lane, (row && !defer && mine) ? (uint32_t)best : (uint32_t)SCT_NO_HIT);
+        if (line) {
+            store_byte_line(min_e, r - lane, (row && !defer && mine) ? (uint32_t)best : (uint32_t)SCT_NO_HIT);
+            if (cnt8) store_byte_line(cnt8, r - lane, (row && !defer) ? mine : 0u);
+        } else if (cnt8 && row && !defer) {
+            cnt8[r] = (uint8_t)mine;
+        }
         if (!row) return;
         if (defer) {
             const uint32_t k = atomicAdd(defer_count, 1u);
@@ -595,6 +602,7 @@ struct FilterArgs {
     const uint2 *tab_slot;
     FamTables ft;
     uint8_t *min_e;
+    uint8_t *cnt8;                // NULL, or where the rows' hit counts go as one byte each (the caller's compact format)
     uint32_t *cnt;
     uint32_t *slots;
     uint64_t slots_cap;
@@ -654,9 +662,11 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     }
     bool active = fits;
     // all 64 rows of the wave exist and lie side by side: their min_e bytes go out as one 64-byte line
-    const bool line = a.rows == nullptr && first + 64 <= n && (((uintptr_t)(a.min_e + first)) & 15) == 0;
+    const bool line = a.rows == nullptr && first + 64 <= n && (((uintptr_t)(a.min_e + first)) & 15) == 0 &&
+                      (a.cnt8 == nullptr || (((uintptr_t)(a.cnt8 + first)) & 15) == 0);
     if (a.rows == nullptr && inrange) {
         // routing (main launch): what k_pack did in round 1
+        if (!line && a.cnt8 && (!fits || (nonacgt && a.prefix_len > 0))) a.cnt8[r] = 0;  // with `line` the wave's store covers them
         if (!fits) {
             if (len_all > PLANE_MAX) {  // not representable in the planes: the exhaustive scan or the DP takes the row
                 a.list_long[atomicAdd(&a.ctr[CTR_LONG], 1u)] = (int32_t)r;
@@ -677,7 +687,10 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         lo = hi = 0;
     }
     if (__ballot(active) == 0) {  // the whole wave has nothing to filter
-        if (line) store_min_e_line(a.min_e, first, SCT_NO_HIT);
+        if (line) {
+            store_byte_line(a.min_e, first, SCT_NO_HIT);
+            if (a.cnt8) store_byte_line(a.cnt8, first, 0u);
+        }
         return;
     }
     const W va = sct_valid_mask<W>(len);
@@ -748,7 +761,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         const uint32_t v = L.hlist[k][lane];
         res.add((int)(v >> 30), v & LOC_MASK);
     }
-    res.store(active, r, nc > (uint32_t)HM, line, a.min_e, a.cnt, a.slots, a.slots_cap, a.slot_off, a.list_defer, a.defer_count, a.slot_cursor,
+    res.store(active, r, nc > (uint32_t)HM, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.slot_off, a.list_defer, a.defer_count, a.slot_cursor,
               a.slot_tag);
 }
 

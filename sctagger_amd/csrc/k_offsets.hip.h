@@ -246,3 +246,22 @@ k_route_all(const uint8_t *__restrict__ segs, const OffT *__restrict__ offs, int
     else list_scan[atomicAdd(&ctr[CTR_SCAN], 1u)] = (int32_t)r;
     cnt[r] = CNT_DEFER;
 }
+
+// hits (uint32 on the device) -> uint16 in the caller-visible buffer (SCT_HITS_U16: half the bytes over the link when the
+// barcode set has at most 32 768 entries).  `total` is read on the device; nothing is written if it exceeds `cap`.
+__global__ void __launch_bounds__(256) k_narrow_hits(const uint32_t *__restrict__ hits, const uint32_t *__restrict__ ctr, uint64_t cap,
+                                                      uint16_t *__restrict__ out) {
+    const uint64_t total = *reinterpret_cast<const uint64_t *>(ctr + CTR_TOTAL);
+    if (total > cap) return;
+    // eight entries (16 bytes out) per thread where the addresses allow it
+    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i0 >= total) return;
+    if (i0 + 8 <= total && ((uintptr_t)(out + i0) & 15) == 0) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4 a = *reinterpret_cast<const u4 *>(hits + i0), b = *reinterpret_cast<const u4 *>(hits + i0 + 4);
+        *reinterpret_cast<u4 *>(out + i0) = u4{(a.x & 0xFFFFu) | (a.y << 16), (a.z & 0xFFFFu) | (a.w << 16), (b.x & 0xFFFFu) | (b.y << 16),
+                                               (b.z & 0xFFFFu) | (b.w << 16)};
+    } else {
+        for (uint64_t i = i0; i < i0 + 8 && i < total; i++) out[i] = (uint16_t)hits[i];
+    }
+}

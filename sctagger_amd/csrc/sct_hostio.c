@@ -254,11 +254,13 @@ void sctio_parse_block(const uint8_t *buf, int64_t len, int32_t final, int64_t m
 
 /*
  * sctio_render for a block whose hits come as per-row COUNTS (uint8 if cnt_bytes == 1, else uint32) and int32 segment offsets:
- * the hit list of row r starts where the counts of the rows before it end.  With out == NULL only the size is returned.
+ * the hit list of row r starts where the counts of the rows before it end; the hits are uint16 or uint32 entries.  With
+ * out == NULL only the size is returned.
  */
 int64_t sctio_render_block(const uint8_t *namebuf, const int64_t *name_start, const int64_t *name_end, const uint8_t *segs,
-                           const int32_t *offs, const uint8_t *min_e, const void *cnt, int32_t cnt_bytes, const uint32_t *hits,
-                           const uint8_t *pattern_text, int32_t bl, int64_t n, uint8_t *out) {
+                           const int32_t *offs, const uint8_t *min_e, const void *cnt, int32_t cnt_bytes, const void *hits,
+                           int32_t hit_bytes /* 2 = uint16 entries, else uint32 */, const uint8_t *pattern_text, int32_t bl, int64_t n,
+                           uint8_t *out) {
     int64_t size = 0, pos = 0;
     uint8_t *o = out;
     for (int64_t r = 0; r < n; r++) {
@@ -283,7 +285,8 @@ int64_t sctio_render_block(const uint8_t *namebuf, const int64_t *name_start, co
         *o++ = '\t';
         for (int64_t k = 0; k < c; k++) {
             if (k) *o++ = ',';
-            memcpy(o, pattern_text + (int64_t)hits[pos + k] * bl, (size_t)bl); o += bl;
+            const int64_t p = hit_bytes == 2 ? (int64_t)((const uint16_t *)hits)[pos + k] : (int64_t)((const uint32_t *)hits)[pos + k];
+            memcpy(o, pattern_text + p * bl, (size_t)bl); o += bl;
         }
         pos += c;
         *o++ = '\n';

@@ -569,6 +569,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.tab_slot = c->tab_slot.as<uint2>();
     fa.ft = c->ft;
     fa.min_e = l.min_e_ptr;
+    fa.cnt8 = l.cnt8_ptr;  // the filter launches write the one-byte counts themselves (queue_batch leaves them out of k_offsets)
     fa.cnt = l.cnt.as<uint32_t>();
     fa.slot_off = l.slot_off.as<uint64_t>();
     fa.list_long = l.list_long.as<int32_t>();
@@ -610,7 +611,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
 }
 
 // cnt -> hit_offs (+ the compact counts) -> total, on the lane's stream
-static void queue_offsets(sct_ctx *c, Lane &l) {
+static void queue_offsets(sct_ctx *c, Lane &l, bool counts_done = false) {
     const int64_t n = l.n_seg;
     hipStream_t st = l.stream;
     const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -620,7 +621,7 @@ static void queue_offsets(sct_ctx *c, Lane &l) {
         k_sum_blocks<uint32_t><<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), nullptr);
         k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
         k_offsets<<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), total, l.hit_offs.as<int64_t>(),
-                                                l.cnt8_ptr, l.cnt32_ptr, l.ctr());
+                                                counts_done ? nullptr : l.cnt8_ptr, l.cnt32_ptr, l.ctr());
     } else {
         (void)hipMemsetAsync(l.hit_offs.p, 0, 8, st);
     }
@@ -657,7 +658,7 @@ static int queue_batch(sct_ctx *c, Lane &l) {
                                                                          l.list_scan.as<int32_t>(), l.list_dp.as<int32_t>(), l.ctr());
         }
     }
-    queue_offsets(c, l);
+    queue_offsets(c, l, /* the filter launches wrote the one-byte counts: */ bp.filter_ok);
     if (n > 0 && bp.filter_ok) {
         Timer t(c, l, "k_fill");
         k_fill<<<blocks_for(n, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
@@ -954,11 +955,12 @@ struct ChunkPlan {
     int64_t r0, r1;  // rows
     int64_t b0, b1;  // bytes of segs
     int64_t hit_base = 0;
+    uint64_t narrow_cap = 0;  // 16-bit hits: what the narrowing kernel queued with the chunk could write
 };
 
 extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes, const void *index, int32_t index_format, int64_t n,
-                                int32_t max_err, int32_t threads, uint8_t *min_e, void *counts, int32_t count_format,
-                                const uint32_t **hits_out, int64_t *n_hits_out) {
+                                int32_t max_err, int32_t threads, uint8_t *min_e, void *counts, int32_t count_format, int32_t hits_format,
+                                const void **hits_out, int64_t *n_hits_out) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
     if (!hits_out || !n_hits_out) return fail(SCT_E_ARG, "sct_match_stream: NULL output pointer");
     *hits_out = nullptr;
@@ -969,6 +971,10 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     if (seg_bytes > 0 && !segs) return fail(SCT_E_ARG, "segs is NULL");
     if (index_format < SCT_IDX_OFFS64 || index_format > SCT_IDX_LEN16) return fail(SCT_E_ARG, "unknown index format %d", index_format);
     if (count_format < SCT_CNT_OFFS64 || count_format > SCT_CNT_U8) return fail(SCT_E_ARG, "unknown count format %d", count_format);
+    if (hits_format != SCT_HITS_U32 && hits_format != SCT_HITS_U16) return fail(SCT_E_ARG, "unknown hits format %d", hits_format);
+    const bool hits16 = hits_format == SCT_HITS_U16;
+    if (hits16 && c->have_bc && c->np > 65536)
+        return fail(SCT_E_RANGE, "%d barcodes give pattern ids beyond 16 bits: ask for SCT_HITS_U32", c->n_bc);
     HIPCHK(hipSetDevice(c->device));
     BatchParams bp;
     if (int rc = batch_params(c, max_err, threads, count_format, bp)) return rc;
@@ -991,8 +997,8 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     // Page-locked host memory (sct_host_alloc, hipHostMalloc, hipHostRegister) is mapped into the device's address space: the
     // kernels read the rows and their index from it directly ("zero copy"), at the rate of the PCIe link (57 GB/s measured,
     // profiles/r02_pcie_probe.json), every byte once — there is no upload step to wait for.  Pageable memory is copied.
-    auto device_view = [&](const void *p) -> const void * {
-        if (!p || !c->zero_copy) return nullptr;
+    auto device_view = [&](const void *p, bool always = false) -> const void * {
+        if (!p || !(c->zero_copy || always)) return nullptr;
         hipPointerAttribute_t at;
         const void *d = nullptr;
         if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) d = at.devicePointer;
@@ -1035,7 +1041,10 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     }
     if (int rc = ensure_host_hits(c, (size_t)(n < (1 << 18) ? (1 << 18) : n + n / 4))) return rc;
     // a call of one chunk lets the fill kernel write the hits into the page-locked result buffer itself
-    uint32_t *zc_hits = n_chunks == 1 ? (uint32_t *)device_view(c->h_hits) : nullptr;
+    uint32_t *zc_hits = (n_chunks == 1 && !hits16) ? (uint32_t *)device_view(c->h_hits) : nullptr;
+    // 16-bit hits: the lists are assembled on the device as always and a last kernel writes them, narrowed, into the result buffer
+    uint16_t *zc_hits16 = hits16 ? (uint16_t *)device_view(c->h_hits, true) : nullptr;
+    if (hits16 && !zc_hits16) return fail(SCT_E_STATE, "the page-locked result buffer is not mapped into the device");
     std::vector<ChunkPlan> plan((size_t)n_chunks);
     const size_t isz = index_entry_size(index_format);
     int64_t bytes_seen = 0;   // lengths formats: running sum of the row lengths
@@ -1143,6 +1152,12 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
             }
         }
         if (int rc = queue_batch(c, l)) return rc;
+        if (hits16 && n_chunks == 1) {   // the only chunk: its hits start at 0, no need to wait for anything
+            Timer t(c, l, "k_narrow_hits");
+            const uint64_t cap16 = 2 * (uint64_t)c->h_hits_cap;
+            cp.narrow_cap = cap16;
+            k_narrow_hits<<<blocks_for((int64_t)(l.slots_cap + l.retry_cap + 1), 2048), 256, 0, st>>>(l.hits.as<uint32_t>(), l.ctr(), cap16, zc_hits16);
+        }
         if (!l.direct_min_e || (!l.direct_cnt && count_format != SCT_CNT_OFFS64)) {
             Timer t(c, l, "copy_d2h");
             if (!l.direct_min_e) HIPCHK(hipMemcpyAsync(min_e + cp.r0, l.min_e.p, (size_t)m, hipMemcpyDeviceToHost, st));
@@ -1183,8 +1198,14 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
                 if (hit_base) k_rebase<<<blocks_for(m + 1, 256), 256, 0, st>>>(l.hit_offs.as<int64_t>(), m + 1, hit_base);
                 HIPCHK(hipMemcpyAsync((int64_t *)counts + cp.r0, l.hit_offs.p, 8 * (size_t)(m + 1), hipMemcpyDeviceToHost, st));
             }
-            if (l.n_hits && !l.direct_hits)
+            if (hits16) {
+                // (the buffer was sized for uint32 entries: twice what the narrowed lists need)
+                if (l.n_hits && (n_chunks > 1 || slow || (uint64_t)l.n_hits > cp.narrow_cap))
+                    k_narrow_hits<<<blocks_for(l.n_hits, 2048), 256, 0, st>>>(l.hits_ptr, l.ctr(), ~0ull,
+                                                                              (uint16_t *)device_view(c->h_hits, true) + hit_base);
+            } else if (l.n_hits && !l.direct_hits) {
                 HIPCHK(hipMemcpyAsync(c->h_hits + hit_base, l.hits_ptr, 4 * (size_t)l.n_hits, hipMemcpyDeviceToHost, st));
+            }
         }
         hit_base += l.n_hits;
         for (int i = 0; i < 5; i++) c->stats[i] += l.stats[i];
@@ -1230,9 +1251,9 @@ extern "C" int sct_match(sct_ctx *c, const char *segs, const int64_t *offs, int6
     *hits = nullptr;
     *n_hits = 0;
     if (n < 0 || !offs) return fail(SCT_E_ARG, "sct_match: bad offsets");
-    const uint32_t *h = nullptr;
+    const void *h = nullptr;
     int64_t total = 0;
-    int rc = sct_match_stream(c, segs, offs[n], offs, SCT_IDX_OFFS64, n, max_err, threads, min_e, hit_offs, SCT_CNT_OFFS64, &h, &total);
+    int rc = sct_match_stream(c, segs, offs[n], offs, SCT_IDX_OFFS64, n, max_err, threads, min_e, hit_offs, SCT_CNT_OFFS64, SCT_HITS_U32, &h, &total);
     if (rc) return rc;
     uint32_t *out = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(total ? total : 1));
     if (!out) return fail(SCT_E_ARG, "out of host memory for %lld hits", (long long)total);

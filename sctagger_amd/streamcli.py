@@ -40,7 +40,7 @@ def _iolib():
         vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
         lib.sctio_parse_block.argtypes = [vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp]
         lib.sctio_parse_block.restype = None
-        lib.sctio_render_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i64, vp]
+        lib.sctio_render_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i64, vp]
         lib.sctio_render_block.restype = i64
         lib._stream_ready = True
     return lib
@@ -118,6 +118,8 @@ class _Worker(threading.Thread):
         base = ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p).value
         at, n_rows, out, keep = 0, 0, [], []
         cnt8 = self.cnt.view(np.uint8)
+        # 16-bit hits while the pattern ids fit (2 per barcode): half the bytes back over the link
+        hfmt, hbytes = (_native.HITS_U16, 2) if 2 * self.bc.shape[0] <= 65536 else (_native.HITS_U32, 4)
         while at < len(buf):
             lib.sctio_parse_block(base + at, len(buf) - at, 1 if final else 0, self.cap_rows, self.cap_bytes, self.ns.ctypes.data,
                                   self.ne.ctypes.data, self.segs.ctypes.data, self.offs.ctypes.data, self.lens.ctypes.data,
@@ -136,17 +138,17 @@ class _Worker(threading.Thread):
                 index, ifmt = self.offs[:n + 1], _native.IDX_OFFS32
             try:
                 me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
-                                               count_format=_native.CNT_U8, min_e=self.min_e, counts=cnt8, copy_hits=False)
+                                               count_format=_native.CNT_U8, min_e=self.min_e, counts=cnt8, copy_hits=False, hits_format=hfmt)
                 cbytes = 1
             except _native.SctError as e:
                 if e.code != _native.E_RANGE:
                     raise
                 me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
-                                               count_format=_native.CNT_U32, min_e=self.min_e, counts=self.cnt, copy_hits=False)
+                                               count_format=_native.CNT_U32, min_e=self.min_e, counts=self.cnt, copy_hits=False, hits_format=hfmt)
                 cbytes = 4
             hp = hits.ctypes.data if hits.size else None
             args = [base + at, self.ns.ctypes.data, self.ne.ctypes.data, self.segs.ctypes.data, self.offs.ctypes.data, me.ctypes.data,
-                    cnt.ctypes.data, cbytes, hp, self.table.ctypes.data, self.table.shape[1] if self.table.ndim == 2 else 0, n]
+                    cnt.ctypes.data, cbytes, hp, hbytes, self.table.ctypes.data, self.table.shape[1] if self.table.ndim == 2 else 0, n]
             size = lib.sctio_render_block(*args, None)
             o = np.empty(size, dtype=np.uint8)
             got = lib.sctio_render_block(*args, o.ctypes.data)

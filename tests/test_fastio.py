@@ -171,8 +171,10 @@ def test_block_parser_and_renderer_reproduce_reference_bytes(name, e, t):
             me, ho, hits = trie_oracle.match(util.bc_matrix(mt.barcodes, bl), segs[:o64[-1]].copy(), o64, e, threads=t)
             cnt = np.diff(ho).astype(np.uint8 if cbytes == 1 else np.uint32)
             hits = np.ascontiguousarray(hits, dtype=np.uint32)
+            hbytes = 2 if cbytes == 1 else 4                   # one-byte counts with 16-bit hits, four-byte counts with 32-bit hits
+            hits = np.ascontiguousarray(hits, dtype=np.uint16 if hbytes == 2 else np.uint32)
             args = [base + at, ns.ctypes.data, ne.ctypes.data, segs.ctypes.data, offs.ctypes.data, me.ctypes.data, cnt.ctypes.data, cbytes,
-                    hits.ctypes.data if hits.size else None, table.ctypes.data, bl, n]
+                    hits.ctypes.data if hits.size else None, hbytes, table.ctypes.data, bl, n]
             size = lib.sctio_render_block(*args, None)
             o = np.empty(size, np.uint8)
             assert lib.sctio_render_block(*args, o.ctypes.data) == size

@@ -53,8 +53,10 @@ def check_stream_variants(m, segs, offs, e, t, want, chunk_rows=None):
                         m.match_stream(segs, index, e, t, index_format=ifmt, count_format=cfmt)
                     assert ei.value.code == _native.E_RANGE
                     continue
-                me, cnt, hits = m.match_stream(segs, index, e, t, index_format=ifmt, count_format=cfmt)
-                util.assert_same((me, counts_to_offsets(cnt, cfmt), hits), want, "stream idx=%d cnt=%d" % (ifmt, cfmt))
+                hfmt = _native.HITS_U16 if (k + cfmt) % 2 == 0 and 2 * m.n_bc <= 65536 else _native.HITS_U32
+                me, cnt, hits = m.match_stream(segs, index, e, t, index_format=ifmt, count_format=cfmt, hits_format=hfmt)
+                assert hits.dtype == (np.uint16 if hfmt == _native.HITS_U16 else np.uint32)
+                util.assert_same((me, counts_to_offsets(cnt, cfmt), hits.astype(np.uint32)), want, "stream idx=%d cnt=%d hits=%d" % (ifmt, cfmt, hfmt))
     finally:
         m.set_option("chunk_rows", 0)
 
@@ -91,9 +93,11 @@ def check_zero_copy(m, segs, offs, e, t, want, chunk_rows=0):
                         m.match_stream(psegs, pidx, e, t, index_format=ifmt, count_format=cfmt, min_e=pme, counts=pcnt)
                     assert ei.value.code == _native.E_RANGE
                     continue
-                me, cnt, hits = m.match_stream(psegs, pidx, e, t, index_format=ifmt, count_format=cfmt, min_e=pme, counts=pcnt,
-                                               copy_hits=False)
-                util.assert_same((me, counts_to_offsets(cnt, cfmt), hits), want, "zero copy idx=%d cnt=%d chunk=%d" % (ifmt, cfmt, chunk_rows))
+                for hfmt in ((_native.HITS_U32, _native.HITS_U16) if 2 * m.n_bc <= 65536 and cfmt == _native.CNT_U8 else (_native.HITS_U32,)):
+                    me, cnt, hits = m.match_stream(psegs, pidx, e, t, index_format=ifmt, count_format=cfmt, min_e=pme, counts=pcnt,
+                                                   copy_hits=False, hits_format=hfmt)
+                    util.assert_same((me, counts_to_offsets(cnt, cfmt), hits.astype(np.uint32)), want,
+                                     "zero copy idx=%d cnt=%d hits=%d chunk=%d" % (ifmt, cfmt, hfmt, chunk_rows))
     finally:
         m.set_option("chunk_rows", 0)
         m.sync()
@@ -373,6 +377,11 @@ def test_error_behaviour(m):
     if down[3] != down[4]:
         with pytest.raises(_native.SctError):
             m.match_stream(segs, down, 2, 1, index_format=_native.IDX_OFFS32)
+    m.set_barcodes(synth.make_barcodes(32769, seed=8))
+    with pytest.raises(_native.SctError) as ei:    # pattern ids beyond 16 bits
+        m.match_stream(segs, offs, 2, 1, hits_format=_native.HITS_U16)
+    assert ei.value.code == _native.E_RANGE
+    m.set_barcodes(bc)
     with pytest.raises(_native.SctError) as ei:    # -t whose window prefix reaches bl - max_err: not reproduced
         m.match(segs, offs, 2, 4 ** 14)
     assert ei.value.code == -5
