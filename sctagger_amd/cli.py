@@ -32,7 +32,9 @@ def parse_args(argv=None):
     p.add_argument("--devices", type=int, nargs="+", default=None, help="GPU ids to shard the segments over. Default: 0")
     p.add_argument("--no-stream", action="store_true", help="read the whole -lr file before matching, as the reference does, instead of streaming it in blocks")
     p.add_argument("--gzip-level", type=int, default=4, help="gzip level of the output (the reference writes level 9; the bytes after decompression are identical). Default: 4")
-    l = subparsers.add_parser("extract_lr_bc")             # reference scTagger.py:25-49
+    experimental = ("EXPERIMENTAL: the reference does this step with a third-party library that is not available to this build "
+                    "(%s); the results follow that library's documented behaviour and could not be compared with it")
+    l = subparsers.add_parser("extract_lr_bc", description=experimental % "edlib", help="experimental")   # reference scTagger.py:25-49
     l.add_argument("-r", "--reads", nargs="+", type=str, required=True, help="Space separated paths to reads in FASTQ")
     l.add_argument("-g", "--ranges", nargs="+", type=str, default=list(),
                    help="Ranges where the SR adapter should be found, e.g. f20:40 r1:30 (1-indexed, inclusive). Default: detect from data")
@@ -43,7 +45,7 @@ def parse_args(argv=None):
     l.add_argument("-o", "--outfile", type=str, default=None, help="Path to output file (gzipped). Default: stdout")
     l.add_argument("-p", "--plotfile", type=str, default=None, help="Path to plot file. Default: no plotting")
     l.add_argument("--num-bp-after", type=int, default=20, help="Bases after the end of the adapter alignment to output. Default: 20")
-    q = subparsers.add_parser("extract_sr_bc_from_lr")     # reference scTagger.py:67-79
+    q = subparsers.add_parser("extract_sr_bc_from_lr", description=experimental % "pyahocorasick", help="experimental")   # reference scTagger.py:67-79
     q.add_argument("-i", "--input", type=str, required=True, help="Input TSV file generated from extract_lr_bc step")
     q.add_argument("-o", "--outfile", type=str, default=None, help="Path to output file (gzipped). Default: STDOUT")
     q.add_argument("-wl", "--barcode-whitelist", type=str, required=True, help="Path to TXT barcode whitelist")

@@ -10,7 +10,6 @@ is no fallback.
 import ctypes
 import gzip
 import sys
-from collections import deque
 
 import numpy as np
 
@@ -103,34 +102,34 @@ def read_fastqs(fastqs, gzipped=False):
 # ranges (scTagger.py:199-264 and the -g parsing :106-127)
 # --------------------------------------------------------------------------------------------------------------
 def get_ranges(data):
-    """Peak detection of :199-233 on an int array of adapter locations -> [(first, last), ...]."""
-    ranges = []
+    """Where the adapter is usually found: [(first, last), ...] position ranges, most populated first.
+
+    A restatement of the reference's peak detection (scTagger.py:199-233) — its thresholds are part of the output (the
+    ranges decide which reads are kept), so they are the reference's: a peak counts while the 40 positions around it hold at
+    least 1 % of all locations, it grows over neighbours that hold more than 0.1 % each, and 20 positions either side of a
+    finished range are blanked.  Written here as two linear sweeps from the peak instead of the reference's queue."""
     data = np.asarray(data, dtype=np.int64)
     if data.size == 0:
-        return ranges
-    min_l, max_l = int(data.min()), int(data.max())
-    F = np.bincount(data - min_l, minlength=max_l - min_l + 1).astype(np.float64)
-    T = F.sum()
+        return []
+    lo = int(data.min())
+    hist = np.bincount(data - lo).astype(np.float64)
+    total = hist.sum()
+    grow, ranges = total * 0.001, []
     while True:
-        peak = int(np.argmax(F))
-        around = F[max(0, peak - 20):min(peak + 20, F.size)].sum()
-        _log("--> {: 5.2%} of strend reads fall around {}".format(around / T, min_l + peak))
-        if around < 0.01 * T:
-            break
-        q = deque([peak])
-        first = last = peak
-        while q:
-            i = q.popleft()
-            F[i] = 0
-            if i <= peak and i - 1 > 0 and F[i - 1] > T * 0.001:
-                q.append(i - 1)
-                first = i - 1
-            if i >= peak and i + 1 < F.size and F[i + 1] > T * 0.001:
-                q.append(i + 1)
-                last = i + 1
-        F[max(0, first - 20):min(last + 20, F.size)] = 0
-        ranges.append((min_l + first, min_l + last))
-    return ranges
+        peak = int(np.argmax(hist))
+        share = hist[max(0, peak - 20):min(peak + 20, hist.size)].sum() / total
+        _log("--> {: 5.2%} of the adapter locations lie within 20 positions of {}".format(share, lo + peak))
+        if share < 0.01:
+            return ranges
+        first = peak
+        while first - 1 > 0 and hist[first - 1] > grow:     # position 0 is never joined (the reference tests i - 1 > 0)
+            first -= 1
+        last = peak
+        while last + 1 < hist.size and hist[last + 1] > grow:
+            last += 1
+        hist[max(0, first - 20):min(last + 20, hist.size)] = 0
+        hist[first:last + 1] = 0
+        ranges.append((lo + first, lo + last))
 
 
 def parse_range_specs(specs):

@@ -293,6 +293,27 @@ int main() {
     std::mt19937_64 rng(12345);
     auto rnd = [&](int n) { return (int)(rng() % (uint64_t)n); };
     long checked = 0;
+    // 0. four ASCII bytes at once (sct_decode4, what the filter kernel decodes its rows with) against the byte-wise map_char:
+    //    every byte value in every lane of the word, beside random and beside valid neighbours
+    for (int rep = 0; rep < 300; rep++)
+        for (int lane = 0; lane < 4; lane++)
+            for (int b = 0; b < 256; b++) {
+                uint32_t w = 0;
+                for (int j = 0; j < 4; j++) w |= (uint32_t)(rep % 3 == 0 ? (uint8_t)"ACGTNacgt-"[rnd(10)] : (uint8_t)rnd(256)) << (8 * j);
+                w = (w & ~(0xFFu << (8 * lane))) | ((uint32_t)b << (8 * lane));
+                uint32_t lo, hi, bad;
+                sct_decode4(w, lo, hi, bad);
+                if ((lo | hi | bad) >> 4) { printf("FAIL decode4 stray bits w=%08x\n", w); return 1; }
+                for (int j = 0; j < 4; j++) {
+                    const uint8_t c = (uint8_t)(w >> (8 * j));
+                    const uint32_t code = sct_code(c);
+                    if (((lo >> j) & 1u) != (code & 1u) || ((hi >> j) & 1u) != (code >> 1) || ((bad >> j) & 1u) != (sct_is_acgt(c) ? 0u : 1u)) {
+                        printf("FAIL decode4 w=%08x byte %d\n", w, j);
+                        return 1;
+                    }
+                }
+                checked++;
+            }
     // 1. Myers, 32- and 64-bit words, every pattern length, texts 0..70, small alphabets to force matches
     for (int it = 0; it < 60000; it++) {
         const int m = 1 + rnd(it % 2 ? 32 : 64), n = rnd(71), alpha = 1 + rnd(4);
