@@ -158,7 +158,7 @@ static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline
 // concatenated entry tables (family f's entries start at f * np)
 struct FamTables {
     uint32_t off_base[SCT_NFAM_ALL];
-    uint32_t pid16;  // the pattern ids behind the slots are 16-bit (fewer than 65 536 patterns): half the footprint
+    uint32_t pid16;  // the pattern ids are also held in 16 bits (fewer than 65 536 patterns): half the footprint
 };
 
 template <typename W, int HM, int QC>
@@ -207,8 +207,7 @@ struct EmLds {
 // A queued entry is (qk, qm): qm = lane | t << 8 | t2 << 16 | j << 24 | inline << 31; qk = rest characters (inline)
 // or entry index.
 static constexpr uint32_t QM_INLINE = 0x80000000u;
-static constexpr size_t SLOT_TOTAL = (size_t)SCT_NFAM * (SCT_KEYS + 1);  // slots of the six quarter families; behind them, in
-                                                                         // the same buffer, the pattern ids of the inline entries
+static constexpr size_t SLOT_TOTAL = (size_t)SCT_NFAM * (SCT_KEYS + 1);  // slots of the six quarter families
 
 template <int E, typename W, int HM, bool SL>
 struct FilterWave {
@@ -219,6 +218,8 @@ struct FilterWave {
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
     const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
     const uint2 *__restrict__ tab_slot;     // bucket slots, indexed like tab_off
+    const uint32_t *__restrict__ tab_grp;   // entry index at the first key of every group of 64 keys (quarter families)
+    const uint16_t *__restrict__ tab_ent16; // tab_ent in 16 bits (fewer than 65 536 patterns)
     FamTables ft;
     int lane;
     bool active;
@@ -321,14 +322,20 @@ struct FilterWave {
         __builtin_amdgcn_wave_barrier();
     }
 
-    // pattern id of a verified entry: locator = entry index, or LOC_INLINE | (index into tab_off) << 2 | j
+    // pattern id of a verified entry: locator = entry index, or LOC_INLINE | (slot index) << 2 | j.  An inline slot says where
+    // its bucket starts inside its group of 64 keys; with the group's base (a 24 KB table) that is the entry index.  Everything
+    // read here — the slot again, the group bases, the dense entry ids (16-bit below 65 536 patterns: 0.6 MB at 25 k barcodes) —
+    // stays in the L2 beside the slots; round 1's per-slot id table (2.4 MB, three quarters of it empty) did not, and its
+    // misses were 60 % of the kernel's memory-side traffic.
     __device__ __forceinline__ uint32_t resolve(uint32_t loc) const {
-        if (SL && (loc & LOC_INLINE)) {  // one read: the ids of the inline entries lie behind the slots
-            const uint32_t l = loc & (LOC_INLINE - 1u), at = 3u * (l >> 2) + (l & 3u);
-            if (ft.pid16) return reinterpret_cast<const uint16_t *>(tab_slot + SLOT_TOTAL)[at];
-            return reinterpret_cast<const uint32_t *>(tab_slot + SLOT_TOTAL)[at];
+        uint32_t idx = loc;
+        if (SL && (loc & LOC_INLINE)) {
+            const uint32_t l = loc & (LOC_INLINE - 1u), oi = l >> 2, j = l & 3u;
+            const uint32_t f = oi / (uint32_t)(SCT_KEYS + 1), key = oi - f * (uint32_t)(SCT_KEYS + 1);
+            idx = tab_grp[f * (uint32_t)SCT_GRP_PER_FAM + (key >> SCT_GRP_SHIFT)] + sct_slot_within(tab_slot[oi].x) + j;
         }
-        return tab_ent[loc];
+        if (ft.pid16) return reinterpret_cast<const uint16_t *>(tab_ent16)[idx];
+        return tab_ent[idx];
     }
 
     // Tiering: the families are ordered so that after H1 every barcode at distance 0 has been verified, and after
@@ -600,6 +607,8 @@ struct FilterArgs {
     const int32_t *rows;          // NULL = all rows; else the listed rows (retry launch)
     const uint32_t *tab_off, *tab_ent, *tab_code;
     const uint2 *tab_slot;
+    const uint32_t *tab_grp;
+    const uint16_t *tab_ent16;
     FamTables ft;
     uint8_t *min_e;
     uint8_t *cnt8;                // NULL, or where the rows' hit counts go as one byte each (the caller's compact format)
@@ -707,7 +716,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     static_assert(!(SL && (THIRDS || RT)), "bucket slots exist for the 16-character quarter families only");
-    FilterWave<E, W, HM, SL> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.ft, lane, active, len, lo, hi};
+    FilterWave<E, W, HM, SL> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.ft, lane, active, len, lo, hi};
 #define RUN_FAMILY(FID)                                                         \
     do {                                                                        \
         if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \

@@ -485,17 +485,25 @@ SCT_HD uint32_t wm_anchored_pair(const Fam &fam, EmX &&emx, EmY &&emy, WV vax, W
 // ---------------------------------------------------------------------------------------------------
 // Bucket slots of the quarter families (k_filter.hip.h): one 8-byte word per seed key, read as two 32-bit words
 // (a = bits 0..31, b = bits 32..63), that answers most lookups by itself.
-//   bit 15 clear  inline bucket: bits 0..1 = n <= 3 entries, bits 16(j+1) .. 16(j+1)+15 = rest characters of entry j
-//                 (sct_rest_of) — all a verification needs besides the key
+//   bit 15 clear  inline bucket: bits 0..1 = n <= 3 entries, bits 2..14 = where its entries start inside their group of 64 keys
+//                 (sct_slot_within), bits 16(j+1) .. 16(j+1)+15 = rest characters of entry j (sct_rest_of) — all a
+//                 verification needs besides the key
 //   bit 15 set    long bucket: bits 16..47 = index of its first entry, bits 0..14 | bits 48..63 << 15 = its length
 // The kernel queues entry 0 as `mid`, entry 1 as the funnel shift {top, mid} >> 16 and entry 2 as `top`: the low 16
 // bits of each are that entry's rest (the automaton ignores what lies above them).
 // ---------------------------------------------------------------------------------------------------
-SCT_HD uint64_t sct_slot_inline(uint32_t n, const uint32_t *rest) {
-    uint64_t v = n;
+// `within` (bits 2..14 of an inline slot): index of the bucket's first entry, counted from the first entry of the bucket's GROUP
+// of 64 keys (SCT_GRP_*).  The pattern id of inline entry j is then ent[group base + within + j]: one small table of group
+// bases (1 025 words per family) and the dense entry table replace a per-slot id table three times the size of the slots.
+#define SCT_GRP_SHIFT 6
+#define SCT_GRP_PER_FAM ((SCT_KEYS >> SCT_GRP_SHIFT) + 1)
+#define SCT_SLOT_WITHIN_MAX 0x1FFFu
+SCT_HD uint64_t sct_slot_inline(uint32_t n, const uint32_t *rest, uint32_t within) {
+    uint64_t v = n | ((within & SCT_SLOT_WITHIN_MAX) << 2);
     for (uint32_t j = 0; j < n; j++) v |= (uint64_t)(rest[j] & 0xFFFFu) << (16 * (j + 1));
     return v;
 }
+SCT_HD uint32_t sct_slot_within(uint32_t a) { return (a >> 2) & SCT_SLOT_WITHIN_MAX; }
 SCT_HD uint64_t sct_slot_long(uint32_t first, uint32_t n) {
     return 0x8000ull | (n & 0x7FFFu) | ((uint64_t)first << 16) | ((uint64_t)(n >> 15) << 48);
 }

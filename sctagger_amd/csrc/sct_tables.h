@@ -3,8 +3,8 @@
 //
 // Per family f (sct_core.h): an offsets array of nkeys(f) + 1 entries holding ABSOLUTE indices into the entry tables
 // (family f's entries start at f * np), the entries as pattern ids (ascending inside a bucket) and as 2-bit codes, and
-// — for the six quarter families — one 8-byte bucket slot per key (sct_slot_*), indexed like the offsets, with the
-// pattern ids of the slots' inline entries beside them.
+// — for the six quarter families — one 8-byte bucket slot per key (sct_slot_*), indexed like the offsets, and the entry
+// index at the start of every group of 64 keys (an inline slot says where its entries start inside its group).
 #pragma once
 #include <stdint.h>
 
@@ -17,7 +17,7 @@ struct SctSeedTables {
     uint32_t off_base[SCT_NFAM_ALL] = {};  // where family f's offsets (and slots) start
     std::vector<uint32_t> off, ent, code;
     std::vector<uint64_t> slot;
-    std::vector<uint32_t> slot_pid;        // pattern id of inline entry j of slot i at [3 * i + j]: one read resolves a hit
+    std::vector<uint32_t> grp;             // per quarter family SCT_GRP_PER_FAM words: entry index at the first key of every group of 64 keys
     double long_share = 1.0;               // share of the quarter families' keys whose bucket does not fit a slot
 };
 
@@ -63,21 +63,22 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
     size_t slot_total = 0;
     for (int f = 0; f < SCT_NFAM; f++) slot_total += (size_t)sct_family_nkeys(f) + 1;
     T.slot.assign(slot_total, 0ull);
-    T.slot_pid.assign(3 * slot_total, 0u);
+    T.grp.assign((size_t)SCT_NFAM * SCT_GRP_PER_FAM, 0u);
     size_t long_keys = 0;
     for (int f = 0; f < SCT_NFAM; f++) {
         const SctFamilyRT fam = sct_family_rt(f, bl);
         const uint32_t *o = T.off.data() + T.off_base[f];
         uint64_t *sl = T.slot.data() + T.off_base[f];
+        uint32_t *grp = T.grp.data() + (size_t)f * SCT_GRP_PER_FAM;
+        for (uint32_t g = 0; g < SCT_GRP_PER_FAM; g++) grp[g] = o[(size_t)g << SCT_GRP_SHIFT < SCT_KEYS ? (size_t)g << SCT_GRP_SHIFT : SCT_KEYS];
         for (uint32_t k = 0; k < sct_family_nkeys(f); k++) {
             const uint32_t cnt = o[k + 1] - o[k];
-            if (cnt <= 3) {
+            const uint32_t within = o[k] - grp[k >> SCT_GRP_SHIFT];
+            // (a short bucket behind thousands of entries of its own group cannot say where it starts: it is listed as a long one)
+            if (cnt <= 3 && within <= SCT_SLOT_WITHIN_MAX) {
                 uint32_t rest[3] = {0, 0, 0};
-                for (uint32_t j = 0; j < cnt; j++) {
-                    rest[j] = sct_rest_of(fam, T.code[o[k] + j]);
-                    T.slot_pid[3 * ((size_t)T.off_base[f] + k) + j] = T.ent[o[k] + j];
-                }
-                sl[k] = sct_slot_inline(cnt, rest);
+                for (uint32_t j = 0; j < cnt; j++) rest[j] = sct_rest_of(fam, T.code[o[k] + j]);
+                sl[k] = sct_slot_inline(cnt, rest, within);
             } else {
                 long_keys++;
                 sl[k] = sct_slot_long(o[k], cnt);

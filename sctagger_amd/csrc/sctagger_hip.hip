@@ -191,7 +191,7 @@ struct sct_ctx {
     int n_bc = 0, bl = 0, np = 0;
     bool have_bc = false, have_tables = false, have_thirds = false;
     FamTables ft{};
-    DevBuf pat, tab_off, tab_ent, tab_code, tab_slot;
+    DevBuf pat, tab_off, tab_ent, tab_code, tab_slot, tab_grp, tab_ent16;
     std::vector<Lane *> lanes;  // lanes[0] always exists
     // stream API: page-locked result buffer, owned by the context, valid until the next stream call
     uint32_t *h_hits = nullptr;
@@ -329,7 +329,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
         l->release();
         delete l;
     }
-    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->tab_slot, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip,
+    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->tab_slot, &c->tab_grp, &c->tab_ent16, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip,
                       &c->ad_peq, &c->ad_strand, &c->ad_dist, &c->ad_locs, &c->ad_first, &c->ad_last};
     for (DevBuf *b : bufs) b->release();
     if (c->h_hits) (void)hipHostFree(c->h_hits);
@@ -440,26 +440,22 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             FamTables ft{};
             for (int f = 0; f < tb.nfam; f++) ft.off_base[f] = tb.off_base[f];
             c->long_share = tb.long_share;
-            // one buffer: the slots, then the pattern ids of their inline entries (k_filter.hip.h: resolve)
             if (tb.slot.size() != SLOT_TOTAL) {
                 rc = fail(SCT_E_STATE, "seed tables: unexpected slot count");
                 break;
             }
-            if (c->tab_slot.ensure(tb.slot.size() * sizeof(uint64_t) + tb.slot_pid.size() * sizeof(uint32_t)) ||
-                c->tab_off.ensure(tb.off.size() * sizeof(uint32_t) + 16) || c->tab_ent.ensure(tb.ent.size() * sizeof(uint32_t)) ||
-                c->tab_code.ensure(tb.code.size() * sizeof(uint32_t))) {
+            ft.pid16 = np <= 65536 ? 1u : 0u;
+            if (ft.pid16) pid16.assign(tb.ent.begin(), tb.ent.end());
+            if (c->tab_slot.ensure(tb.slot.size() * sizeof(uint64_t)) || c->tab_grp.ensure(tb.grp.size() * sizeof(uint32_t)) ||
+                c->tab_ent16.ensure(pid16.size() * sizeof(uint16_t) + 16) || c->tab_off.ensure(tb.off.size() * sizeof(uint32_t) + 16) ||
+                c->tab_ent.ensure(tb.ent.size() * sizeof(uint32_t)) || c->tab_code.ensure(tb.code.size() * sizeof(uint32_t))) {
                 rc = SCT_E_HIP;
                 break;
             }
-            ft.pid16 = np <= 65536 ? 1u : 0u;
             hipError_t e = hipMemcpyAsync(c->tab_slot.p, tb.slot.data(), tb.slot.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
-            char *ids = (char *)c->tab_slot.p + tb.slot.size() * sizeof(uint64_t);
-            if (ft.pid16) {
-                pid16.assign(tb.slot_pid.begin(), tb.slot_pid.end());
-                if (e == hipSuccess) e = hipMemcpyAsync(ids, pid16.data(), pid16.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st);
-            } else if (e == hipSuccess) {
-                e = hipMemcpyAsync(ids, tb.slot_pid.data(), tb.slot_pid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-            }
+            if (e == hipSuccess) e = hipMemcpyAsync(c->tab_grp.p, tb.grp.data(), tb.grp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess && ft.pid16 && !pid16.empty())
+                e = hipMemcpyAsync(c->tab_ent16.p, pid16.data(), pid16.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipMemcpyAsync(c->tab_code.p, tb.code.data(), tb.code.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipMemcpyAsync(c->tab_off.p, tb.off.data(), tb.off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipMemcpyAsync(c->tab_ent.p, tb.ent.data(), tb.ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
@@ -567,6 +563,8 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.tab_ent = c->tab_ent.as<uint32_t>();
     fa.tab_code = c->tab_code.as<uint32_t>();
     fa.tab_slot = c->tab_slot.as<uint2>();
+    fa.tab_grp = c->tab_grp.as<uint32_t>();
+    fa.tab_ent16 = c->tab_ent16.as<uint16_t>();
     fa.ft = c->ft;
     fa.min_e = l.min_e_ptr;
     fa.cnt8 = l.cnt8_ptr;  // the filter launches write the one-byte counts themselves (queue_batch leaves them out of k_offsets)

@@ -233,7 +233,7 @@ static bool check_adapter(const std::vector<int> &q, const std::vector<int> &t) 
 
 // ---- the filter path over the seed tables, emulated on the host: every (family, placement) lookup of a text goes
 // through the bucket slots (and, second run, through the plain offsets), every candidate through the anchored
-// automaton on its rest characters, pattern ids are resolved as the kernel does (inline entry j -> ent[off[key] + j]).
+// automaton on its rest characters, pattern ids are resolved as the kernel does (inline entry j -> ent[group base + within + j]).
 // Result = (minimum distance, set of pattern ids at it); must equal the plain DP over all patterns.
 struct PatPlanes {
     uint32_t x, y;
@@ -266,7 +266,8 @@ static bool emulate_filter(const SctSeedTables &T, const std::vector<std::vector
                 if (sct_slot_is_inline(sa)) {
                     const uint32_t q[3] = {mid, sct_slot_next(mid, top), top};
                     for (uint32_t j = 0; j < sct_slot_inline_count(sa); j++)
-                        add(wm_anchored_rest<E, uint32_t>(fam, em, va, q[j], a, b), T.slot_pid[3 * ((size_t)T.off_base[f] + key) + j]);
+                        add(wm_anchored_rest<E, uint32_t>(fam, em, va, q[j], a, b),
+                            T.ent[T.grp[(size_t)f * SCT_GRP_PER_FAM + (key >> SCT_GRP_SHIFT)] + sct_slot_within(sa) + j]);
                 } else {
                     for (uint32_t k = 0; k < sct_slot_long_count(sa, top); k++)
                         add(wm_anchored_rest<E, uint32_t>(fam, em, va, sct_rest_of(fam, T.code[mid + k]), a, b), T.ent[mid + k]);
@@ -348,11 +349,12 @@ int main() {
     for (int it = 0; it < 200000; it++) {
         const uint32_t n = (uint32_t)rnd(4);
         uint32_t rest[3] = {(uint32_t)rng(), (uint32_t)rng(), (uint32_t)rng()};
-        const uint64_t v = sct_slot_inline(n, rest);
+        const uint32_t within = (uint32_t)rnd(SCT_SLOT_WITHIN_MAX + 1);
+        const uint64_t v = sct_slot_inline(n, rest, within);
         const uint32_t a = (uint32_t)v, b = (uint32_t)(v >> 32);
         const uint32_t mid = sct_slot_mid(a, b), top = sct_slot_top(b);
         const uint32_t q[3] = {mid, sct_slot_next(mid, top), top};  // entries 0, 1, 2 as queued
-        bool ok = sct_slot_is_inline(a) && sct_slot_inline_count(a) == n;
+        bool ok = sct_slot_is_inline(a) && sct_slot_inline_count(a) == n && sct_slot_within(a) == within;
         for (uint32_t j = 0; j < n; j++) ok = ok && (q[j] & 0xFFFFu) == (rest[j] & 0xFFFFu);
         const uint32_t first = (uint32_t)rng();
         const uint32_t len = it % 3 == 0 ? 4u + (uint32_t)rnd(70000) : 4u + (uint32_t)(rng() % 0x7FFFFFFCull);
