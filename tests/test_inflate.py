@@ -1,0 +1,124 @@
+"""The DEFLATE decoder of the streaming command (sctagger_amd/csrc/sct_inflate.c) against zlib: every block type, every
+strategy and level, output blocks of awkward sizes, truncated and corrupted streams; and the gzip container around it
+(sctagger_amd/streamcli.py: header fields, several members, padding, CRC and length checks).  CPU only."""
+import ctypes
+import gzip
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from sctagger_amd import streamcli
+
+
+def inflate(raw, cap=1 << 20):
+    """-> (output bytes, status, input bytes used) through sctio_inflate_run with output blocks of `cap` bytes."""
+    lib = streamcli._iolib()
+    st = lib.sctio_inflate_new()
+    buf = np.frombuffer(raw, dtype=np.uint8) if raw else np.zeros(1, np.uint8)
+    lib.sctio_inflate_set_input(st, buf.ctypes.data, len(raw))
+    out = np.empty(32768 + cap, np.uint8)
+    parts, status, used = [], ctypes.c_int32(0), ctypes.c_int64(0)
+    while True:
+        n = lib.sctio_inflate_run(st, out.ctypes.data, cap, ctypes.byref(status), ctypes.byref(used))
+        assert 0 <= n <= cap
+        parts.append(out[32768:32768 + n].tobytes())
+        if status.value != 0:
+            break
+    lib.sctio_inflate_free(st)
+    return b"".join(parts), status.value, used.value
+
+
+def corpus():
+    rng = random.Random(1)
+    yield b""
+    yield b"a"
+    yield b"abc" * 5
+    yield bytes(rng.getrandbits(8) for _ in range(70000))                      # incompressible: stored blocks
+    yield b"A" * 400000                                                         # distance 1, maximal lengths
+    yield ("\n".join("r%09d\t1\t30\t%s" % (i, "".join(rng.choice("ACGT") for _ in range(22))) for i in range(40000))).encode()
+    yield bytes(rng.choice(b"ab") for _ in range(150000))                       # two symbols: very short codes
+    yield b"".join(bytes([rng.getrandbits(8)]) * rng.randint(1, 300) for _ in range(1500))
+    x = bytearray()
+    for _ in range(1500):                                                       # long-range copies up to the window size
+        if x and rng.random() < 0.6:
+            st = rng.randrange(len(x))
+            x += x[st:st + rng.randint(3, 400)]
+        else:
+            x += bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 50)))
+    yield bytes(x)
+    yield bytes(range(256)) * 300                                               # every literal; codes longer than the primary table
+
+
+@pytest.mark.parametrize("ci,data", list(enumerate(corpus())), ids=lambda v: str(v) if isinstance(v, int) else "")
+def test_decoder_equals_zlib(ci, data):
+    for level in (0, 1, 4, 9):
+        for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+            c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+            raw = c.compress(data) + c.flush()
+            for cap in (65536, 70001, 1 << 20):
+                got, status, used = inflate(raw, cap)
+                assert status == 1 and used == len(raw) and got == data, (ci, level, strategy, cap, status, used, len(raw))
+
+
+def test_truncated_and_corrupted_streams_are_reported_not_followed():
+    rng = random.Random(2)
+    data = ("\n".join("r%09d\t1\t30\tACGTACGTACGTACGTACGTAC" % i for i in range(30000))).encode()
+    for level in (1, 6):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        raw = c.compress(data) + c.flush()
+        for cut in (0, 1, 2, 10, len(raw) // 2, len(raw) - 1):
+            got, status, _ = inflate(raw[:cut])
+            assert status < 0 and data.startswith(got), (cut, status)
+        for _ in range(400):                       # flipped bits: any outcome but a crash; what zlib accepts must be accepted alike
+            b = bytearray(raw)
+            b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            got, status, _ = inflate(bytes(b), 65536)
+            try:
+                want = zlib.decompressobj(-15).decompress(bytes(b))
+            except zlib.error:
+                want = None
+            if status == 1:
+                assert want is not None and got == want
+    for junk in (b"\x07", b"\xff" * 40, bytes(rng.getrandbits(8) for _ in range(5000))):   # reserved block type, nonsense
+        got, status, _ = inflate(junk)
+        assert status < 0 or zlib.decompressobj(-15).decompress(junk) == got
+
+
+def test_gzip_container(tmp_path):
+    rng = random.Random(3)
+    text = ("\n".join("r%d\t0\t5\t%s" % (i, "".join(rng.choice("ACGTN") for _ in range(rng.randint(0, 40)))) for i in range(20000)) + "\n").encode()
+
+    def read(path, block=1 << 16):
+        return b"".join(b for b, _ in streamcli.iter_blocks(str(path), block))
+
+    p = tmp_path / "named.tsv.gz"                  # FNAME + mtime in the header (gzip.open writes them)
+    with gzip.open(p, "wb", compresslevel=6) as f:
+        f.write(text)
+    assert read(p) == text
+    hdr = tmp_path / "hdr.tsv.gz"                  # FEXTRA, FCOMMENT and FHCRC
+    member = gzip.compress(text[:5000])
+    body = member[10:]
+    hdr.write_bytes(bytes([0x1F, 0x8B, 8, 4 | 16 | 2, 0, 0, 0, 0, 0, 255]) + b"\x03\x00xyz" + b"a comment\0" + b"\x12\x34" + body)
+    assert read(hdr) == text[:5000]
+    multi = tmp_path / "multi.tsv.gz"              # three members, zero padding behind the last
+    multi.write_bytes(gzip.compress(text[:7000]) + gzip.compress(b"") + gzip.compress(text[7000:], 1) + b"\0" * 700)
+    assert read(multi) == text
+    bad_crc = bytearray(gzip.compress(text))
+    bad_crc[-6] ^= 0x40
+    q = tmp_path / "crc.tsv.gz"
+    q.write_bytes(bytes(bad_crc))
+    with pytest.raises(gzip.BadGzipFile):
+        read(q)
+    bad_len = bytearray(gzip.compress(text))
+    bad_len[-1] ^= 1
+    q.write_bytes(bytes(bad_len))
+    with pytest.raises(gzip.BadGzipFile):
+        read(q)
+    q.write_bytes(gzip.compress(text)[:-9])        # trailer missing
+    with pytest.raises((EOFError, gzip.BadGzipFile)):
+        read(q)
+    q.write_bytes(gzip.compress(text) + b"garbage")
+    with pytest.raises(gzip.BadGzipFile):
+        read(q)

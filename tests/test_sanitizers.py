@@ -17,7 +17,8 @@ def _asan_runtime():
 
 
 def test_c_helpers_and_oracle_under_asan_ubsan():
-    """tests/test_fastio.py, test_oracle.py and the CPU part of test_fuzz.py once more, in a python that has libasan preloaded and loads the
+    """tests/test_fastio.py, test_inflate.py (the DEFLATE decoder on valid, truncated and corrupted streams), test_oracle.py and
+    the CPU part of test_fuzz.py once more, in a python that has libasan preloaded and loads the
     sanitizer builds of libsctagger_io / liboracle: any heap overrun, use after free or undefined operation aborts it."""
     rt = _asan_runtime()
     assert rt, "gcc's libasan.so not found"
@@ -27,7 +28,8 @@ def test_c_helpers_and_oracle_under_asan_ubsan():
                SCT_IO_LIB=os.path.join(ROOT, "sctagger_amd", "csrc", "libsctagger_io_asan.so"),
                SCT_ORACLE_LIB=os.path.join(ROOT, "oracle", "liboracle_asan.so"))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_fastio.py"),
-                        os.path.join(ROOT, "tests", "test_oracle.py"), os.path.join(ROOT, "tests", "test_fuzz.py"), "-m", "not gpu"],
+                        os.path.join(ROOT, "tests", "test_inflate.py"), os.path.join(ROOT, "tests", "test_oracle.py"),
+                        os.path.join(ROOT, "tests", "test_fuzz.py"), "-m", "not gpu"],
                        env=env, capture_output=True, cwd=ROOT, timeout=1200)
     out = r.stdout.decode() + r.stderr.decode()
     assert r.returncode == 0 and "AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]
