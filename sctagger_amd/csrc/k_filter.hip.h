@@ -132,7 +132,7 @@ struct LaneResult {
 //            (d, pattern id) to that segment's list in LDS (LDS atomic counter);
 //   finish   (after the last family) every lane folds its own list into (minimum, distinct pattern ids), sorts
 //            and stores.
-// A segment with more than HMAX verified matches (duplicates included) or more than K_SLOTS ties is deferred.
+// A segment with more than HMAX verified matches AT ITS MINIMUM (duplicates included; insert_hit) or more than K_SLOTS ties is deferred.
 // All cross-lane traffic is inside one wave: LDS operations of a wave execute in issue order, so no barrier is
 // needed; __builtin_amdgcn_wave_barrier() only pins the compiler's ordering.
 // ------------------------------------------------------------------------------------------------------------
@@ -148,7 +148,7 @@ struct QueueCap {
 // 3.52 vs 3.39 ms at 25 k barcodes, 0.09 % of the rows retried); larger sets have more ties and keep 8 (400 k barcodes:
 // 24 % instead of 16 % of the rows retried with 6).
 static constexpr int HMAX = 8, HMAX_SL = 6;  // main launch
-static constexpr int K_RETRY = 32, H_RETRY = 60;  // retry launch: 60 x 256 B of hit lists leave two blocks of 80 KB per CU
+static constexpr int K_RETRY = 32, H_RETRY = 80;  // retry launch: 80 x 256 B of LDS hold 320 hit-list entries for each of a wave's 16 rows
 static constexpr int H_RETRY_SL = H_RETRY;
 static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
 static constexpr uint32_t LOC_MASK = (1u << 30) - 1u;    // locator in a hit-list entry (2 bits of distance above it)
@@ -209,9 +209,13 @@ struct EmLds {
 static constexpr uint32_t QM_INLINE = 0x80000000u;
 static constexpr size_t SLOT_TOTAL = (size_t)SCT_NFAM * (SCT_KEYS + 1);  // slots of the six quarter families
 
-template <int E, typename W, int HM, bool SL>
+template <int E, typename W, int HM, bool SL, int RPW = 64>
 struct FilterWave {
     static constexpr int HMAX = HM;
+    // hit list entries per row: the LDS array hlist[HM][64] is shared out among the wave's RPW rows, entry k of row r at
+    // [k * RPW + r] — HM per row in the main launch (64 rows), four times as many in the retry launch (16 rows)
+    static constexpr int CAP = HM * 64 / RPW;
+    __device__ __forceinline__ uint32_t &hl(uint32_t k, uint32_t row) { return (&L.hlist[0][0])[k * (uint32_t)RPW + row]; }
     static constexpr int QCAP = QueueCap<SL, HM, W>::value;
     FilterWaveLds<W, HM, QCAP> &L;
     const uint32_t *__restrict__ tab_off;
@@ -236,15 +240,56 @@ struct FilterWave {
     static constexpr uint32_t RING = 2u * (uint32_t)QCAP;
     __device__ __forceinline__ uint32_t *ring() { return &L.qk[0]; }
 
+    // A verified candidate (distance d <= E, locator loc) of the segment in lane `src`.  Only the candidates at the segment's
+    // FINAL minimum are reported, and the minimum only falls: one that is farther away than the best seen so far is dropped,
+    // and when the list is full a newcomer takes the place of an entry that is farther away than itself (compare-and-swap: two
+    // lanes may come for the same place).  The row is deferred only if more entries AT ITS MINIMUM turn up than the list holds
+    // — with a few million barcodes most rows see a dozen candidates two edits away before the one that is one edit away, and
+    // round 1 deferred them all (92 % of the rows at 3.6 M barcodes, e <= 2).
+    static constexpr uint32_t HCNT_OVERFLOW = 0x80000000u;
+    __device__ __forceinline__ void insert_hit(uint32_t src, uint32_t d, uint32_t loc) {
+        if constexpr (SL) {
+            // bucket slots = small barcode sets (up to ~40 k): a row sees few candidates besides the right one, the plain
+            // list is enough and 4 % faster at 25 k barcodes (3.16 vs 3.28 ms per 10 M rows)
+            atomicMin(&L.best[src], d);
+            const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
+            if (k < (uint32_t)CAP) hl(k, src) = (d << 30) | loc;
+            else atomicOr(&L.hcnt[src], HCNT_OVERFLOW);
+            return;
+        }
+        const uint32_t before = atomicMin(&L.best[src], d);
+        if (d > before) return;
+        const uint32_t entry = (d << 30) | loc;
+        const uint32_t k = atomicAdd(&L.hcnt[src], 1u) & ~HCNT_OVERFLOW;
+        if (k < (uint32_t)CAP) hl(k, src) = entry;
+        // every lane that was given a place has written it before any lane looks for one to take over (two ifs in a row, not an
+        // if / else whose sides the compiler may order either way: a place still holding old bytes must not be "replaced")
+        __builtin_amdgcn_wave_barrier();
+        if (k >= (uint32_t)CAP) {
+            bool placed = false;
+            for (int i = 0; i < CAP && !placed; i++) {
+                uint32_t cur = hl((uint32_t)i, src);
+                while ((cur >> 30) > d) {
+                    const uint32_t seen = atomicCAS(&hl((uint32_t)i, src), cur, entry);
+                    if (seen == cur) {
+                        placed = true;
+                        break;
+                    }
+                    cur = seen;
+                }
+            }
+            // no place: unless a closer one has turned up meanwhile the row has more candidates at its minimum than the list holds
+            if (!placed && L.best[src] >= d) atomicOr(&L.hcnt[src], HCNT_OVERFLOW);
+        }
+    }
+
     template <typename Fam>
     __device__ __forceinline__ void record(const Fam &fam, uint32_t e, uint32_t d) {
         const uint32_t src = (e >> 16) & 63u, j = e >> 30;
         const int t = (int)((e >> 22) & 31u), t2 = t + fam.GAP + (int)((e >> 27) & 7u) - fam.SLACK;
         const uint32_t oi = ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[src].lo, L.pl[src].hi, t, t2);
-        atomicMin(&L.best[src], d);
         if (j < 3u) {
-            const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
-            if (k < HMAX) L.hlist[k][src] = (d << 30) | LOC_INLINE | (oi << 2) | j;
+            insert_hit(src, d, LOC_INLINE | (oi << 2) | j);
         } else {
             // an entry of a long bucket: every entry of the bucket with these rest characters is this barcode
             // sequence (duplicates are distinct ids and all of them hits; each is also queued itself, the ids are
@@ -252,8 +297,7 @@ struct FilterWave {
             const uint32_t s = tab_off[oi], en = tab_off[oi + 1];
             for (uint32_t g = s; g < en; g++) {
                 if (((sct_rest_of(fam, tab_code[g]) ^ e) & 0xFFFFu) != 0u) continue;
-                const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
-                if (k < HMAX) L.hlist[k][src] = (d << 30) | g;
+                insert_hit(src, d, g);
             }
         }
     }
@@ -306,17 +350,13 @@ struct FilterWave {
                 if (ix)
                     gx = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[sx].lo, L.pl[sx].hi, tx, t2x)) << 2) |
                          ((mx >> 24) & 3u);
-                atomicMin(&L.best[sx], dx);
-                const uint32_t k = atomicAdd(&L.hcnt[sx], 1u);
-                if (k < HMAX) L.hlist[k][sx] = (dx << 30) | gx;
+                insert_hit(sx, dx, gx);
             }
             if (vy && dy <= (uint32_t)E) {
                 if (iy)
                     gy = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[sy].lo, L.pl[sy].hi, ty, t2y)) << 2) |
                          ((my >> 24) & 3u);
-                atomicMin(&L.best[sy], dy);
-                const uint32_t k = atomicAdd(&L.hcnt[sy], 1u);
-                if (k < HMAX) L.hlist[k][sy] = (dy << 30) | gy;
+                insert_hit(sy, dy, gy);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -716,7 +756,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     static_assert(!(SL && (THIRDS || RT)), "bucket slots exist for the 16-character quarter families only");
-    FilterWave<E, W, HM, SL> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.ft, lane, active, len, lo, hi};
+    FilterWave<E, W, HM, SL, RPW> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.ft, lane, active, len, lo, hi};
 #define RUN_FAMILY(FID)                                                         \
     do {                                                                        \
         if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \
@@ -745,33 +785,138 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     }
 #undef RUN_FAMILY
     // Locators -> pattern ids, in place, by all lanes of the wave: with RPW rows per wave, 64 / RPW lanes share a row's
-    // list (the retry launch keeps up to 64 hits for each of its 16 rows), up to four table reads in flight per lane.
+    // list, up to four table reads in flight per lane.
+    using FW = FilterWave<E, W, HM, SL, RPW>;
+    constexpr uint32_t CAP = (uint32_t)FW::CAP;
     {
         constexpr int PARTS = 64 / RPW;
         const int row = lane % RPW, part = lane / RPW;
-        const uint32_t n_row = L.hcnt[row] < (uint32_t)HM ? L.hcnt[row] : (uint32_t)HM;  // 0 for rows without work
+        const uint32_t c_row = L.hcnt[row] & ~FW::HCNT_OVERFLOW;
+        const uint32_t n_row = c_row < CAP ? c_row : CAP;  // 0 for rows without work
         for (uint32_t k0 = (uint32_t)part; k0 < n_row; k0 += 4 * PARTS) {
             uint32_t v[4], pid[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = k0 + i * PARTS < n_row ? L.hlist[k0 + i * PARTS][row] : 0u;
+            for (int i = 0; i < 4; i++) v[i] = k0 + i * PARTS < n_row ? W_.hl(k0 + i * PARTS, (uint32_t)row) : 0u;
 #pragma unroll
             for (int i = 0; i < 4; i++) pid[i] = k0 + i * PARTS < n_row ? W_.resolve(v[i] & LOC_MASK) : 0u;
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (k0 + i * PARTS < n_row) L.hlist[k0 + i * PARTS][row] = (v[i] & ~LOC_MASK) | pid[i];
+                if (k0 + i * PARTS < n_row) W_.hl(k0 + i * PARTS, (uint32_t)row) = (v[i] & ~LOC_MASK) | pid[i];
         }
         __builtin_amdgcn_wave_barrier();
     }
-    const uint32_t nc = active ? L.hcnt[lane] : 0u;
-    LaneResult<E, KS> res;
-    res.init();
-    const uint32_t lim = nc < (uint32_t)HM ? nc : (uint32_t)HM;
-    for (uint32_t k = 0; k < lim; k++) {
-        const uint32_t v = L.hlist[k][lane];
-        res.add((int)(v >> 30), v & LOC_MASK);
+    const uint32_t hc = active ? L.hcnt[lane] : 0u;
+    const uint32_t nc = hc & ~FW::HCNT_OVERFLOW;
+    if constexpr (RPW == 64) {
+        // main launch: one lane per row folds its (short) list into minimum + distinct pattern ids in registers
+        LaneResult<E, KS> res;
+        res.init();
+        const uint32_t lim = nc < CAP ? nc : CAP;
+        for (uint32_t k = 0; k < lim; k++) {
+            const uint32_t v = W_.hl(k, (uint32_t)lane);
+            res.add((int)(v >> 30), v & LOC_MASK);
+        }
+        res.store(active, r, (hc & FW::HCNT_OVERFLOW) != 0u, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.slot_off, a.list_defer,
+                  a.defer_count, a.slot_cursor, a.slot_tag);
+    } else {
+        // Retry launch: lists of up to CAP entries per row (hundreds of ties at a few million barcodes and two edits) are
+        // folded by the whole wave, row after row, in LDS: entries that are not at the row's minimum are struck, then every entry
+        // that has an equal one before it, then every remaining entry counts the smaller ones — its place in the sorted,
+        // duplicate-free list.  The lists go to the slot array at (row's share of) a block reserved with one atomic per wave.
+        constexpr int PER = (int)((CAP + 63) / 64);
+        constexpr uint32_t SENT = 0xFFFFFFFFu;
+        const bool ovf = (hc & FW::HCNT_OVERFLOW) != 0u;
+        const uint32_t n_own = (active && !ovf) ? (nc < CAP ? nc : CAP) : 0u;
+        // pass A, row after row: strike what is not at the row's minimum, strike duplicates, count what is left
+        uint32_t my_cnt = 0;
+        for (int row = 0; row < RPW; row++) {
+            const uint32_t n = __builtin_amdgcn_readlane(n_own, row);
+            if (n == 0) continue;
+            const uint32_t best = L.best[row];
+            uint32_t val[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const uint32_t idx = (uint32_t)lane + 64u * (uint32_t)i;
+                uint32_t x = SENT;
+                if (idx < n) {
+                    const uint32_t e = W_.hl(idx, (uint32_t)row);
+                    x = (e >> 30) == best ? (e & LOC_MASK) : SENT;
+                    W_.hl(idx, (uint32_t)row) = x;
+                }
+                val[i] = x;
+            }
+            __builtin_amdgcn_wave_barrier();
+            bool dup[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) dup[i] = false;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t y = W_.hl(j, (uint32_t)row);  // the same address for every lane: one broadcast read
+#pragma unroll
+                for (int i = 0; i < PER; i++) dup[i] |= (y == val[i]) && (j < (uint32_t)lane + 64u * (uint32_t)i);
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t mine = 0;
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const uint32_t idx = (uint32_t)lane + 64u * (uint32_t)i;
+                if (val[i] != SENT) {
+                    if (dup[i]) W_.hl(idx, (uint32_t)row) = SENT;
+                    else mine++;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+            if (lane == row) my_cnt = mine;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // room in the slot array for exactly what the wave's rows hold: one atomic per wave
+        uint32_t inc = my_cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        const uint32_t total = __shfl(inc, 63, 64);
+        unsigned long long base = 0;
+        if (lane == 0 && total) base = atomicAdd(a.slot_cursor, (unsigned long long)total);
+        base = __shfl(base, 0, 64);
+        const bool no_room = base + total > a.slots_cap;  // wave-uniform
+        if (active && (ovf || no_room)) {
+            a.list_defer[atomicAdd(a.defer_count, 1u)] = (int32_t)r;
+            a.cnt[r] = CNT_DEFER;
+        }
+        const uint32_t start_own = inc - my_cnt;
+        // pass B: every entry that is left counts the smaller ones — its place in the row's sorted list
+        for (int row = 0; row < RPW && !no_room; row++) {
+            const uint32_t n = __builtin_amdgcn_readlane(n_own, row);
+            if (n == 0 || __builtin_amdgcn_readlane(my_cnt, row) == 0) continue;
+            const unsigned long long start = base + __builtin_amdgcn_readlane(start_own, row);
+            uint32_t val[PER], rank[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const uint32_t idx = (uint32_t)lane + 64u * (uint32_t)i;
+                val[i] = idx < n ? W_.hl(idx, (uint32_t)row) : SENT;
+                rank[i] = 0;
+            }
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t y = W_.hl(j, (uint32_t)row);
+#pragma unroll
+                for (int i = 0; i < PER; i++) rank[i] += (y < val[i]) ? 1u : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < PER; i++)
+                if (val[i] != SENT) a.slots[start + rank[i]] = val[i];
+        }
+        if (active && !ovf && !no_room) {
+            a.cnt[r] = my_cnt;
+            a.min_e[r] = my_cnt ? (uint8_t)L.best[lane] : (uint8_t)SCT_NO_HIT;
+            if (my_cnt) a.slot_off[r] = (base + start_own) | a.slot_tag;
+            if (a.cnt8) {
+                a.cnt8[r] = (uint8_t)(my_cnt < 255u ? my_cnt : 255u);
+                if (my_cnt > 255u) atomicOr(&a.ctr[CTR_CNT_OVERFLOW], 1u);
+            }
+        }
     }
-    res.store(active, r, nc > (uint32_t)HM, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.slot_off, a.list_defer, a.defer_count, a.slot_cursor,
-              a.slot_tag);
 }
 
 // RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows, so that the pair compaction of

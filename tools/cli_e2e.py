@@ -39,7 +39,7 @@ def write_lr_file(path, segs, offs):
     return len(data)
 
 
-def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_rows=20000, quiet=False):
+def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_rows=20000, quiet=False, extra=()):
     """-> dict with the CLI's wall time over n rows x 25 k barcodes (gz TSV in, gz TSV out) and the sample check."""
     import bench
     os.makedirs(work, exist_ok=True)
@@ -59,7 +59,7 @@ def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_
     walls = []
     for _ in range(2):          # the second run has the input file and the libraries in the page cache
         t0 = time.time()
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", lr, "-sr", sr, "-mr", "2", "-t", "16", "-o", out],
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", lr, "-sr", sr, "-mr", "2", "-t", "16", "-o", out] + list(extra),
                               stderr=open(os.path.join(work, "cli.err"), "w"))
         walls.append(time.time() - t0)
     wall = min(walls)
@@ -88,4 +88,4 @@ def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/sct_e2e"
-    print(json.dumps(run(n, work)), flush=True)
+    print(json.dumps(run(n, work, extra=sys.argv[3:])), flush=True)
