@@ -92,8 +92,8 @@ void sct_free_hits(sct_ctx *ctx, uint32_t *hits);
  * The same seam for callers that care about the PCIe link: compact transfer formats and a pipelined engine.  The rows
  * are cut into chunks (option "chunk_rows") that move through several streams (option "lanes"), so that the upload of chunk
  * k+1, the kernels of chunk k and the download of chunk k-1 overlap; sct_match above is this call with 64-bit offsets
- * both ways.  Give it page-locked buffers (sct_host_alloc) for segs / index / min_e / counts: copies from or to
- * pageable memory are staged by the runtime, block the calling thread and defeat the overlap (the results are the same).
+ * both ways.  Page-locked buffers (sct_host_alloc) for segs / index / min_e / counts are read and written in place by the
+ * kernels; pageable ones are page-locked for the duration of the call when they are large (option "register"), else copied.
  *   segs, seg_bytes   the reference's lr_segs (scTagger.py:616-627) and its size
  *   index             where each row lies in segs, in one of four forms (index_format):
  *       SCT_IDX_OFFS64  int64 offs[n+1]   CSR offsets, offs[0] == 0, offs[n] == seg_bytes
@@ -155,7 +155,10 @@ int sct_sync(sct_ctx *ctx);
  *                            memory, 2^24 when it is pageable (staged copies do not overlap with anything)
  *   "lanes"            1..8  chunks of a stream call in flight at once, each on a stream of its own (default 5)
  *   "zero_copy"        0|1   1 (default): sct_match_stream's kernels read page-locked segs / index buffers in place over the
- *                            host link; 0: they are uploaded first (pageable buffers always are)
+ *                            host link; 0: they are uploaded first
+ *   "register"         0|1   1 (default): pageable segs / index / min_e / counts buffers of a stream call of at least 4 MB of
+ *                            segments are page-locked for the duration of the call (hipHostRegister) and then read and
+ *                            written in place as well; 0: they go through staged copies
  */
 int sct_set_option(sct_ctx *ctx, const char *key, int64_t value);
 

@@ -230,6 +230,39 @@ def test_many_ties_defer_to_the_scan_path(m):
     assert m.last_stats()["exhaustive"] >= 1
 
 
+def test_hundreds_of_ties_are_folded_by_the_retry_launch(m):
+    """70 and 150 barcodes two substitutions away from a planted core (far more than the main launch's 8 list entries and than
+    round 1's 32 register slots): the retry launch folds lists of up to 320 entries per row in LDS, the exhaustive scan is not
+    needed; with 330 the list overflows and the scan takes the row.  Checked through pageable and page-locked buffers."""
+    core = synth.make_barcodes(1, seed=64)[0]
+    for n_near, scanned in ((70, 0), (150, 0), (330, 1)):
+        bc = synth.make_barcodes(60_000, seed=65)         # plain tables (no bucket slots): the replacing hit lists
+        k = 0
+        for pos in range(2, 14):                           # inner positions: no shift against the flanks saves an edit
+            for pos2 in range(pos + 1, 14):
+                for alt in range(9):
+                    if k >= n_near:
+                        break
+                    b = core.copy()                        # two substitutions: all at distance 2 from the core
+                    b[pos] = ord("ACGT"[("ACGT".index(chr(b[pos])) + 1 + alt % 3) % 4])
+                    b[pos2] = ord("ACGT"[("ACGT".index(chr(b[pos2])) + 1 + alt // 3) % 4])
+                    bc[1000 + k] = b
+                    k += 1
+        assert k == n_near
+        row = np.concatenate([np.frombuffer(b"TCT", np.uint8), core, np.frombuffer(b"GGA", np.uint8)])
+        base, bo = synth.make_segments(3000, bc, seed=66)
+        segs = np.concatenate([base, row, row])
+        offs = np.concatenate([bo, [bo[-1] + row.size, bo[-1] + 2 * row.size]]).astype(np.int64)
+        m.set_barcodes(bc)
+        want = trie_oracle.match(bc, segs, offs, 2, threads=1, workers=8)
+        assert want[0][-1] == 2 and np.diff(want[1])[-1] >= n_near
+        got = m.match(segs, offs, 2, 1)
+        util.assert_same(got, want, "%d ties" % n_near)
+        st = m.last_stats()
+        assert st["retried"] >= 2 and (st["exhaustive"] >= 2 if scanned else st["exhaustive"] == 0), st
+        check_zero_copy(m, segs, offs, 2, 1, want)
+
+
 def test_moderate_ties_are_retried_not_scanned(m):
     """9..32 ties: handled by the filter's retry launch (larger lists), not by the exhaustive scan."""
     rng = np.random.default_rng(6)
