@@ -61,8 +61,9 @@ def check_stream_variants(m, segs, offs, e, t, want, chunk_rows=None):
         m.set_option("chunk_rows", 0)
 
 
-def pinned_copy(m, a):
-    p = m.host_array(max(a.size, 1), a.dtype)[:a.size]
+def pinned_copy(m, a, skew=0):
+    """`a` in page-locked memory; skew > 0: starting `skew` elements into the allocation (an address that is not 16-byte aligned)"""
+    p = m.host_array(max(a.size, 1) + skew, a.dtype)[skew:skew + a.size]
     p[:] = a
     return p
 
@@ -84,8 +85,11 @@ def check_zero_copy(m, segs, offs, e, t, want, chunk_rows=0):
         for ifmt, index in idx:
             pidx = pinned_copy(m, index)
             for cfmt in (_native.CNT_U8, _native.CNT_U32, _native.CNT_OFFS64):
-                pme = m.host_array(max(n, 1), np.uint8)
-                pcnt = m.host_array(n + 1, _native._CNT_DTYPE[cfmt])
+                skew = (ifmt + cfmt) % 3                        # some runs on buffers that start at odd addresses
+                if skew:
+                    psegs, pidx = pinned_copy(m, segs, skew), pinned_copy(m, index, skew)
+                pme = m.host_array(max(n, 1) + skew, np.uint8)[skew:]
+                pcnt = m.host_array(n + 1 + skew, _native._CNT_DTYPE[cfmt])[skew:]
                 pme[:] = 7            # stale contents must not survive
                 pcnt[:] = 9
                 if cfmt == _native.CNT_U8 and max_cnt > 255:
