@@ -253,8 +253,7 @@ struct FilterWave {
             // list is enough and 4 % faster at 25 k barcodes (3.16 vs 3.28 ms per 10 M rows)
             atomicMin(&L.best[src], d);
             const uint32_t k = atomicAdd(&L.hcnt[src], 1u);
-            if (k < (uint32_t)CAP) hl(k, src) = (d << 30) | loc;
-            else atomicOr(&L.hcnt[src], HCNT_OVERFLOW);
+            if (k < (uint32_t)CAP) hl(k, src) = (d << 30) | loc;   // (a count beyond CAP is the overflow mark of this variant)
             return;
         }
         const uint32_t before = atomicMin(&L.best[src], d);
@@ -816,7 +815,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
             const uint32_t v = W_.hl(k, (uint32_t)lane);
             res.add((int)(v >> 30), v & LOC_MASK);
         }
-        res.store(active, r, (hc & FW::HCNT_OVERFLOW) != 0u, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.slot_off, a.list_defer,
+        res.store(active, r, (hc & FW::HCNT_OVERFLOW) != 0u || nc > CAP, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.slot_off, a.list_defer,
                   a.defer_count, a.slot_cursor, a.slot_tag);
     } else {
         // Retry launch: lists of up to CAP entries per row (hundreds of ties at a few million barcodes and two edits) are
@@ -825,7 +824,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         // duplicate-free list.  The lists go to the slot array at (row's share of) a block reserved with one atomic per wave.
         constexpr int PER = (int)((CAP + 63) / 64);
         constexpr uint32_t SENT = 0xFFFFFFFFu;
-        const bool ovf = (hc & FW::HCNT_OVERFLOW) != 0u;
+        const bool ovf = (hc & FW::HCNT_OVERFLOW) != 0u || (SL && nc > CAP);
         const uint32_t n_own = (active && !ovf) ? (nc < CAP ? nc : CAP) : 0u;
         // pass A, row after row: strike what is not at the row's minimum, strike duplicates, count what is left
         uint32_t my_cnt = 0;
