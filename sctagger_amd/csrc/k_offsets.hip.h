@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, 
                                                const uint32_t *__restrict__ slots_retry,
                                                const uint64_t *__restrict__ slot_off, const int64_t *__restrict__ hit_offs,
                                                const uint32_t *__restrict__ route_cnt, int64_t n, uint32_t *__restrict__ hits,
-                                               uint64_t hits_cap, const uint32_t *__restrict__ ctr) {
+                                               uint64_t hits_cap, const uint32_t *__restrict__ ctr, uint16_t *__restrict__ hits16) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     // more hits than `hits` can take (only possible when it is the caller-visible page-locked buffer, sized by an estimate):
@@ -167,7 +167,12 @@ __global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, 
     const uint64_t so = slot_off[r];
     const uint32_t *src = (so & SLOT_TAG_RETRY) ? slots_retry : slots;
     const uint64_t at = so & ~SLOT_TAG_RETRY;
-    for (uint32_t i = 0; i < c; i++) hits[o + i] = src[at + i];
+    // hits16 != NULL: the caller takes 16-bit hits and no row needs the scan kernels' 32-bit array: straight into the result buffer
+    if (hits16) {
+        for (uint32_t i = 0; i < c; i++) hits16[o + i] = (uint16_t)src[at + i];
+    } else {
+        for (uint32_t i = 0; i < c; i++) hits[o + i] = src[at + i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -149,6 +149,7 @@ struct Lane {
     uint32_t *cnt32_ptr = nullptr;
     uint32_t *hits_ptr = nullptr;
     uint64_t hits_cap = 0;      // entries hits_ptr can take
+    uint16_t *hits16_ptr = nullptr;  // 16-bit hits of a one-chunk stream call: the fill kernel writes them itself (hits_cap = their room)
     bool direct_min_e = false, direct_cnt = false, direct_hits = false;
     BatchParams bp;
     int64_t n_hits = 0;
@@ -535,6 +536,7 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
     l.cnt32_ptr = bp.count_format == SCT_CNT_U32 ? l.cnt_out.as<uint32_t>() : nullptr;
     l.hits_ptr = l.hits.as<uint32_t>();
     l.hits_cap = l.hits.cap / 4;
+    l.hits16_ptr = nullptr;
     l.direct_min_e = l.direct_cnt = l.direct_hits = false;
     return SCT_OK;
 }
@@ -663,7 +665,7 @@ static int queue_batch(sct_ctx *c, Lane &l) {
         Timer t(c, l, "k_fill");
         k_fill<<<blocks_for(n, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
                                                    l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(), n, l.hits_ptr,
-                                                   l.hits_cap, l.ctr());
+                                                   l.hits_cap, l.ctr(), l.hits16_ptr);
     }
     HIPCHK(hipMemcpyAsync(l.h_ctr, l.counters.p, sizeof(uint32_t) * CTR_WORDS, hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
@@ -681,6 +683,11 @@ static int slow_path(sct_ctx *c, Lane &l) {
     hipStream_t st = l.stream;
     uint32_t *ctr = l.ctr();
     uint32_t *h = l.h_ctr;
+    if (l.hits16_ptr) {  // the scan kernels write 32-bit hits: back to the lane's own array (narrowed afterwards)
+        l.hits16_ptr = nullptr;
+        l.hits_ptr = l.hits.as<uint32_t>();
+        l.hits_cap = l.hits.cap / 4;
+    }
     if (l.host_segs) {
         // a zero-copy batch: the scan kernels read every listed row once per barcode slice — bring the bytes to the device first
         if (l.segs.ensure((size_t)l.seg_bytes + 64)) return SCT_E_HIP;
@@ -774,7 +781,7 @@ static int slow_path(sct_ctx *c, Lane &l) {
             Timer t(c, l, "k_fill");
             k_fill<<<blocks_for(n, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
                                                        l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.route.as<uint32_t>(), n,
-                                                       l.hits_ptr, l.hits_cap, l.ctr());
+                                                       l.hits_ptr, l.hits_cap, l.ctr(), nullptr);
         }
         if (n_scan) {
             Timer t(c, l, "k_scan_fill");
@@ -828,7 +835,7 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
         if (l.bp.filter_ok && l.n_seg > 0)
             k_fill<<<blocks_for(l.n_seg, 256), 256, 0, l.stream>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
                                                                    l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(),
-                                                                   l.n_seg, l.hits_ptr, l.hits_cap, l.ctr());
+                                                                   l.n_seg, l.hits_ptr, l.hits_cap, l.ctr(), nullptr);
         HIPCHK(hipStreamSynchronize(l.stream));
         HIPCHK(hipGetLastError());
     }
@@ -1131,6 +1138,11 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
             l.hits_cap = c->h_hits_cap;
             l.direct_hits = true;
         }
+        if (hits16 && n_chunks == 1) {   // the only chunk: its hits start at 0, the fill kernel can write them narrowed
+            l.hits16_ptr = zc_hits16;
+            l.hits_cap = 2 * (uint64_t)c->h_hits_cap;
+            cp.narrow_cap = l.hits_cap;
+        }
         if (l.offs32.ensure(4 * (size_t)(m + 1))) return SCT_E_HIP;
         if (!zc_segs && l.segs.ensure((size_t)bytes + 64)) return SCT_E_HIP;
         if ((!zc_index || !by_offs) && l.index_in.ensure(isz * (size_t)(m + 1) + 16)) return SCT_E_HIP;
@@ -1177,12 +1189,6 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
             }
         }
         if (int rc = queue_batch(c, l)) return rc;
-        if (hits16 && n_chunks == 1) {   // the only chunk: its hits start at 0, no need to wait for anything
-            Timer t(c, l, "k_narrow_hits");
-            const uint64_t cap16 = 2 * (uint64_t)c->h_hits_cap;
-            cp.narrow_cap = cap16;
-            k_narrow_hits<<<blocks_for((int64_t)(l.slots_cap + l.retry_cap + 1), 2048), 256, 0, st>>>(l.hits.as<uint32_t>(), l.ctr(), cap16, zc_hits16);
-        }
         if (!l.direct_min_e || (!l.direct_cnt && count_format != SCT_CNT_OFFS64)) {
             Timer t(c, l, "copy_d2h");
             if (!l.direct_min_e) HIPCHK(hipMemcpyAsync(min_e + cp.r0, l.min_e.p, (size_t)m, hipMemcpyDeviceToHost, st));
@@ -1225,9 +1231,18 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
             }
             if (hits16) {
                 // (the buffer was sized for uint32 entries: twice what the narrowed lists need)
-                if (l.n_hits && (n_chunks > 1 || slow || (uint64_t)l.n_hits > cp.narrow_cap))
+                if (l.n_hits && (n_chunks > 1 || slow || (uint64_t)l.n_hits > cp.narrow_cap)) {
+                    if (l.hits16_ptr && !slow) {
+                        // the fill kernel found the result buffer too small and wrote nothing: fill the 32-bit array on the device first
+                        if (l.hits.ensure(4 * (size_t)(l.n_hits + 1))) return SCT_E_HIP;
+                        k_fill<<<blocks_for(m, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
+                                                                   l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(), m,
+                                                                   l.hits.as<uint32_t>(), l.hits.cap / 4, l.ctr(), nullptr);
+                        l.hits_ptr = l.hits.as<uint32_t>();
+                    }
                     k_narrow_hits<<<blocks_for(l.n_hits, 2048), 256, 0, st>>>(l.hits_ptr, l.ctr(), ~0ull,
                                                                               (uint16_t *)device_view(c->h_hits, true) + hit_base);
+                }
             } else if (l.n_hits && !l.direct_hits) {
                 HIPCHK(hipMemcpyAsync(c->h_hits + hit_base, l.hits_ptr, 4 * (size_t)l.n_hits, hipMemcpyDeviceToHost, st));
             }
