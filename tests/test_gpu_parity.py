@@ -267,6 +267,39 @@ def test_hundreds_of_ties_are_folded_by_the_retry_launch(m):
         check_zero_copy(m, segs, offs, 2, 1, want)
 
 
+def test_result_buffer_grows_when_the_estimate_is_too_small():
+    """8 000 rows with 72 hits each: far more hits than the page-locked result buffer of a fresh context holds (sized by an
+    estimate of 1.25 per row).  The fill kernels notice, write nothing, the host enlarges the buffer and fills again — for
+    32-bit hits written in place, for 16-bit hits, and over several chunks."""
+    core = synth.make_barcodes(1, seed=64)[0]
+    bc = synth.make_barcodes(20_000, seed=67)
+    k = 0
+    for pos in range(3, 12):                               # inner positions: two substitutions there cannot be had for one indel
+        for pos2 in range(pos + 1, 12):
+            for alt in (1, 2):
+                b = core.copy()
+                b[pos] = ord("ACGT"[("ACGT".index(chr(b[pos])) + alt) % 4])
+                b[pos2] = ord("ACGT"[("ACGT".index(chr(b[pos2])) + alt) % 4])
+                bc[500 + k] = b
+                k += 1
+    row = np.concatenate([np.frombuffer(b"TCT", np.uint8), core, np.frombuffer(b"GGA", np.uint8)])
+    n = 8000
+    segs = np.tile(row, n)
+    offs = 22 * np.arange(n + 1, dtype=np.int64)
+    want1 = trie_oracle.match(bc, segs[:22], offs[:2], 2, threads=1)
+    per = int(want1[1][1])
+    assert per >= 70 and want1[0][0] == 2
+    want_hits = np.tile(want1[2], n)
+    for hfmt, chunk in ((_native.HITS_U32, 0), (_native.HITS_U16, 0), (_native.HITS_U32, 3000), (_native.HITS_U16, 3000)):
+        with _native.Matcher(0) as fresh:                      # a fresh context: the result buffer starts at its minimum size
+            fresh.set_barcodes(bc)
+            fresh.set_option("chunk_rows", chunk)
+            psegs, plen = pinned_copy(fresh, segs), pinned_copy(fresh, np.full(n, 22, np.uint8))
+            me, cnt, hits = fresh.match_stream(psegs, plen, 2, 1, index_format=_native.IDX_LEN8, count_format=_native.CNT_U8,
+                                               min_e=fresh.host_array(n, np.uint8), counts=fresh.host_array(n, np.uint8), hits_format=hfmt)
+            assert (me == 2).all() and (cnt == per).all() and np.array_equal(hits.astype(np.uint32), want_hits), (hfmt, chunk)
+
+
 def test_moderate_ties_are_retried_not_scanned(m):
     """9..32 ties: handled by the filter's retry launch (larger lists), not by the exhaustive scan."""
     rng = np.random.default_rng(6)
