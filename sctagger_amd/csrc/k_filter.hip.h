@@ -15,7 +15,7 @@ __device__ __forceinline__ void store_byte_line(uint8_t *__restrict__ min_e, int
     const uint32_t w1 = __shfl_down(w, 4, 64), w2 = __shfl_down(w, 8, 64), w3 = __shfl_down(w, 12, 64);
     if ((lane & 15) == 0) {
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<u4 *>(min_e + r0 + lane) = u4{w, w1, w2, w3};
+        __builtin_nontemporal_store(u4{w, w1, w2, w3}, reinterpret_cast<u4 *>(min_e + r0 + lane));  // written once, read by nobody here: past the L2's tables
     }
 }
 
@@ -90,7 +90,7 @@ struct LaneResult {
             cnt[r] = CNT_DEFER;
             return;
         }
-        cnt[r] = mine;
+        __builtin_nontemporal_store(mine, &cnt[r]);
         if (mine == 0) {
             if (!line) min_e[r] = SCT_NO_HIT;
             return;
@@ -111,10 +111,10 @@ struct LaneResult {
         }
         if (!line) min_e[r] = (uint8_t)best;
         const uint64_t start = base + inc - mine;
-        slot_off[r] = start | slot_tag;
+        __builtin_nontemporal_store((uint64_t)(start | slot_tag), &slot_off[r]);
 #pragma unroll
         for (int i = 0; i < K_SLOTS; i++)
-            if (i < nh) slots[start + i] = h[i];
+            if (i < nh) __builtin_nontemporal_store(h[i], &slots[start + i]);
     }
 };
 

@@ -1,13 +1,21 @@
 #!/bin/bash
-# A few PMC passes over a short bench run. Usage: bash tools/pmc_quick.sh <tag> [bench args]
+# FETCH_SIZE / WRITE_SIZE / L2 hit rate of the resident loop's dominant kernel, and its time. Usage: bash tools/pmc_quick.sh <tag>
 set -o pipefail
-tag=$1; shift
-out=gpurun_out/prof_$tag; mkdir -p $out
+tag=${1:-q}; out=gpurun_out/pmcq_$tag; mkdir -p $out
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-/root/repo}
-for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
-  name=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  echo "== pmc $pass" >> $R/$out/progress.log
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/$out/pmc_$name -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $R/$out/pmc_$name.json 2> $R/$out/pmc_$name.err || { tail -5 $R/$out/pmc_$name.err; echo "(pass failed)"; }
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  name=$(echo $pass | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/$out/pmc_$name -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --mode resident --no-cpu-baseline --no-cli > $R/$out/pmc_$name.json 2> $R/$out/pmc_$name.err || tail -3 $R/$out/pmc_$name.err
 done
-echo done
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$R/$out/pmc_*/*counter_collection.csv"):
+    for row in csv.DictReader(open(f)):
+        if "k_filter<2, unsigned int, false, 6, 6, 64" in row["Kernel_Name"]:
+            agg["main"][row["Counter_Name"]].append(float(row["Counter_Value"]))
+c = {k: sum(v) / len(v) for k, v in agg["main"].items()}
+print("FETCH MB %.0f  WRITE MB %.0f  L2 hit %.4f" % (c.get("FETCH_SIZE", 0) * 1024 / 1e6, c.get("WRITE_SIZE", 0) * 1024 / 1e6, c.get("TCC_HIT_sum", 0) / max(1, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))))
+PY
+python3 $R/bench.py --steps 20 --warmup 5 --mode resident --no-cpu-baseline --no-cli | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('resident ms', d['ms_per_step'], d['kernels_ms'])"
