@@ -66,7 +66,8 @@ __device__ __forceinline__ void sct_decode_row(const uint8_t *__restrict__ segs,
     // the word containing byte `start` of the buffer: aligned by ADDRESS (the buffer itself may start anywhere), so a word
     // that holds one byte of the buffer never leaves that byte's page
     const uintptr_t at = (uintptr_t)segs + (uintptr_t)start;
-    const uint32_t *wp = reinterpret_cast<const uint32_t *>(at & ~(uintptr_t)3);
+    // (an address computed as an integer loses its address space: say "global" again, or the loads are issued as flat ones)
+    const __attribute__((address_space(1))) uint32_t *wp = (const __attribute__((address_space(1))) uint32_t *)(at & ~(uintptr_t)3);
     sct_decode_words<W>([&](int k) { return __builtin_nontemporal_load(wp + k); }, (int)(at & 3), len, lo, hi, nonacgt);
 }
 
@@ -98,7 +99,7 @@ __device__ __forceinline__ bool sct_decode_rows_staged(const uint8_t *__restrict
     const uint64_t nbytes = smax - base;
     if (nbytes > (uint64_t)stage_bytes) return false;
     const int n16 = (int)((nbytes + 15) >> 4);
-    const sct_u4 *src = reinterpret_cast<const sct_u4 *>((uintptr_t)base);
+    const __attribute__((address_space(1))) sct_u4 *src = (const __attribute__((address_space(1))) sct_u4 *)(uintptr_t)base;
     for (int i = lane; i < n16; i += 64) {
         const sct_u4 v = __builtin_nontemporal_load(src + i);
         *reinterpret_cast<sct_u4 *>(stage + 4 * i) = v;
