@@ -58,11 +58,13 @@ struct LaneResult {
     // (store_byte_line; lanes without a result of their own contribute SCT_NO_HIT)
     // cnt8 != NULL: the caller's one-byte counts are written here as well (a list never holds more than K_SLOTS entries; rows
     // without a result of their own get 0 until the launch or the slow path that owns them writes theirs)
+    // The wave's lists lie back to back from `base` in row order, so ONE 8-byte word per wave (wave_base[first / 64]) tells
+    // k_fill where they are: row r's list starts `sum of the counts of the wave's earlier rows` behind it (round 1 wrote an
+    // 8-byte offset per row: 80 MB per 10 M rows out and in again).
     __device__ __forceinline__ void store(bool row, int64_t r, bool overflow, bool line, uint8_t *__restrict__ min_e, uint8_t *__restrict__ cnt8,
                                           uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots, uint64_t slots_cap,
-                                          uint64_t *__restrict__ slot_off, int32_t *__restrict__ list_defer,
-                                          uint32_t *__restrict__ defer_count, unsigned long long *__restrict__ slot_cursor,
-                                          uint64_t slot_tag) {
+                                          uint64_t *__restrict__ wave_base, int64_t first, int32_t *__restrict__ list_defer,
+                                          uint32_t *__restrict__ defer_count, unsigned long long *__restrict__ slot_cursor) {
         const int lane = threadIdx.x & 63;
         bool defer = row && (overflow || nh > K_SLOTS);
         const uint32_t mine = (row && !defer) ? (uint32_t)nh : 0u;
@@ -77,6 +79,7 @@ struct LaneResult {
         if (lane == 0 && total) base = atomicAdd(slot_cursor, (unsigned long long)total);
         base = __shfl(base, 0, 64);
         if (base + total > slots_cap) defer = row;  // wave-uniform: no room for this wave's lists
+        if (lane == 0) __builtin_nontemporal_store((uint64_t)base, &wave_base[first >> 6]);
         if (line) {
             store_byte_line(min_e, r - lane, (row && !defer && mine) ? (uint32_t)best : (uint32_t)SCT_NO_HIT);
             if (cnt8) store_byte_line(cnt8, r - lane, (row && !defer) ? mine : 0u);
@@ -111,7 +114,6 @@ struct LaneResult {
         }
         if (!line) min_e[r] = (uint8_t)best;
         const uint64_t start = base + inc - mine;
-        __builtin_nontemporal_store((uint64_t)(start | slot_tag), &slot_off[r]);
 #pragma unroll
         for (int i = 0; i < K_SLOTS; i++)
             if (i < nh) __builtin_nontemporal_store(h[i], &slots[start + i]);
@@ -150,7 +152,6 @@ struct QueueCap {
 static constexpr int HMAX = 8, HMAX_SL = 6;  // main launch
 static constexpr int K_RETRY = 32, H_RETRY = 80;  // retry launch: 80 x 256 B of LDS hold 320 hit-list entries for each of a wave's 16 rows
 static constexpr int H_RETRY_SL = H_RETRY;
-static constexpr uint64_t SLOT_TAG_RETRY = 1ull << 63;  // slot_off values that point into the retry launch's slot buffer
 static constexpr uint32_t LOC_MASK = (1u << 30) - 1u;    // locator in a hit-list entry (2 bits of distance above it)
 static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline slot entry (entry indices stay below it)
 
@@ -654,13 +655,13 @@ struct FilterArgs {
     uint32_t *cnt;
     uint32_t *slots;
     uint64_t slots_cap;
-    uint64_t *slot_off;
+    uint64_t *slot_off;           // retry launch: where each of its rows' lists starts in `slots`
+    uint64_t *wave_base;          // main launch: where each wave's lists start in `slots`
     int32_t *list_defer;          // main launch: list_retry; retry launch: list_scan
     uint32_t *defer_count;
     int32_t *list_long, *list_dp; // routing lists of the main launch (rows the filter cannot take)
     uint32_t *ctr;                // the batch's counter record (CTR_*)
     unsigned long long *slot_cursor;
-    uint64_t slot_tag;
     int bl, prefix_len;
 };
 
@@ -815,8 +816,8 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
             const uint32_t v = W_.hl(k, (uint32_t)lane);
             res.add((int)(v >> 30), v & LOC_MASK);
         }
-        res.store(active, r, (hc & FW::HCNT_OVERFLOW) != 0u || nc > CAP, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.slot_off, a.list_defer,
-                  a.defer_count, a.slot_cursor, a.slot_tag);
+        res.store(active, r, (hc & FW::HCNT_OVERFLOW) != 0u || nc > CAP, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.wave_base, first,
+                  a.list_defer, a.defer_count, a.slot_cursor);
     } else {
         // Retry launch: lists of up to CAP entries per row (hundreds of ties at a few million barcodes and two edits) are
         // folded by the whole wave, row after row, in LDS: entries that are not at the row's minimum are struck, then every entry
@@ -907,9 +908,9 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
                 if (val[i] != SENT) a.slots[start + rank[i]] = val[i];
         }
         if (active && !ovf && !no_room) {
-            a.cnt[r] = my_cnt;
+            a.cnt[r] = my_cnt | CNT_RETRIED;
             a.min_e[r] = my_cnt ? (uint8_t)L.best[lane] : (uint8_t)SCT_NO_HIT;
-            if (my_cnt) a.slot_off[r] = (base + start_own) | a.slot_tag;
+            if (my_cnt) a.slot_off[r] = base + start_own;
             if (a.cnt8) {
                 a.cnt8[r] = (uint8_t)(my_cnt < 255u ? my_cnt : 255u);
                 if (my_cnt > 255u) atomicOr(&a.ctr[CTR_CNT_OVERFLOW], 1u);

@@ -33,7 +33,7 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *t
 template <typename T>
 __device__ __forceinline__ uint64_t scan_value(T v) { return (uint64_t)v; }
 template <>
-__device__ __forceinline__ uint64_t scan_value<uint32_t>(uint32_t v) { return v == CNT_DEFER ? 0ull : (uint64_t)v; }
+__device__ __forceinline__ uint64_t scan_value<uint32_t>(uint32_t v) { return v == CNT_DEFER ? 0ull : (uint64_t)(v & CNT_MASK); }
 
 // a thread's SCAN_ITEMS consecutive items; one- and two-byte items (row lengths, possibly read in place from page-locked
 // host memory) come as ONE 8- or 16-byte load when the address allows it
@@ -149,29 +149,40 @@ __global__ void __launch_bounds__(256) k_rebase(int64_t *__restrict__ hit_offs, 
     if (i < n1) hit_offs[i] += base;
 }
 
-// filter path: slots -> CSR
+// filter path: slots -> CSR.  One lane per row, the 64 rows of a wave are the 64 rows of one wave of the main filter launch:
+// their lists lie back to back from wave_base[r / 64], so a row's list starts behind the counts of the wave's earlier rows
+// that the main launch stored itself (not deferred: neither retried nor left to the scan kernels).  Rows finished by the
+// retry launch (CNT_RETRIED) have their own offset in slot_off.
 __global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ slots,
-                                               const uint32_t *__restrict__ slots_retry,
+                                               const uint32_t *__restrict__ slots_retry, const uint64_t *__restrict__ wave_base,
                                                const uint64_t *__restrict__ slot_off, const int64_t *__restrict__ hit_offs,
                                                const uint32_t *__restrict__ route_cnt, int64_t n, uint32_t *__restrict__ hits,
                                                uint64_t hits_cap, const uint32_t *__restrict__ ctr, uint16_t *__restrict__ hits16) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+    const int lane = threadIdx.x & 63;
+    const bool in = r < n;
+    const uint32_t raw = in ? cnt[r] : 0u;
+    const bool deferred = in && route_cnt[r] == CNT_DEFER;  // written by the scan path's fill pass
+    const bool retried = !deferred && raw != CNT_DEFER && (raw & CNT_RETRIED) != 0u;
+    const uint32_t c = (deferred || raw == CNT_DEFER) ? 0u : (raw & CNT_MASK);
+    uint32_t before = retried ? 0u : c;   // inclusive scan of the counts the main launch stored
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(before, o, 64);
+        if (lane >= o) before += t;
+    }
+    before -= retried ? 0u : c;
     // more hits than `hits` can take (only possible when it is the caller-visible page-locked buffer, sized by an estimate):
     // nothing is written; the host sees the total, enlarges the buffer and fills again
     if (*reinterpret_cast<const uint64_t *>(ctr + CTR_TOTAL) > hits_cap) return;
-    if (route_cnt[r] == CNT_DEFER) return;  // written by the scan path's fill pass
-    const uint32_t c = cnt[r];
-    const int64_t o = hit_offs[r];
     if (c == 0) return;
-    const uint64_t so = slot_off[r];
-    const uint32_t *src = (so & SLOT_TAG_RETRY) ? slots_retry : slots;
-    const uint64_t at = so & ~SLOT_TAG_RETRY;
+    const int64_t o = hit_offs[r];
+    const uint32_t *src = retried ? slots_retry + slot_off[r] : slots + (wave_base[r >> 6] + before);
     // hits16 != NULL: the caller takes 16-bit hits and no row needs the scan kernels' 32-bit array: straight into the result buffer
     if (hits16) {
-        for (uint32_t i = 0; i < c; i++) hits16[o + i] = (uint16_t)src[at + i];
+        for (uint32_t i = 0; i < c; i++) hits16[o + i] = (uint16_t)src[i];
     } else {
-        for (uint32_t i = 0; i < c; i++) hits[o + i] = src[at + i];
+        for (uint32_t i = 0; i < c; i++) hits[o + i] = src[i];
     }
 }
 

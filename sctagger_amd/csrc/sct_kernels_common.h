@@ -4,6 +4,8 @@
 #pragma once
 static constexpr int K_SLOTS = 8;          // hits kept per segment by the filter kernel before it defers
 static constexpr uint32_t CNT_DEFER = 0xFFFFFFFFu;
+static constexpr uint32_t CNT_RETRIED = 0x80000000u;  // flag in cnt[r]: the row's list lies in the retry launch's slots (at slot_off[r])
+static constexpr uint32_t CNT_MASK = 0x7FFFFFFFu;
 // The bucket slots pay while nearly every lookup is answered inline; with many long buckets the plain offset / code
 // tables are faster.  Measured per 2 M segments, slots off / on (tools/sweep_slots.sh): e <= 2: 25 k barcodes (0.8 % of the
 // keys long) 0.98 / 0.73 ms, 35 k (2.4 %) 1.09 / 0.97, 50 k (7 %) 1.27 / 1.55, 100 k (35 %) 2.01 / 5.09;

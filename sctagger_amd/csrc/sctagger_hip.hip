@@ -139,7 +139,7 @@ struct Lane {
     const char *host_segs = nullptr;    // zero-copy batches: the same bytes on the host (the slow path copies them to `segs`)
     DevBuf segs, offs64, offs32, index_in;
     // work / results
-    DevBuf min_e, cnt, route, slots, slots_retry, list_retry, slot_off, list_long, list_scan, list_dp, counters, hit_offs, sums, hits,
+    DevBuf min_e, cnt, route, slots, slots_retry, list_retry, slot_off, wave_base, list_long, list_scan, list_dp, counters, hit_offs, sums, hits,
         part_best, part_cnt, cnt_out;
     uint64_t slots_cap = 0, retry_cap = 0;
     // where the kernels write the results the caller sees: the lane's own buffers (copied out afterwards) or, for a stream
@@ -170,7 +170,7 @@ struct Lane {
     }
     uint32_t *ctr() const { return counters.as<uint32_t>(); }
     void release() {
-        DevBuf *bufs[] = {&segs, &offs64, &offs32, &index_in, &min_e, &cnt, &route, &slots, &slots_retry, &list_retry, &slot_off, &list_long,
+        DevBuf *bufs[] = {&segs, &offs64, &offs32, &index_in, &min_e, &cnt, &route, &slots, &slots_retry, &list_retry, &slot_off, &wave_base, &list_long,
                           &list_scan, &list_dp, &counters, &hit_offs, &sums, &hits, &part_best, &part_cnt, &cnt_out};
         for (DevBuf *b : bufs) b->release();
         for (hipEvent_t e : pool) (void)hipEventDestroy(e);
@@ -527,7 +527,8 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
         // array can therefore hold whatever the two launches produce (rows of the scan lists are sized by the slow path)
         l.slots_cap = (uint64_t)n1 * K_SLOTS;
         l.retry_cap = (uint64_t)n1 * K_SLOTS < 65536 ? 65536 : (uint64_t)n1 * K_SLOTS;
-        if (l.slots.ensure(4 * l.slots_cap) || l.slots_retry.ensure(4 * l.retry_cap) || l.slot_off.ensure(8 * n1) || l.list_retry.ensure(4 * n1))
+        if (l.slots.ensure(4 * l.slots_cap) || l.slots_retry.ensure(4 * l.retry_cap) || l.slot_off.ensure(8 * n1) || l.wave_base.ensure(8 * (n1 / 64 + 2)) ||
+            l.list_retry.ensure(4 * n1))
             return SCT_E_HIP;
     }
     if (l.hits.ensure(4 * (size_t)(l.slots_cap + l.retry_cap + 1))) return SCT_E_HIP;
@@ -574,6 +575,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.cnt8 = l.cnt8_ptr;  // the filter launches write the one-byte counts themselves (queue_batch leaves them out of k_offsets)
     fa.cnt = l.cnt.as<uint32_t>();
     fa.slot_off = l.slot_off.as<uint64_t>();
+    fa.wave_base = l.wave_base.as<uint64_t>();
     fa.list_long = l.list_long.as<int32_t>();
     fa.list_dp = l.list_dp.as<int32_t>();
     fa.ctr = ctr;
@@ -590,7 +592,6 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.list_defer = l.list_retry.as<int32_t>();
         fa.defer_count = ctr + CTR_RETRY;
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR);
-        fa.slot_tag = 0ull;
         launch_filter(bp.max_err, v, fa, blocks_for(n, 256), capped((n + 63) / 64), st);
     }
     {
@@ -607,7 +608,6 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.list_defer = l.list_scan.as<int32_t>();
         fa.defer_count = ctr + CTR_SCAN;
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR_RETRY);
-        fa.slot_tag = SLOT_TAG_RETRY;
         launch_filter(bp.max_err, v, fa, capped((n + 15) / 16), capped((n + 15) / 16), st);  // one wave of 16 rows per block
     }
 }
@@ -664,7 +664,7 @@ static int queue_batch(sct_ctx *c, Lane &l) {
     if (n > 0 && bp.filter_ok) {
         Timer t(c, l, "k_fill");
         k_fill<<<blocks_for(n, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
-                                                   l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(), n, l.hits_ptr,
+                                                   l.wave_base.as<uint64_t>(), l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(), n, l.hits_ptr,
                                                    l.hits_cap, l.ctr(), l.hits16_ptr);
     }
     HIPCHK(hipMemcpyAsync(l.h_ctr, l.counters.p, sizeof(uint32_t) * CTR_WORDS, hipMemcpyDeviceToHost, st));
@@ -780,7 +780,7 @@ static int slow_path(sct_ctx *c, Lane &l) {
         if (bp.filter_ok) {
             Timer t(c, l, "k_fill");
             k_fill<<<blocks_for(n, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
-                                                       l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.route.as<uint32_t>(), n,
+                                                       l.wave_base.as<uint64_t>(), l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.route.as<uint32_t>(), n,
                                                        l.hits_ptr, l.hits_cap, l.ctr(), nullptr);
         }
         if (n_scan) {
@@ -834,7 +834,7 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
         l.hits_cap = c->h_hits_cap;
         if (l.bp.filter_ok && l.n_seg > 0)
             k_fill<<<blocks_for(l.n_seg, 256), 256, 0, l.stream>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
-                                                                   l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(),
+                                                                   l.wave_base.as<uint64_t>(), l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(),
                                                                    l.n_seg, l.hits_ptr, l.hits_cap, l.ctr(), nullptr);
         HIPCHK(hipStreamSynchronize(l.stream));
         HIPCHK(hipGetLastError());
@@ -1236,7 +1236,7 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
                         // the fill kernel found the result buffer too small and wrote nothing: fill the 32-bit array on the device first
                         if (l.hits.ensure(4 * (size_t)(l.n_hits + 1))) return SCT_E_HIP;
                         k_fill<<<blocks_for(m, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
-                                                                   l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(), m,
+                                                                   l.wave_base.as<uint64_t>(), l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(), m,
                                                                    l.hits.as<uint32_t>(), l.hits.cap / 4, l.ctr(), nullptr);
                         l.hits_ptr = l.hits.as<uint32_t>();
                     }
