@@ -149,6 +149,9 @@ int sct_sync(sct_ctx *ctx);
  *   "force_exhaustive" 0|1   skip the seed-filter kernel and scan every barcode for every segment
  *   "timing"           0|1   record HIP events around each kernel of sct_run (default 1)
  *   "no_thirds"        0|1   1 = never use the 20/22-bit seed families chosen for >= 2^19 patterns at max_err <= 1
+ *   "wide"            -1|0|1 the sixteen 20-bit seed families of max_err = 2 (sct_core.h): -1 = built and used from 2^20 patterns
+ *                            (524 288 barcodes) on (default), 0 = not used, 1 = built whatever the size (takes effect at the
+ *                            next sct_set_barcodes) and used
  *   "slots"           -1|0|1 8-byte bucket slots of the 16-character seed tables: -1 = used while few keys hold more
  *                            than three barcodes (3.5 % at max_err 2, 10 % below; default), 0 = never, 1 = always
  *   "chunk_rows"       n     rows per chunk of sct_match_stream / sct_match; 0 (default) = 2^20 when segs is page-locked

@@ -5,6 +5,7 @@ struct SctFilterVariant {
     bool rt;      // barcode length other than 16: piece boundaries computed at run time
     bool slots;   // lookups read the 8-byte bucket slots
     bool thirds;  // the 20/22-bit families of very large barcode sets (max_err <= 1)
+    bool wide;    // the sixteen 20-bit families of large barcode sets (max_err = 2)
 };
 template <typename OffT>
 struct FilterArgs;

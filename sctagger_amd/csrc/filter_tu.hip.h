@@ -5,6 +5,8 @@
 
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/sctagger_hip.h"
 #include "sct_core.h"
 #include "sct_kernels_common.h"
@@ -25,35 +27,45 @@ void launch(const SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, un
     // (every one but the main launch's 32-bit instantiation) run one wave per block (FilterWavesPerBlock)
     if (!v.retry) {
         if (v.rt) {
-            k_filter<E, uint32_t, false, K_SLOTS, HMAX, 64, true, false, OffT><<<g, 256, 0, st>>>(fa);
-            k_filter<E, uint64_t, false, K_SLOTS, HMAX, 64, true, false, OffT><<<g64, 64, 0, st>>>(fa);
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, true, false, OffT><<<g, 256, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, true, false, OffT><<<g64, 64, 0, st>>>(fa);
         } else if (v.thirds) {
             if constexpr (E <= 1) {
-                k_filter<E, uint32_t, true, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
-                k_filter<E, uint64_t, true, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+                k_filter<E, uint32_t, SCHEME_THIRDS, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
+                k_filter<E, uint64_t, SCHEME_THIRDS, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+            }
+        } else if (v.wide) {
+            if constexpr (E == 2) {
+                k_filter<E, uint32_t, SCHEME_WIDE, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
+                k_filter<E, uint64_t, SCHEME_WIDE, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.slots) {
-            k_filter<E, uint32_t, false, HMAX_SL, HMAX_SL, 64, false, true, OffT><<<g, 256, 0, st>>>(fa);
-            k_filter<E, uint64_t, false, HMAX_SL, HMAX_SL, 64, false, true, OffT><<<g64, 64, 0, st>>>(fa);
+            k_filter<E, uint32_t, SCHEME_QUARTERS, HMAX_SL, HMAX_SL, 64, false, true, OffT><<<g, 256, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, HMAX_SL, HMAX_SL, 64, false, true, OffT><<<g64, 64, 0, st>>>(fa);
         } else {
-            k_filter<E, uint32_t, false, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
-            k_filter<E, uint64_t, false, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
         }
     } else {
         if (v.rt) {
-            k_filter<E, uint32_t, false, K_RETRY, H_RETRY, 16, true, false, OffT><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, false, K_RETRY, H_RETRY, 16, true, false, OffT><<<g64, 64, 0, st>>>(fa);
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY, 16, true, false, OffT><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY, 16, true, false, OffT><<<g64, 64, 0, st>>>(fa);
         } else if (v.thirds) {
             if constexpr (E <= 1) {
-                k_filter<E, uint32_t, true, K_RETRY, H_RETRY, 16, false, false, OffT><<<g, 64, 0, st>>>(fa);
-                k_filter<E, uint64_t, true, K_RETRY, H_RETRY, 16, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+                k_filter<E, uint32_t, SCHEME_THIRDS, K_RETRY, H_RETRY, 16, false, false, OffT><<<g, 64, 0, st>>>(fa);
+                k_filter<E, uint64_t, SCHEME_THIRDS, K_RETRY, H_RETRY, 16, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+            }
+        } else if (v.wide) {
+            if constexpr (E == 2) {
+                k_filter<E, uint32_t, SCHEME_WIDE, K_RETRY, H_RETRY, 16, false, false, OffT><<<g, 64, 0, st>>>(fa);
+                k_filter<E, uint64_t, SCHEME_WIDE, K_RETRY, H_RETRY, 16, false, false, OffT><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.slots) {
-            k_filter<E, uint32_t, false, K_RETRY, H_RETRY_SL, 16, false, true, OffT><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, false, K_RETRY, H_RETRY_SL, 16, false, true, OffT><<<g64, 64, 0, st>>>(fa);
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, 16, false, true, OffT><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, 16, false, true, OffT><<<g64, 64, 0, st>>>(fa);
         } else {
-            k_filter<E, uint32_t, false, K_RETRY, H_RETRY, 16, false, false, OffT><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, false, K_RETRY, H_RETRY, 16, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY, 16, false, false, OffT><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY, 16, false, false, OffT><<<g64, 64, 0, st>>>(fa);
         }
     }
 }

@@ -158,13 +158,16 @@ static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline
 // where each family's offsets start inside the concatenated offset table; the offsets themselves index the
 // concatenated entry tables (family f's entries start at f * np)
 struct FamTables {
-    uint32_t off_base[SCT_NFAM_ALL];
+    uint32_t off_base[SCT_NFAM_TABLES];
     uint32_t pid16;  // the pattern ids are also held in 16 bits (fewer than 65 536 patterns): half the footprint
 };
 
-template <typename W, int HM, int QC>
+// WIDE: the placement table holds (t, t2, u) triples of the wide families (sct_core.h), up to 9 combinations of shifts
+template <typename W, int HM, int QC, bool WIDE = false>
 struct FilterWaveLds {
     static constexpr int QCAP = QC;
+    typedef typename std::conditional<WIDE, uint32_t, uint16_t>::type PtabT;
+    static constexpr int PTAB = WIDE ? (sizeof(W) == 4 ? 160 : 448) : (sizeof(W) == 4 ? 128 : 320);
     static constexpr int HMAX = HM;
     alignas(32) W em[64][4];  // em[lane][c]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
     W va[sizeof(W) == 4 ? 64 : 1];  // bits 0..len (64-bit instantiations derive it from slen: their LDS is the scarcer)
@@ -173,7 +176,7 @@ struct FilterWaveLds {
     } pl[64];            // the segments' bit-planes (lookup lanes read the planes of the segment they work for)
     uint8_t slen[64];    // and lengths
     uint8_t alist[64];   // lanes whose segment still generates candidates, compacted
-    uint16_t ptab[sizeof(W) == 4 ? 128 : 320];  // this family's placements for the longest segment: t | t2 << 8
+    PtabT ptab[PTAB];    // this family's placements for the longest segment: t | t2 << 8 (| u << 16)
     uint32_t best[64];   // smallest distance verified so far for the lane's segment
     uint32_t hcnt[64];
     alignas(16) uint32_t hlist[HM][64];  // hlist, qk and qm double as the stage of the ASCII decode (k_decode.hip.h)
@@ -210,7 +213,7 @@ struct EmLds {
 static constexpr uint32_t QM_INLINE = 0x80000000u;
 static constexpr size_t SLOT_TOTAL = (size_t)SCT_NFAM * (SCT_KEYS + 1);  // slots of the six quarter families
 
-template <int E, typename W, int HM, bool SL, int RPW = 64>
+template <int E, typename W, int HM, bool SL, int RPW = 64, bool WIDE = false>
 struct FilterWave {
     static constexpr int HMAX = HM;
     // hit list entries per row: the LDS array hlist[HM][64] is shared out among the wave's RPW rows, entry k of row r at
@@ -218,7 +221,7 @@ struct FilterWave {
     static constexpr int CAP = HM * 64 / RPW;
     __device__ __forceinline__ uint32_t &hl(uint32_t k, uint32_t row) { return (&L.hlist[0][0])[k * (uint32_t)RPW + row]; }
     static constexpr int QCAP = QueueCap<SL, HM, W>::value;
-    FilterWaveLds<W, HM, QCAP> &L;
+    FilterWaveLds<W, HM, QCAP, WIDE> &L;
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
     const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
@@ -247,7 +250,14 @@ struct FilterWave {
     // lanes may come for the same place).  The row is deferred only if more entries AT ITS MINIMUM turn up than the list holds
     // — with a few million barcodes most rows see a dozen candidates two edits away before the one that is one edit away, and
     // round 1 deferred them all (92 % of the rows at 3.6 M barcodes, e <= 2).
-    static constexpr uint32_t HCNT_OVERFLOW = 0x80000000u;
+    // hcnt = entries handed out so far | one overflow mark per distance (bit 29 + d): what counts when the row is finished is the
+    // mark of its FINAL minimum — a list that ran over with candidates two edits away is fine again once one that is one edit
+    // away has turned up
+    static constexpr uint32_t HCNT_OVERFLOW = 0xE0000000u;
+    static constexpr int HCNT_OVERFLOW_SHIFT = 29;
+    __device__ static __forceinline__ bool overflowed(uint32_t hc, uint32_t best) {
+        return best <= (uint32_t)E && ((hc >> (HCNT_OVERFLOW_SHIFT + best)) & 1u) != 0u;
+    }
     __device__ __forceinline__ void insert_hit(uint32_t src, uint32_t d, uint32_t loc) {
         if constexpr (SL) {
             // bucket slots = small barcode sets (up to ~40 k): a row sees few candidates besides the right one, the plain
@@ -279,7 +289,7 @@ struct FilterWave {
                 }
             }
             // no place: unless a closer one has turned up meanwhile the row has more candidates at its minimum than the list holds
-            if (!placed && L.best[src] >= d) atomicOr(&L.hcnt[src], HCNT_OVERFLOW);
+            if (!placed && L.best[src] >= d) atomicOr(&L.hcnt[src], 1u << (HCNT_OVERFLOW_SHIFT + d));
         }
     }
 
@@ -304,7 +314,7 @@ struct FilterWave {
 
     template <typename Fam>
     __device__ __forceinline__ void verify2(const Fam &fam, uint32_t nq) {  // the nq <= 128 entries from head
-        using Lds = FilterWaveLds<W, HM, QCAP>;
+        using Lds = FilterWaveLds<W, HM, QCAP, WIDE>;
         static_assert(__builtin_offsetof(Lds, qm) == __builtin_offsetof(Lds, qk) + 4 * QCAP && __builtin_offsetof(Lds, qk) % 8 == 0,
                       "the ring runs over qk and qm");
         const uint2 pr = *reinterpret_cast<const uint2 *>(&ring()[(head + 2u * (uint32_t)lane) & (RING - 1)]);
@@ -383,6 +393,15 @@ struct FilterWave {
     // stops generating candidates for the later families — only the minimum tier is reported.
     __device__ __forceinline__ void settle(uint32_t tier) {
         if (active && L.best[lane] <= tier) active = false;
+    }
+
+    // Once every candidate closer than E has been seen (after settle(E - 1)) a minimum of E is final, and so is the overflow mark of
+    // distance E: such a row goes to the next launch whatever else turns up, and stops generating candidates here.  (At 3.6 M
+    // barcodes the rows whose minimum is two edits tie 40 - 90 ways: 11.5 % of the rows, and they are the ones that run all families.)
+    __device__ __forceinline__ void give_up() {
+        if constexpr (!SL) {
+            if (active && L.best[lane] == (uint32_t)E && overflowed(L.hcnt[lane], (uint32_t)E)) active = false;
+        }
     }
 
     // Append the bucket of every lane to the queue; 64-entry batches are verified as they form.  (a, b) are the two
@@ -623,6 +642,73 @@ struct FilterWave {
             head = tail = 0;
         }
     }
+
+    // One family of the wide scheme (sct_core.h, SctWide<WF>): the lookups of run_family's table variant with a third piece in
+    // the key — placements are (t, t2, u) —; what is queued and how it is verified is the quarter pair's business (Base).
+    template <int WF>
+    __device__ __forceinline__ void run_family_wide(int maxlen) {
+        static_assert(WIDE && !SL, "the wide families come with the plain tables");
+        using F = SctWide<WF>;
+        const typename F::Base fam{};
+        const uint64_t am = __ballot(active);
+        if (am == 0) return;
+        const int A = (int)__popcll(am);
+        if (active) L.alist[lane_rank(am)] = (uint8_t)lane;
+        int P = 0;
+#pragma unroll
+        for (int s = -F::SMAX; s <= F::SMAX; s++) {
+#pragma unroll
+            for (int x = -F::DMAX; x <= F::DMAX; x++) {
+                const int d = F::COUPLED ? s + x : x;
+                const int t2o = fam.GAP + d, uo = (F::FROM_B ? t2o : 0) + F::OFFC + s;
+                const int t0 = uo < 0 ? -uo : 0;
+                const int ext = t2o + fam.LB > uo + 2 ? t2o + fam.LB : uo + 2;
+                const int c = maxlen - ext - t0 + 1;
+                if (c > 0) {
+                    for (int i = lane; i < c; i += 64)
+                        L.ptab[P + i] = (uint32_t)(t0 + i) | ((uint32_t)(t0 + i + t2o) << 8) | ((uint32_t)(t0 + i + uo) << 16);
+                    P += c;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (P == 0) return;
+        const uint32_t inv = 65536u / (uint32_t)A + 1u;
+        int p = (int)(((uint32_t)lane * inv) >> 16);
+        const int a = lane - p * A;
+        const int dp = 64 / A;
+        const bool worker = p < dp;
+        const int passes = (P + dp - 1) / dp;
+        const uint32_t sl = L.alist[a];
+        const W slo = L.pl[sl].lo, shi = L.pl[sl].hi;
+        const int slen = (int)L.slen[sl];
+        const uint32_t *off = tab_off + ft.off_base[F::INDEX];
+        uint32_t ps = 0, pe = 0, pmeta = 0;
+        bool pend = false;
+        for (int pass = 0; pass < passes; pass++) {
+            uint32_t s = 0, e = 0, meta = 0;
+            if (worker && p < P) {
+                const uint32_t tt = L.ptab[p];
+                const int t = (int)(tt & 0xFFu), t2 = (int)((tt >> 8) & 0xFFu), u = (int)(tt >> 16);
+                if (sct_wide_valid(t2, u, slen)) {
+                    const uint32_t key = sct_wide_key<WF, W>(slo, shi, t, t2, u);
+                    const OffPair op = *reinterpret_cast<const OffPair *>(off + key);
+                    s = op.a;
+                    e = op.b;
+                    meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
+                }
+            }
+            p += dp;
+            if (pend) push_range(fam, ps, pe, pmeta);
+            pend = true;
+            ps = s;
+            pe = e;
+            pmeta = meta;
+        }
+        if (pend) push_range(fam, ps, pe, pmeta);
+        if (tail != head) verify2w(fam, tail - head);
+        head = tail = 0;
+    }
 };
 
 // W = uint32_t handles the waves whose longest segment has at most 31 characters, W = uint64_t the others
@@ -666,8 +752,10 @@ struct FilterArgs {
 };
 
 // One wave's RPW rows, starting at row (or list position) `first`.
-template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT, bool SL, typename OffT>
-__device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value> &L, int64_t first,
+// SCHEME: 0 = the six quarter families, 1 = thirds (max_err <= 1), 2 = wide (max_err = 2); sct_core.h
+static constexpr int SCHEME_QUARTERS = 0, SCHEME_THIRDS = 1, SCHEME_WIDE = 2;
+template <int E, typename W, int SCHEME, int KS, int HM, int RPW, bool RT, bool SL, typename OffT>
+__device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE> &L, int64_t first,
                                             int64_t n) {
     const int bl = RT ? a.bl : 16;
     const int lane = threadIdx.x & 63;
@@ -690,7 +778,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     W lo, hi;
     bool nonacgt;
     {
-        using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value>;
+        using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE>;
         static_assert(__builtin_offsetof(Lds, qk) == __builtin_offsetof(Lds, hlist) + 4 * 64 * HM &&
                           __builtin_offsetof(Lds, qm) == __builtin_offsetof(Lds, qk) + 4 * Lds::QCAP && __builtin_offsetof(Lds, hlist) % 16 == 0,
                       "hlist, qk and qm form the decode stage");
@@ -755,14 +843,41 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     L.best[lane] = E + 1;
     L.hcnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    static_assert(!(SL && (THIRDS || RT)), "bucket slots exist for the 16-character quarter families only");
-    FilterWave<E, W, HM, SL, RPW> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.ft, lane, active, len, lo, hi};
+    constexpr bool THIRDS = SCHEME == SCHEME_THIRDS, WIDE = SCHEME == SCHEME_WIDE;
+    static_assert(!(SL && (SCHEME != SCHEME_QUARTERS || RT)), "bucket slots exist for the 16-character quarter families only");
+    static_assert(!WIDE || (E == 2 && !RT), "the wide families are those of max_err = 2 and 16-character barcodes");
+    FilterWave<E, W, HM, SL, RPW, WIDE> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.ft, lane, active, len, lo, hi};
 #define RUN_FAMILY(FID)                                                         \
     do {                                                                        \
         if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \
         else W_.run_family(SctFamily<FID>{}, maxlen);                           \
     } while (0)
-    if (THIRDS) {
+    if constexpr (WIDE) {
+        W_.template run_family_wide<0>(maxlen);
+        W_.settle(0);
+        W_.template run_family_wide<1>(maxlen);
+        W_.template run_family_wide<3>(maxlen);
+        W_.template run_family_wide<4>(maxlen);
+        W_.settle(1);
+        W_.give_up();
+        W_.template run_family_wide<2>(maxlen);
+        W_.give_up();
+        W_.template run_family_wide<5>(maxlen);
+        W_.give_up();
+        W_.template run_family_wide<6>(maxlen);
+        W_.template run_family_wide<7>(maxlen);
+        W_.template run_family_wide<8>(maxlen);
+        W_.give_up();
+        W_.template run_family_wide<9>(maxlen);
+        W_.template run_family_wide<10>(maxlen);
+        W_.give_up();
+        W_.template run_family_wide<11>(maxlen);
+        W_.template run_family_wide<12>(maxlen);
+        W_.give_up();
+        W_.template run_family_wide<13>(maxlen);
+        W_.template run_family_wide<14>(maxlen);
+        W_.template run_family_wide<15>(maxlen);
+    } else if (THIRDS) {
         RUN_FAMILY(SCT_F_T01);
         if (E >= 1) {
             W_.settle(0);
@@ -777,16 +892,20 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         }
         if (E >= 2) {
             W_.settle(1);
+            W_.give_up();
             RUN_FAMILY(SCT_F_MID);
+            W_.give_up();
             RUN_FAMILY(SCT_F_02);
+            W_.give_up();
             RUN_FAMILY(SCT_F_13);
+            W_.give_up();
             RUN_FAMILY(SCT_F_03);
         }
     }
 #undef RUN_FAMILY
     // Locators -> pattern ids, in place, by all lanes of the wave: with RPW rows per wave, 64 / RPW lanes share a row's
     // list, up to four table reads in flight per lane.
-    using FW = FilterWave<E, W, HM, SL, RPW>;
+    using FW = FilterWave<E, W, HM, SL, RPW, WIDE>;
     constexpr uint32_t CAP = (uint32_t)FW::CAP;
     {
         constexpr int PARTS = 64 / RPW;
@@ -816,7 +935,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
             const uint32_t v = W_.hl(k, (uint32_t)lane);
             res.add((int)(v >> 30), v & LOC_MASK);
         }
-        res.store(active, r, (hc & FW::HCNT_OVERFLOW) != 0u || nc > CAP, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.wave_base, first,
+        res.store(active, r, SL ? nc > CAP : FW::overflowed(hc, L.best[lane]), line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.wave_base, first,
                   a.list_defer, a.defer_count, a.slot_cursor);
     } else {
         // Retry launch: lists of up to CAP entries per row (hundreds of ties at a few million barcodes and two edits) are
@@ -825,7 +944,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         // duplicate-free list.  The lists go to the slot array at (row's share of) a block reserved with one atomic per wave.
         constexpr int PER = (int)((CAP + 63) / 64);
         constexpr uint32_t SENT = 0xFFFFFFFFu;
-        const bool ovf = (hc & FW::HCNT_OVERFLOW) != 0u || (SL && nc > CAP);
+        const bool ovf = SL ? nc > CAP : FW::overflowed(hc, L.best[lane]);
         const uint32_t n_own = (active && !ovf) ? (nc < CAP ? nc : CAP) : 0u;
         // pass A, row after row: strike what is not at the row's minimum, strike duplicates, count what is left
         uint32_t my_cnt = 0;
@@ -932,21 +1051,21 @@ struct FilterWavesPerBlock {
     static constexpr int value = (RPW == 64 && sizeof(W) == 4) ? 4 : 1;
 };
 
-template <int E, typename W, bool THIRDS, int KS, int HM, int RPW, bool RT, bool SL, typename OffT>
+template <int E, typename W, int SCHEME, int KS, int HM, int RPW, bool RT, bool SL, typename OffT>
 __global__ void __launch_bounds__(256)
 k_filter(const FilterArgs<OffT> a) {
     constexpr int WPB = FilterWavesPerBlock<W, RPW>::value;
-    __shared__ FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value> lds[WPB];
+    __shared__ FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE> lds[WPB];
     const int64_t n = a.n_dev ? (int64_t)*a.n_dev : a.n;
     const int64_t first = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * RPW;
     if constexpr (WPB == 4) {
         // the main launch's 32-bit instantiation — where the time goes — is launched over all rows and stays loop-free:
         // wrapped in the loop below the compiler hoists enough address arithmetic out of it to cost two waves per SIMD
-        if (first < n) filter_rows<E, W, THIRDS, KS, HM, RPW, RT, SL, OffT>(a, lds[threadIdx.x >> 6], first, n);
+        if (first < n) filter_rows<E, W, SCHEME, KS, HM, RPW, RT, SL, OffT>(a, lds[threadIdx.x >> 6], first, n);
     } else {
         const int64_t step = (int64_t)gridDim.x * WPB * RPW;
         for (int64_t f = first; f < n; f += step) {
-            filter_rows<E, W, THIRDS, KS, HM, RPW, RT, SL, OffT>(a, lds[0], f, n);
+            filter_rows<E, W, SCHEME, KS, HM, RPW, RT, SL, OffT>(a, lds[0], f, n);
             __builtin_amdgcn_wave_barrier();
         }
     }

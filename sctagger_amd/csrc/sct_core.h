@@ -255,6 +255,7 @@ SCT_HD uint32_t sct_pattern_key(int f, uint32_t plo, uint32_t phi) {
     }
 }
 SCT_HD uint32_t sct_family_nkeys(int f) {
+    if (f >= SCT_NFAM_ALL) return 1u << 20;  // the wide families (SCT_WIDE_KEYS)
     switch (f) {
     case SCT_F_T01: return SctFamily<SCT_F_T01>::NKEYS;
     case SCT_F_T12: return SctFamily<SCT_F_T12>::NKEYS;
@@ -262,6 +263,93 @@ SCT_HD uint32_t sct_family_nkeys(int f) {
     default: return SCT_KEYS;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The WIDE scheme (max_err = 2, barcode sets from a few hundred thousand up): 16-bit keys leave np / 32 768 barcodes in every
+// bucket (110 at the 3.6 M-entry whitelist scale), and every one of them is run through the automaton.  Each quarter pair is
+// therefore split by a THIRD untouched piece, one half (2 characters) of another quarter: 20-bit keys, 16 times shorter buckets.
+// Which half can be relied on follows from what the pair is responsible for (the distributions of <= 2 edits over the quarters
+// that no earlier pair covers, as above; an insertion counts for the piece of the character behind it, so untouched
+// neighbours are contiguous in the text):
+//   (0,1), everything with q0 = q1 = 0:   half 2L untouched: Q0 Q1 2L contiguous                                         W0
+//                                         else 2R untouched and ONE edit in 2L: 2R at t + 10 + s, |s| <= 1                W1
+//                                         else both edits in q2, q3 untouched: 3L at t + 12 + s, |s| <= 2                 W2
+//   (2,3), everything with q2 = q3 = 0:   mirror images: 1R (W3), 1L |s| <= 1 (W4), 0R |s| <= 2 (W5)
+//   (1,2), one edit in q0 and one in q3:  0R untouched: 0R Q1 Q2 contiguous (W6); else 3L untouched: Q1 Q2 3L (W7);
+//                                         else the edits sit in 0R and 3L: 0L at t - 4 + s, |s| <= 1 (W8)
+//   (0,2), one edit in q1 and one in q3:  1L untouched (behind Q0, W9) or 1R untouched (before Q2, W10); |d| <= 1 as before
+//   (1,3), one edit in q0 and one in q2:  2L behind Q1 (W11) or 2R before Q3 (W12)
+//   (0,3), one edit in q1 and one in q2:  1L behind Q0 (W13); else 2R before Q3 (W14), |d| <= 2 both; else the edits sit in 1L
+//                                         and 2R: 1R at t + 6 + s, t2 = t + 12 + s + x, |s|, |x| <= 1 (W15)
+// After W0 every barcode at distance 0 has been seen, after W0 W1 W3 W4 every one at distance <= 1 (a single edit in q2 spoils
+// one half of it and leaves the other; one in q3 leaves 2L; likewise on the other side).  The candidate is verified exactly as
+// in the quarter scheme, anchored on the two quarters (the half is part of the verified rest): same distances, same locators.
+// tests/host_core_check.cpp checks completeness and the tiers against brute force, exhaustively around a pattern.
+// ---------------------------------------------------------------------------------------------------
+#define SCT_NWIDE 16
+#define SCT_WIDE_KEYS (1u << 20)
+#define SCT_F_WIDE0 SCT_NFAM_ALL               // table index of W0
+#define SCT_NFAM_TABLES (SCT_NFAM_ALL + SCT_NWIDE)
+template <int WF>
+struct SctWide {
+    static constexpr int BASE = WF < 3 ? SCT_F_H1 : WF < 6 ? SCT_F_H2 : WF < 9 ? SCT_F_MID : WF < 11 ? SCT_F_02 : WF < 13 ? SCT_F_13 : SCT_F_03;
+    using Base = SctFamily<BASE>;
+    // the half: where it starts in the barcode, which quarter's text position it is measured from, nominal distance from there
+    static constexpr int PC = WF == 0 ? 8 : WF == 1 ? 10 : WF == 2 ? 12 : WF == 3 ? 6 : WF == 4 ? 4 : WF == 5 ? 2 : WF == 6 ? 2 : WF == 7 ? 12
+                              : WF == 8 ? 0 : WF == 9 ? 4 : WF == 10 ? 6 : WF == 11 ? 8 : WF == 12 ? 10 : WF == 13 ? 4 : WF == 14 ? 10 : 6;
+    static constexpr bool FROM_B = WF == 10 || WF == 12 || WF == 14;
+    static constexpr int OFFC = PC - (FROM_B ? Base::PB : Base::PA);
+    // t2 = t + GAP + d, u = (t or t2) + OFFC + s;  COUPLED: d = s + x with x in [DMIN, DMAX]
+    static constexpr int SMAX = (WF == 1 || WF == 4 || WF == 8 || WF == 15) ? 1 : (WF == 2 || WF == 5) ? 2 : 0;
+    static constexpr int DMAX = (WF >= 9 && WF <= 12) ? 1 : (WF == 13 || WF == 14) ? 2 : WF == 15 ? 1 : 0;
+    static constexpr bool COUPLED = WF == 15;
+    static constexpr int INDEX = SCT_F_WIDE0 + WF;
+    static constexpr uint32_t NKEYS = SCT_WIDE_KEYS;
+};
+// key: the pair's 16 bits, then the half's two lo-plane bits and its two hi-plane bits
+template <int WF, typename W>
+SCT_HD uint32_t sct_wide_key(W lo, W hi, int t, int t2, int u) {
+    return sct_placement_key<SctWide<WF>::BASE, W>(lo, hi, t, t2) | (((uint32_t)(lo >> u) & 3u) << 16) | (((uint32_t)(hi >> u) & 3u) << 18);
+}
+template <int WF>
+SCT_HD uint32_t sct_wide_pattern_key_f(uint32_t plo, uint32_t phi) {
+    return sct_wide_key<WF, uint32_t>(plo, phi, SctWide<WF>::Base::PA, SctWide<WF>::Base::PB, SctWide<WF>::PC);
+}
+SCT_HD uint32_t sct_wide_pattern_key(int wf, uint32_t plo, uint32_t phi) {
+    switch (wf) {
+    case 0: return sct_wide_pattern_key_f<0>(plo, phi);
+    case 1: return sct_wide_pattern_key_f<1>(plo, phi);
+    case 2: return sct_wide_pattern_key_f<2>(plo, phi);
+    case 3: return sct_wide_pattern_key_f<3>(plo, phi);
+    case 4: return sct_wide_pattern_key_f<4>(plo, phi);
+    case 5: return sct_wide_pattern_key_f<5>(plo, phi);
+    case 6: return sct_wide_pattern_key_f<6>(plo, phi);
+    case 7: return sct_wide_pattern_key_f<7>(plo, phi);
+    case 8: return sct_wide_pattern_key_f<8>(plo, phi);
+    case 9: return sct_wide_pattern_key_f<9>(plo, phi);
+    case 10: return sct_wide_pattern_key_f<10>(plo, phi);
+    case 11: return sct_wide_pattern_key_f<11>(plo, phi);
+    case 12: return sct_wide_pattern_key_f<12>(plo, phi);
+    case 13: return sct_wide_pattern_key_f<13>(plo, phi);
+    case 14: return sct_wide_pattern_key_f<14>(plo, phi);
+    default: return sct_wide_pattern_key_f<15>(plo, phi);
+    }
+}
+// Placements (t, t2, u) of a wide family for a text of `len` characters: all three pieces inside the text.  Kernels build the
+// same list for the longest text of the wave (fn is called combination by combination, t ascending) and test each lane's length.
+template <int WF, typename Fn>
+SCT_HD void sct_for_each_wide_placement(int len, Fn &&fn) {
+    using F = SctWide<WF>;
+    for (int s = -F::SMAX; s <= F::SMAX; s++)
+        for (int x = -F::DMAX; x <= F::DMAX; x++) {
+            const int d = F::COUPLED ? s + x : x;
+            const int t2o = F::Base::GAP + d, uo = (F::FROM_B ? t2o : 0) + F::OFFC + s;
+            const int t0 = uo < 0 ? -uo : 0;
+            const int ext = t2o + F::Base::LB > uo + 2 ? t2o + F::Base::LB : uo + 2;
+            for (int t = t0; t + ext <= len; t++) fn(t, t + t2o, t + uo);
+        }
+}
+SCT_HD bool sct_wide_valid(int t2, int u, int len) { return t2 + 4 <= len && u + 2 <= len; }
 
 // Seed placements: the pair of text positions (t, t2) at which the two pieces are looked for.  A placement is
 // valid for a text of length L iff the second piece ends inside it: t2 + LB <= L.  Kernels walk the placements

@@ -12,6 +12,10 @@ static constexpr uint32_t CNT_MASK = 0x7FFFFFFFu;
 // e <= 1: 50 k 0.54 / 0.51, 70 k (17 %) 0.58 / 0.76.
 static constexpr double SLOTS_MAX_LONG_SHARE_E2 = 0.035, SLOTS_MAX_LONG_SHARE_E1 = 0.10;
 static constexpr int THIRDS_MIN_PATTERNS = 1 << 19;  // from here on (8 barcodes per 16-bit bucket) the thirds scheme pays
+// max_err = 2: from here on (524 288 barcodes) the sixteen 20-bit families are built and used.  Measured per 1 M segments, quarter
+// scheme / wide scheme (tools/wide_sweep.sh, 10^6 segments/s): 100 k barcodes 778 / 283, 400 k 188 / 144, 500 k 141 / 134,
+// 700 k 99 / 128, 1 M 80 / 126, 2 M 58 / 122, 3.6 M 45 / 112.
+static constexpr int WIDE_MIN_PATTERNS = 1 << 20;
 static constexpr int PLANE_MAX = 63;       // characters kept in the packed bit-planes
 
 // Per-batch device counters (one 64-byte record per lane, read back by the host in ONE copy when the batch is done).

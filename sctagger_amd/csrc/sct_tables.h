@@ -1,8 +1,9 @@
 // sct_tables.h — host-side construction of the seed tables of the filter kernel (plain C++, no HIP): used by
 // sct_set_barcodes and, in tests/host_core_check.cpp, by a CPU emulation of the filter path over the same tables.
 //
-// Per family f (sct_core.h): an offsets array of nkeys(f) + 1 entries holding ABSOLUTE indices into the entry tables
-// (family f's entries start at f * np), the entries as pattern ids (ascending inside a bucket) and as 2-bit codes, and
+// Per family f that is built (sct_core.h; the six quarter families always, the thirds and the wide families on request): an
+// offsets array of nkeys(f) + 1 entries holding ABSOLUTE indices into the entry tables (the families' entries follow one
+// another, np each), the entries as pattern ids (ascending inside a bucket) and as 2-bit codes, and
 // — for the six quarter families — one 8-byte bucket slot per key (sct_slot_*), indexed like the offsets, and the entry
 // index at the start of every group of 64 keys (an inline slot says where its entries start inside its group).
 #pragma once
@@ -14,23 +15,28 @@
 
 struct SctSeedTables {
     int nfam = 0;
-    uint32_t off_base[SCT_NFAM_ALL] = {};  // where family f's offsets (and slots) start
+    uint32_t off_base[SCT_NFAM_TABLES] = {};  // where family f's offsets (and slots) start (families that are not built: 0)
     std::vector<uint32_t> off, ent, code;
     std::vector<uint64_t> slot;
     std::vector<uint32_t> grp;             // per quarter family SCT_GRP_PER_FAM words: entry index at the first key of every group of 64 keys
     double long_share = 1.0;               // share of the quarter families' keys whose bucket does not fit a slot
 };
 
-// pat[p].x / .y: bit-planes of pattern p (np patterns of bl characters, 8 <= bl <= 16); thirds: also build the
-// 20/22-bit families (bl == 16 only).  Returns false if the tables would not be addressable with 32-bit indices.
+// pat[p].x / .y: bit-planes of pattern p (np patterns of bl characters, 8 <= bl <= 16); thirds / wide: also build the
+// 20/22-bit families of max_err <= 1 / the sixteen 20-bit families of max_err = 2 (bl == 16 only).  Returns false if the
+// tables would not be addressable with 32-bit indices.
 template <typename Pat>
-static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds, SctSeedTables &T) {
-    T.nfam = thirds ? SCT_NFAM_ALL : SCT_NFAM;
+static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds, bool wide, SctSeedTables &T) {
+    auto built = [&](int f) { return f < SCT_NFAM || (f < SCT_NFAM_ALL ? thirds : wide); };
+    T.nfam = 0;
     size_t off_total = 0;
-    for (int f = 0; f < T.nfam; f++) {
-        if (off_total + sct_family_nkeys(f) + 1 > 0xFFFFFFFFull || (uint64_t)(f + 1) * (uint64_t)np > 0xFFFFFFFFull) return false;
+    for (int f = 0; f < SCT_NFAM_TABLES; f++) {
+        T.off_base[f] = 0;
+        if (!built(f)) continue;
+        if (off_total + sct_family_nkeys(f) + 1 > 0xFFFFFFFFull || (uint64_t)(T.nfam + 1) * (uint64_t)np > 0x3FFFFFFFull) return false;
         T.off_base[f] = (uint32_t)off_total;
         off_total += (size_t)sct_family_nkeys(f) + 1;
+        T.nfam++;
     }
     const size_t npn = np ? (size_t)np : 1;
     T.off.assign(off_total, 0u);
@@ -42,23 +48,30 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
         for (int j = 0; j < bl; j++) v |= (((pat[p].x >> j) & 1u) | (((pat[p].y >> j) & 1u) << 1)) << (2 * j);
         inter[p] = v;
     }
-    for (int f = 0; f < T.nfam; f++) {
+    std::vector<uint32_t> keys(npn), cur;
+    size_t ent_base = 0;
+    for (int f = 0; f < SCT_NFAM_TABLES; f++) {
+        if (!built(f)) continue;
         const uint32_t nk = sct_family_nkeys(f);
         uint32_t *o = T.off.data() + T.off_base[f];
-        auto key_of = [&](int p) {  // quarter families: piece boundaries from the barcode length
-            if (f >= SCT_NFAM) return sct_pattern_key(f, pat[p].x, pat[p].y);
+        if (f >= SCT_F_WIDE0) {
+            for (int p = 0; p < np; p++) keys[p] = sct_wide_pattern_key(f - SCT_F_WIDE0, pat[p].x, pat[p].y);
+        } else if (f >= SCT_NFAM) {
+            for (int p = 0; p < np; p++) keys[p] = sct_pattern_key(f, pat[p].x, pat[p].y);
+        } else {  // quarter families: piece boundaries from the barcode length
             const SctFamilyRT fam = sct_family_rt(f, bl);
-            return sct_key_of<uint32_t>(fam, pat[p].x, pat[p].y, fam.PA, fam.PB);
-        };
-        for (int p = 0; p < np; p++) o[key_of(p) + 1]++;
-        o[0] = (uint32_t)((size_t)f * np);
+            for (int p = 0; p < np; p++) keys[p] = sct_key_of<uint32_t>(fam, pat[p].x, pat[p].y, fam.PA, fam.PB);
+        }
+        for (int p = 0; p < np; p++) o[keys[p] + 1]++;
+        o[0] = (uint32_t)ent_base;
         for (uint32_t k = 0; k < nk; k++) o[k + 1] += o[k];
-        std::vector<uint32_t> cur(o, o + nk);
+        cur.assign(o, o + nk);
         for (int p = 0; p < np; p++) {
-            const uint32_t at = cur[key_of(p)]++;
+            const uint32_t at = cur[keys[p]]++;
             T.ent[at] = (uint32_t)p;
             T.code[at] = inter[p];
         }
+        ent_base += (size_t)np;
     }
     size_t slot_total = 0;
     for (int f = 0; f < SCT_NFAM; f++) slot_total += (size_t)sct_family_nkeys(f) + 1;

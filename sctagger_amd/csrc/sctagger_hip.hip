@@ -122,7 +122,7 @@ struct TimedSpan {
 // What one batch is run with (set when it is queued, used again by the slow path).
 struct BatchParams {
     int max_err = 0, threads = 1, prefix_len = 0;
-    bool filter_ok = false, use_slots = false, use_thirds = false, rt_families = false;
+    bool filter_ok = false, use_slots = false, use_thirds = false, use_wide = false, rt_families = false;
     int count_format = SCT_CNT_OFFS64;  // SCT_CNT_*: which compact form of the counts the offsets kernel also writes
 };
 
@@ -190,7 +190,8 @@ struct sct_ctx {
     int device = 0;
     // barcodes
     int n_bc = 0, bl = 0, np = 0;
-    bool have_bc = false, have_tables = false, have_thirds = false;
+    bool have_bc = false, have_tables = false, have_thirds = false, have_wide = false;
+    int tables_nfam = 0;   // families the seed tables hold (entry indices run up to tables_nfam * np)
     FamTables ft{};
     DevBuf pat, tab_off, tab_ent, tab_code, tab_slot, tab_grp, tab_ent16;
     std::vector<Lane *> lanes;  // lanes[0] always exists
@@ -204,6 +205,7 @@ struct sct_ctx {
     int32_t wl_n = -1;
     // options
     bool force_exhaustive = false, timing = true, no_thirds = false;
+    int wide_mode = -1;    // -1 = by the size of the barcode set, 0 = never, 1 = build and use the wide families whatever the size
     int slots_mode = -1;       // -1 = by the share of long buckets, 0 = never, 1 = whenever the tables hold them
     double long_share = 1.0;   // share of the seed keys whose bucket does not fit a slot (sct_set_barcodes)
     bool zero_copy = true;     // stream API: kernels read page-locked caller buffers in place instead of uploading them
@@ -369,6 +371,7 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "force_exhaustive")) c->force_exhaustive = value != 0;
     else if (!strcmp(key, "timing")) c->timing = value != 0;
     else if (!strcmp(key, "no_thirds")) c->no_thirds = value != 0;
+    else if (!strcmp(key, "wide")) c->wide_mode = value < 0 ? -1 : (value != 0);  // takes effect at the next sct_set_barcodes
     else if (!strcmp(key, "slots")) c->slots_mode = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "chunk_rows")) {
         if (value < 0 || value > 0x7FFFFFF0) return fail(SCT_E_ARG, "chunk_rows must be in 0 .. 2^31-16");
@@ -409,6 +412,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
     c->have_bc = false;
     c->have_tables = false;
     c->have_thirds = false;
+    c->have_wide = false;
     const int np = 2 * n;
     std::vector<uint2> pat((size_t)np);
     for (int i = 0; i < n; i++) {
@@ -431,17 +435,19 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
     if (bl >= 8 && bl <= 16) {
         // seed tables (sct_tables.h): counting sort of the pattern ids by key, per family, plus the bucket slots.
         // The thirds families (20/22-bit keys) are only worth their 38 MB of offsets for very large barcode sets.
+        // Likewise the wide families of max_err = 2 (sixteen tables of np entries and 4 MB of offsets each).
         const bool thirds = bl == 16 && np >= THIRDS_MIN_PATTERNS;
+        const bool wide = bl == 16 && np > 0 && (c->wide_mode < 0 ? np >= WIDE_MIN_PATTERNS : c->wide_mode == 1);
         SctSeedTables tb;
         std::vector<uint16_t> pid16;
         int rc = SCT_OK;
         do {
-            if (!sct_build_tables(pat.data(), np, bl, thirds, tb)) {
+            if (!sct_build_tables(pat.data(), np, bl, thirds, wide, tb)) {
                 rc = fail(SCT_E_UNSUPPORTED, "too many barcodes for the seed tables");
                 break;
             }
             FamTables ft{};
-            for (int f = 0; f < tb.nfam; f++) ft.off_base[f] = tb.off_base[f];
+            for (int f = 0; f < SCT_NFAM_TABLES; f++) ft.off_base[f] = tb.off_base[f];
             c->long_share = tb.long_share;
             if (tb.slot.size() != SLOT_TOTAL) {
                 rc = fail(SCT_E_STATE, "seed tables: unexpected slot count");
@@ -471,6 +477,8 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             c->ft = ft;
             c->have_tables = true;
             c->have_thirds = thirds;
+            c->have_wide = wide;
+            c->tables_nfam = tb.nfam;
         } while (0);
         if (rc) {
             (void)hipStreamSynchronize(st);
@@ -502,10 +510,11 @@ static int batch_params(sct_ctx *c, int32_t max_err, int32_t threads, int count_
     if (bp.prefix_len >= c->bl - max_err)
         return fail(SCT_E_UNSUPPORTED, "threads = %d gives the reference a window prefix of %d characters, not below bl - max_err = %d: "
                     "its sentinel entry would enter the results (scTagger.py:675); not supported", threads, bp.prefix_len, c->bl - max_err);
-    bp.filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && c->np > 0 && (uint64_t)SCT_NFAM_ALL * (uint64_t)c->np < LOC_INLINE;
+    bp.filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && c->np > 0 && (uint64_t)c->tables_nfam * (uint64_t)c->np < LOC_INLINE;
     bp.rt_families = c->bl != 16;  // quarter families with run-time piece boundaries
     bp.use_thirds = bp.filter_ok && c->have_thirds && max_err <= 1 && !c->no_thirds;
-    bp.use_slots = c->bl == 16 && !bp.use_thirds &&
+    bp.use_wide = bp.filter_ok && c->have_wide && max_err == 2 && c->wide_mode != 0;
+    bp.use_slots = c->bl == 16 && !bp.use_thirds && !bp.use_wide &&
                    (c->slots_mode < 0 ? c->long_share <= (max_err <= 1 ? SLOTS_MAX_LONG_SHARE_E1 : SLOTS_MAX_LONG_SHARE_E2) : c->slots_mode == 1);
     bp.count_format = count_format;
     return SCT_OK;
@@ -581,7 +590,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.ctr = ctr;
     fa.bl = c->bl;
     fa.prefix_len = bp.prefix_len;
-    SctFilterVariant v{false, bp.rt_families, bp.use_slots && !bp.rt_families, bp.use_thirds};
+    SctFilterVariant v{false, bp.rt_families, bp.use_slots && !bp.rt_families, bp.use_thirds, bp.use_wide};
     {
         Timer t(c, l, "k_filter");
         fa.n = n;

@@ -8,6 +8,7 @@
 #include <random>
 #include <vector>
 
+#include <functional>
 #include <set>
 
 #include "../sctagger_amd/csrc/sct_core.h"
@@ -119,6 +120,64 @@ static int anchored_thirds(const std::vector<int> &p, const std::vector<int> &t)
         b = std::min(b, anchored_family<E, SCT_F_T02, W>(p, t));
     }
     return b;
+}
+
+// the wide scheme (sixteen 20-bit families, max_err = 2): minimum anchored distance over the placements of family WF whose key
+// equals the pattern's; `lookups` counts the placements
+template <int WF, typename W>
+static int anchored_wide_family(const std::vector<int> &p, const std::vector<int> &t, long *lookups = nullptr) {
+    uint64_t plo, phi, tlo, thi;
+    planes(p, plo, phi);
+    planes(t, tlo, thi);
+    const int L = (int)t.size();
+    EmArray<W> em;
+    const W va = sct_valid_mask<W>(L), ve = va & ~(W)1, l1 = (W)tlo << 1, h1 = (W)thi << 1;
+    em.m[0] = ~l1 & ~h1 & ve; em.m[1] = l1 & ~h1 & ve; em.m[2] = ~l1 & h1 & ve; em.m[3] = l1 & h1 & ve;
+    uint32_t code = 0;
+    for (int j = 0; j < 16; j++) code |= (uint32_t)p[j] << (2 * j);
+    const uint32_t pkey = sct_wide_pattern_key(WF, (uint32_t)plo, (uint32_t)phi);
+    int best = 3;
+    sct_for_each_wide_placement<WF>(L, [&](int a, int b, int u) {
+        if (lookups) ++*lookups;
+        if (a < 0 || u < 0 || !sct_wide_valid(b, u, L)) { printf("FAIL wide placement outside the text\n"); exit(1); }
+        if (sct_wide_key<WF, W>((W)tlo, (W)thi, a, b, u) != pkey) return;
+        best = std::min(best, wm_anchored<2, SctWide<WF>::BASE, W>(em, va, code, a, b));
+    });
+    return best;
+}
+// tier 0 = W0; tier 1 = W0 W1 W3 W4; tier 2 = all
+template <typename W = uint32_t>
+static int anchored_wide(const std::vector<int> &p, const std::vector<int> &t, int tier, long *lookups = nullptr) {
+    int b = anchored_wide_family<0, W>(p, t, lookups);
+    if (tier >= 1) {
+        b = std::min(b, anchored_wide_family<1, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<3, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<4, W>(p, t, lookups));
+    }
+    if (tier >= 2) {
+        b = std::min(b, anchored_wide_family<2, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<5, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<6, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<7, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<8, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<9, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<10, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<11, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<12, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<13, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<14, W>(p, t, lookups));
+        b = std::min(b, anchored_wide_family<15, W>(p, t, lookups));
+    }
+    return b;
+}
+// distance as the wide scheme reports it: the minimum over all families; with the tiers: a text whose minimum is 0 has it after
+// tier 0, one whose minimum is 1 after tier 1
+template <typename W = uint32_t>
+static bool check_wide(const std::vector<int> &p, const std::vector<int> &t, int want) {
+    if (anchored_wide<W>(p, t, 2) != std::min(want, 3)) { printf("FAIL wide want=%d got=%d n=%zu\n", want, anchored_wide<W>(p, t, 2), t.size()); return false; }
+    if (want == 0 && anchored_wide<W>(p, t, 0) != 0) { printf("FAIL wide tier 0\n"); return false; }
+    if (want <= 1 && anchored_wide<W>(p, t, 1) != want) { printf("FAIL wide tier 1 want=%d got=%d\n", want, anchored_wide<W>(p, t, 1)); return false; }
+    return true;
 }
 
 // run-time families (barcode lengths 8..16): minimum anchored distance over all six quarter families
@@ -287,6 +346,50 @@ static bool emulate_filter(const SctSeedTables &T, const std::vector<std::vector
         if (d == want) want_hits.insert((uint32_t)p);
     }
     (void)bl;
+    return want == best && want_hits == hits;
+}
+
+// the same through the wide families' tables (max_err = 2, 16-character barcodes)
+template <int WF>
+static void emulate_wide_family(const SctSeedTables &T, uint64_t tlo, uint64_t thi, int L, const EmArray<uint32_t> &em, uint32_t va,
+                                const std::function<void(int, uint32_t)> &add) {
+    const uint32_t *off = T.off.data() + T.off_base[SctWide<WF>::INDEX];
+    sct_for_each_wide_placement<WF>(L, [&](int a, int b, int u) {
+        const uint32_t key = sct_wide_key<WF, uint32_t>((uint32_t)tlo, (uint32_t)thi, a, b, u);
+        for (uint32_t gk = off[key]; gk < off[key + 1]; gk++)
+            add(wm_anchored<2, SctWide<WF>::BASE, uint32_t>(em, va, T.code[gk], a, b), T.ent[gk]);
+    });
+}
+static bool emulate_filter_wide(const SctSeedTables &T, const std::vector<std::vector<int>> &pats, const std::vector<int> &t) {
+    const int L = (int)t.size();
+    uint64_t tlo, thi;
+    planes(t, tlo, thi);
+    EmArray<uint32_t> em;
+    const uint32_t va = sct_valid_mask<uint32_t>(L), ve = va & ~1u, l1 = (uint32_t)tlo << 1, h1 = (uint32_t)thi << 1;
+    em.m[0] = ~l1 & ~h1 & ve; em.m[1] = l1 & ~h1 & ve; em.m[2] = ~l1 & h1 & ve; em.m[3] = l1 & h1 & ve;
+    int best = 3;
+    std::set<uint32_t> hits;
+    const std::function<void(int, uint32_t)> add = [&](int d, uint32_t pid) {
+        if (d > 2) return;
+        if (d < best) { best = d; hits.clear(); }
+        if (d == best) hits.insert(pid);
+    };
+    emulate_wide_family<0>(T, tlo, thi, L, em, va, add);  emulate_wide_family<1>(T, tlo, thi, L, em, va, add);
+    emulate_wide_family<2>(T, tlo, thi, L, em, va, add);  emulate_wide_family<3>(T, tlo, thi, L, em, va, add);
+    emulate_wide_family<4>(T, tlo, thi, L, em, va, add);  emulate_wide_family<5>(T, tlo, thi, L, em, va, add);
+    emulate_wide_family<6>(T, tlo, thi, L, em, va, add);  emulate_wide_family<7>(T, tlo, thi, L, em, va, add);
+    emulate_wide_family<8>(T, tlo, thi, L, em, va, add);  emulate_wide_family<9>(T, tlo, thi, L, em, va, add);
+    emulate_wide_family<10>(T, tlo, thi, L, em, va, add); emulate_wide_family<11>(T, tlo, thi, L, em, va, add);
+    emulate_wide_family<12>(T, tlo, thi, L, em, va, add); emulate_wide_family<13>(T, tlo, thi, L, em, va, add);
+    emulate_wide_family<14>(T, tlo, thi, L, em, va, add); emulate_wide_family<15>(T, tlo, thi, L, em, va, add);
+    int want = 3;
+    std::set<uint32_t> want_hits;
+    for (size_t p = 0; p < pats.size(); p++) {
+        const int d = brute_infix(pats[p], t);
+        if (d > 2) continue;
+        if (d < want) { want = d; want_hits.clear(); }
+        if (d == want) want_hits.insert((uint32_t)p);
+    }
     return want == best && want_hits == hits;
 }
 
@@ -551,7 +654,8 @@ int main() {
             pp[p] = {(uint32_t)lo, (uint32_t)hi};
         }
         SctSeedTables T;
-        if (!sct_build_tables(pp.data(), (int)pp.size(), bl, false, T)) { printf("FAIL build\n"); return 1; }
+        const bool wide = bl == 16 && it % 4 == 1;  // every other 16-character set (16 x 4 MB of offsets to clear each time)
+        if (!sct_build_tables(pp.data(), (int)pp.size(), bl, false, wide, T)) { printf("FAIL build\n"); return 1; }
         for (int k = 0; k < 30; k++) {
             std::vector<int> t;
             const int n = rnd(32);
@@ -576,6 +680,7 @@ int main() {
                                 emulate_filter<2>(T, pats, bl, t, sl);
                 if (!ok) { printf("FAIL filter emulation bl=%d patterns=%zu slots=%d\n", bl, pats.size(), sl); return 1; }
             }
+            if (wide && !emulate_filter_wide(T, pats, t)) { printf("FAIL wide filter emulation patterns=%zu\n", pats.size()); return 1; }
             checked++;
         }
     }
@@ -611,6 +716,7 @@ int main() {
         if (anchored<0>(p, t) != std::min(want, 1)) { printf("FAIL anchored0 want=%d got=%d\n", want, anchored<0>(p, t)); return 1; }
         if (anchored<1>(p, t) != std::min(want, 2)) { printf("FAIL anchored1 want=%d got=%d\n", want, anchored<1>(p, t)); return 1; }
         if (anchored<2>(p, t) != std::min(want, 3)) { printf("FAIL anchored2 want=%d got=%d n=%zu\n", want, anchored<2>(p, t), t.size()); return 1; }
+        if (!check_wide(p, t, want)) return 1;
         if (want <= 0 && !seeds_cover<0>(p, t)) { printf("FAIL seeds0\n"); return 1; }
         if (want <= 1 && !seeds_cover<1>(p, t)) { printf("FAIL seeds1\n"); return 1; }
         if (want <= 2 && !seeds_cover<2>(p, t)) { printf("FAIL seeds2 want=%d\n", want); return 1; }
@@ -640,6 +746,7 @@ int main() {
         if (anchored<1, uint64_t>(p, t) != std::min(want, 2)) { printf("FAIL anchored64/1\n"); return 1; }
         if (anchored<2, uint64_t>(p, t) != std::min(want, 3)) { printf("FAIL anchored64/2 want=%d got=%d n=%zu\n", want, anchored<2, uint64_t>(p, t), t.size()); return 1; }
         if (t.size() <= 31 && anchored<2, uint32_t>(p, t) != std::min(want, 3)) { printf("FAIL anchored32 vs 64\n"); return 1; }
+        if (!check_wide<uint64_t>(p, t, want)) return 1;
         checked++;
     }
     // 2c. run-time piece boundaries: barcode lengths 8..16, texts 0..31
@@ -701,6 +808,8 @@ int main() {
                 if (anchored<2>(p, t) != std::min(want, 3)) { printf("FAIL anchored2 exhaustive\n"); return 1; }
                 if (anchored<1>(p, t) != std::min(want, 2)) { printf("FAIL anchored1 exhaustive\n"); return 1; }
                 if (anchored_thirds<1>(p, t) != std::min(want, 2)) { printf("FAIL thirds1 exhaustive\n"); return 1; }
+                if (!check_wide(p, t, want)) return 1;
+                if (s.size() <= 31 && !check_wide(p, s, w2)) return 1;
                 if (s.size() <= 31 && anchored<2>(p, s) != std::min(w2 <= 2 ? w2 : 3, 3)) { printf("FAIL anchored2 bare\n"); return 1; }
                 if (s.size() <= 31 && w2 <= 2 && !seeds_cover<2>(p, s)) { printf("FAIL seeds2 bare\n"); return 1; }
                 n_texts++;

@@ -88,3 +88,8 @@ def test_gpu_fuzz_all_paths():
             m.set_option("force_exhaustive", 0)
             m.set_option("chunk_rows", 0)
             m.set_option("slots", -1)
+            if bl == 16 and e == 2 and n_bc > 0:   # the wide seed families of large sets, forced on the small one
+                m.set_option("wide", 1)
+                m.set_barcodes(bc, bl)
+                util.assert_same(m.match(segs, offs, e, t), want, "trial %d wide families n_bc=%d" % (trial, n_bc))
+                m.set_option("wide", -1)

@@ -118,6 +118,14 @@ def run_both(m, bc, segs, offs, e, t=1, stream=True):
         m.set_option("slots", sl)
         util.assert_same(m.match(segs, offs, e, t), a, "slots=%d vs default" % sl)
     m.set_option("slots", -1)
+    if e == 2 and len(bc) > 0 and len(bc[0]) == 16:        # the sixteen 20-bit families that large sets use at two edits
+        m.set_option("wide", 1)
+        m.set_barcodes(bc)
+        try:
+            util.assert_same(m.match(segs, offs, e, t), a, "wide families vs default")
+        finally:
+            m.set_option("wide", -1)
+            m.set_barcodes(bc)
     m.upload_segments(segs, offs)           # the resident three-step API: one batch, int64 offsets on the device
     m.run(e, t)
     util.assert_same(m.download(), a, "upload/run/download vs match")
@@ -537,6 +545,25 @@ def test_cfg5_scale_barcode_set(m):
     util.assert_same(a, b, "filter vs exhaustive at 3.6M barcodes")
     k = 200
     want = trie_oracle.match(bc, segs[:offs[k]], offs[:k + 1], 1, threads=16, workers=8)
+    assert np.array_equal(a[0][:k], want[0]) and np.array_equal(a[2][:a[1][k]], want[2])
+
+
+def test_wide_scheme_equals_quarters(m):
+    """From 2^20 patterns on, max_err = 2 uses the sixteen 20-bit 'wide' seed families (sct_core.h); they must agree with the
+    16-bit quarter families (option wide = 0) and with the oracle — ragged rows, both mask widths, ties by the dozen."""
+    bc = synth.make_barcodes(600_000, seed=23)
+    segs, offs = ragged(6000, bc, 23, 60)
+    m.set_barcodes(bc)
+    a = m.match(segs, offs, 2, 16)
+    assert m.last_stats()["exhaustive"] == 0
+    m.set_option("wide", 0)
+    try:
+        b = m.match(segs, offs, 2, 16)
+    finally:
+        m.set_option("wide", -1)
+    util.assert_same(a, b, "wide vs quarters")
+    k = 300
+    want = trie_oracle.match(bc, segs[:offs[k]], offs[:k + 1], 2, threads=16, workers=8)
     assert np.array_equal(a[0][:k], want[0]) and np.array_equal(a[2][:a[1][k]], want[2])
 
 

@@ -11,13 +11,17 @@ e = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 bc = synth.make_barcodes(nbc, seed=5)
 segs, offs = bench.make_batch(n, bc, 5)
 m = _native.Matcher(0)
+if os.environ.get("SCT_WIDE"):   # -1 = by size, 0 = never, 1 = always
+    m.set_option("wide", int(os.environ["SCT_WIDE"]))
+t0 = time.perf_counter()
 m.set_barcodes(bc)
+t_set = time.perf_counter() - t0
 m.upload_segments(segs, offs)
 m.run(e, 16)
 t0 = time.perf_counter(); m.run(e, 16); dt = time.perf_counter() - t0
 a = m.download()
 cnt = np.diff(a[1])
-print(json.dumps({"segments": n, "barcodes": nbc, "max_err": e, "seconds": round(dt, 4), "segments_per_s": n / dt, "stats": m.last_stats(),
+print(json.dumps({"segments": n, "barcodes": nbc, "max_err": e, "set_barcodes_s": round(t_set, 3), "wide": os.environ.get("SCT_WIDE", "auto"), "seconds": round(dt, 4), "segments_per_s": n / dt, "stats": m.last_stats(),
                   "timing_ms": {k: round(v, 3) for k, v in m.last_timing()},
                   "ties_percentiles_50_90_99_999_max": [int(np.percentile(cnt, q)) for q in (50, 90, 99, 99.9)] + [int(cnt.max())],
                   "share_rows_with_more_than_8_32_240_ties": [float((cnt > k).mean()) for k in (8, 32, 240)],
