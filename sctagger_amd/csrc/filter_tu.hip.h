@@ -48,24 +48,24 @@ void launch(const SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, un
         }
     } else {
         if (v.rt) {
-            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY, 16, true, false, OffT><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY, 16, true, false, OffT><<<g64, 64, 0, st>>>(fa);
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT><<<g64, 64, 0, st>>>(fa);
         } else if (v.thirds) {
             if constexpr (E <= 1) {
-                k_filter<E, uint32_t, SCHEME_THIRDS, K_RETRY, H_RETRY, 16, false, false, OffT><<<g, 64, 0, st>>>(fa);
-                k_filter<E, uint64_t, SCHEME_THIRDS, K_RETRY, H_RETRY, 16, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+                k_filter<E, uint32_t, SCHEME_THIRDS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g, 64, 0, st>>>(fa);
+                k_filter<E, uint64_t, SCHEME_THIRDS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.wide) {
             if constexpr (E == 2) {
-                k_filter<E, uint32_t, SCHEME_WIDE, K_RETRY, H_RETRY, 16, false, false, OffT><<<g, 64, 0, st>>>(fa);
-                k_filter<E, uint64_t, SCHEME_WIDE, K_RETRY, H_RETRY, 16, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+                k_filter<E, uint32_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g, 64, 0, st>>>(fa);
+                k_filter<E, uint64_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.slots) {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, 16, false, true, OffT><<<g, 64, 0, st>>>(fa);
             k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, 16, false, true, OffT><<<g64, 64, 0, st>>>(fa);
         } else {
-            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY, 16, false, false, OffT><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY, 16, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);
         }
     }
 }

@@ -152,6 +152,11 @@ struct QueueCap {
 static constexpr int HMAX = 8, HMAX_SL = 6;  // main launch
 static constexpr int K_RETRY = 32, H_RETRY = 80;  // retry launch: 80 x 256 B of LDS hold 320 hit-list entries for each of a wave's 16 rows
 static constexpr int H_RETRY_SL = H_RETRY;
+// without slots (larger barcode sets): the same 320 entries per row for 4 rows per wave — a quarter of the LDS per (one-wave) block,
+// four times the waves per CU; these launches wait for table reads and are short of waves, not of lanes.  Retry launch per 1 M
+// rows with 16 / 8 / 4 rows per wave: 3.6 M barcodes wide scheme 5.4 / 4.0 / 4.1 ms, 1 M wide 5.0 / 5.0 / 4.7, 3.6 M quarters
+// 12.6 / 8.4 / 7.9, 400 k quarters 2.3 / 1.8 / 1.6
+static constexpr int H_RETRY_NS = 20, RETRY_RPW_NS = 4;
 static constexpr uint32_t LOC_MASK = (1u << 30) - 1u;    // locator in a hit-list entry (2 bits of distance above it)
 static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline slot entry (entry indices stay below it)
 
