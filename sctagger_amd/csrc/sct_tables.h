@@ -9,6 +9,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "sct_core.h"
@@ -48,10 +50,13 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
         for (int j = 0; j < bl; j++) v |= (((pat[p].x >> j) & 1u) | (((pat[p].y >> j) & 1u) << 1)) << (2 * j);
         inter[p] = v;
     }
-    std::vector<uint32_t> keys(npn), cur;
-    size_t ent_base = 0;
-    for (int f = 0; f < SCT_NFAM_TABLES; f++) {
-        if (!built(f)) continue;
+    // the families are independent (disjoint parts of off / ent / code): a few host threads share them out
+    std::vector<int> fams;
+    for (int f = 0; f < SCT_NFAM_TABLES; f++)
+        if (built(f)) fams.push_back(f);
+    auto build_family = [&](int rank) {
+        const int f = fams[(size_t)rank];
+        std::vector<uint32_t> keys(npn), cur;
         const uint32_t nk = sct_family_nkeys(f);
         uint32_t *o = T.off.data() + T.off_base[f];
         if (f >= SCT_F_WIDE0) {
@@ -63,7 +68,7 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
             for (int p = 0; p < np; p++) keys[p] = sct_key_of<uint32_t>(fam, pat[p].x, pat[p].y, fam.PA, fam.PB);
         }
         for (int p = 0; p < np; p++) o[keys[p] + 1]++;
-        o[0] = (uint32_t)ent_base;
+        o[0] = (uint32_t)((size_t)rank * (size_t)np);
         for (uint32_t k = 0; k < nk; k++) o[k + 1] += o[k];
         cur.assign(o, o + nk);
         for (int p = 0; p < np; p++) {
@@ -71,7 +76,19 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
             T.ent[at] = (uint32_t)p;
             T.code[at] = inter[p];
         }
-        ent_base += (size_t)np;
+    };
+    {
+        unsigned nt = np >= 100000 ? std::thread::hardware_concurrency() : 1u;
+        nt = nt < 1u ? 1u : (nt > 8u ? 8u : nt);
+        if (nt > fams.size()) nt = (unsigned)fams.size();
+        std::atomic<int> next{0};
+        auto worker = [&]() {
+            for (int r = next.fetch_add(1); r < (int)fams.size(); r = next.fetch_add(1)) build_family(r);
+        };
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < nt; i++) th.emplace_back(worker);
+        worker();
+        for (auto &t : th) t.join();
     }
     size_t slot_total = 0;
     for (int f = 0; f < SCT_NFAM; f++) slot_total += (size_t)sct_family_nkeys(f) + 1;

@@ -10,6 +10,6 @@ def test_core_header_on_host():
     build = os.path.join(util.HERE, "_build")
     os.makedirs(build, exist_ok=True)
     exe = os.path.join(build, "host_core_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(util.HERE, "host_core_check.cpp")])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(util.HERE, "host_core_check.cpp")])
     out = subprocess.check_output([exe]).decode()
     assert out.startswith("OK"), out

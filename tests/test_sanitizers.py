@@ -40,7 +40,7 @@ def test_core_header_and_table_builder_under_asan_ubsan():
     build = os.path.join(util.HERE, "_build")
     os.makedirs(build, exist_ok=True)
     exe = os.path.join(build, "host_core_check_asan")
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-o", exe, os.path.join(util.HERE, "host_core_check.cpp")])
     r = subprocess.run([exe], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"), timeout=1200)
     out = r.stdout.decode() + r.stderr.decode()
