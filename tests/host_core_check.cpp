@@ -684,6 +684,32 @@ int main() {
             checked++;
         }
     }
+    // 1e. a set large enough for the threaded build (sct_tables.h): all 25 families; every pattern sits once in the bucket of its
+    //     key, ids ascending inside a bucket, the families' entries follow one another
+    {
+        const int np = 120000;
+        std::vector<PatPlanes> pp((size_t)np);
+        for (auto &q : pp) q = {(uint32_t)(rng() & 0xFFFFu), (uint32_t)(rng() & 0xFFFFu)};
+        SctSeedTables T;
+        if (!sct_build_tables(pp.data(), np, 16, true, true, T) || T.nfam != SCT_NFAM_TABLES) { printf("FAIL threaded build\n"); return 1; }
+        for (int f = 0; f < SCT_NFAM_TABLES; f++) {
+            const uint32_t nk = sct_family_nkeys(f);
+            const uint32_t *o = T.off.data() + T.off_base[f];
+            if (o[0] != (uint32_t)((size_t)f * np) || o[nk] != (uint32_t)((size_t)(f + 1) * np)) { printf("FAIL threaded build: family %d range\n", f); return 1; }
+            for (uint32_t k = 0; k < nk; k++) {
+                if (o[k] > o[k + 1]) { printf("FAIL threaded build: offsets of family %d\n", f); return 1; }
+                for (uint32_t g = o[k]; g < o[k + 1]; g++) {
+                    const uint32_t p = T.ent[g];
+                    const uint32_t key = f >= SCT_F_WIDE0 ? sct_wide_pattern_key(f - SCT_F_WIDE0, pp[p].x, pp[p].y) : sct_pattern_key(f, pp[p].x, pp[p].y);
+                    if (key != k || (g > o[k] && T.ent[g - 1] >= p)) { printf("FAIL threaded build: entry of family %d\n", f); return 1; }
+                    uint32_t code = 0;
+                    for (int j = 0; j < 16; j++) code |= (((pp[p].x >> j) & 1u) | (((pp[p].y >> j) & 1u) << 1)) << (2 * j);
+                    if (T.code[g] != code) { printf("FAIL threaded build: code of family %d\n", f); return 1; }
+                }
+            }
+            checked += np;
+        }
+    }
     // 2. transposed Wu-Manber + seed completeness, bl = 16, texts 0..31, planted copies with 0..3 edits
     for (int it = 0; it < 300000; it++) {
         const int m = 16, alpha = (it % 7 == 0) ? 2 : 4;
