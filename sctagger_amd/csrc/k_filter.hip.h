@@ -50,8 +50,8 @@ struct LaneResult {
     }
     // Wave-cooperative store (every lane of the wave must call it; `row` says whether the lane owns a row).
     // The hit lists of the wave are written back to back into the dense `slots` array: one wave-wide prefix sum
-    // of the list lengths and one 64-bit atomic per wave reserve the space, slot_off[r] remembers where row r's
-    // list starts.  Rows with too many ties are pushed to the scan list instead.
+    // of the list lengths and one 64-bit atomic per wave reserve the space, wave_base[first / 64] remembers where the
+    // wave's lists start (see below).  Rows with too many ties are pushed to the retry list instead.
     // `slots_cap` = entries the slot array holds: a wave whose lists would run past it defers all its rows (the main
     // launch's array holds K_SLOTS entries for every row and cannot overflow; the retry launch's is sized for the usual case).
     // `line`: the wave's rows are 64 consecutive ones starting at r - lane and their min_e bytes are written as one line
@@ -721,7 +721,7 @@ struct FilterWave {
 // THIRDS = true (max_err <= 1 only) walks the 20/22-bit families of the thirds scheme instead of the quarters.
 // KS / HM: ties kept per segment / verified matches kept per segment before the row is deferred.  The main launch
 // (KS 8, HM 16) covers all rows; rows it defers are retried by a launch with KS 32, HM 64 over the list `rows`
-// (16 listed rows per wave), and only what that launch defers again goes to the exhaustive scan.
+// (16 listed rows per wave with slots, 4 without), and only what that launch defers again goes to the exhaustive scan.
 // RT = true: barcode length `bl` (8..16) other than 16, piece boundaries computed at run time (sct_family_rt).
 // SL = true: lookups read bucket slots (FilterWave); chosen by the host while few buckets are longer than a slot.
 // OffT: type of the CSR offsets (FilterArgs).
@@ -1043,7 +1043,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     }
 }
 
-// RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows, so that the pair compaction of
+// RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows (4 without slots), so that the pair compaction of
 // run_family spreads each row's lookups over four lanes and the few retried rows finish sooner.  The waves
 // of the retry launch — whose row count only exists on the device when it is queued — and of the 64-bit instantiation —
 // which usually has nothing to do — come as a small fixed grid and stride over the rows.

@@ -16,7 +16,7 @@
 //   per LANE (a stream with its own buffers; lane 0 serves the resident three-step API, lanes 0..2 the chunks of the
 //   stream API in turn):
 //     segments   the rows' ASCII bytes + CSR offsets (int64 as uploaded, or uint32 relative to the chunk)
-//     results    min_e u8[n], cnt u32[n], slot_off u64[n] + dense slots u32[] (filter path), hit_offs i64[n+1],
+//     results    min_e u8[n], cnt u32[n], wave_base u64[n/64] (+ slot_off u64[n] for retried rows) + dense slots u32[] (filter path), hit_offs i64[n+1],
 //                hits u32[total], and a 64-byte counter record (CTR_*) the host reads back once per batch
 //
 // A batch (all resident rows, or one chunk) is queued WITHOUT any host synchronisation: main filter launch, retry launch
