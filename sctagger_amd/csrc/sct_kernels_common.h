@@ -11,6 +11,10 @@ static constexpr uint32_t CNT_MASK = 0x7FFFFFFFu;
 // keys long) 0.98 / 0.73 ms, 35 k (2.4 %) 1.09 / 0.97, 50 k (7 %) 1.27 / 1.55, 100 k (35 %) 2.01 / 5.09;
 // e <= 1: 50 k 0.54 / 0.51, 70 k (17 %) 0.58 / 0.76.
 static constexpr double SLOTS_MAX_LONG_SHARE_E2 = 0.035, SLOTS_MAX_LONG_SHARE_E1 = 0.10;
+// The slot kernels put every entry of a long bucket that shares a verified candidate's rest characters on the hit list by reading
+// the bucket again (FilterWave::record): fine for the handful of entries a long bucket usually has, quadratic for a set in which
+// one sequence is listed under thousands of ids.  Such sets use the plain tables (entries queued by index, no second pass).
+static constexpr uint32_t SLOTS_MAX_BUCKET = 256;
 static constexpr int THIRDS_MIN_PATTERNS = 1 << 19;  // from here on (8 barcodes per 16-bit bucket) the thirds scheme pays
 // max_err = 2: from here on (524 288 barcodes) the sixteen 20-bit families are built and used.  Measured per 1 M segments, quarter
 // scheme / wide scheme (tools/wide_sweep.sh, 10^6 segments/s): 100 k barcodes 778 / 283, 400 k 188 / 144, 500 k 141 / 134,

@@ -22,6 +22,7 @@ struct SctSeedTables {
     std::vector<uint64_t> slot;
     std::vector<uint32_t> grp;             // per quarter family SCT_GRP_PER_FAM words: entry index at the first key of every group of 64 keys
     double long_share = 1.0;               // share of the quarter families' keys whose bucket does not fit a slot
+    uint32_t max_bucket = 0;               // entries in the longest bucket of the quarter families
 };
 
 // pat[p].x / .y: bit-planes of pattern p (np patterns of bl characters, 8 <= bl <= 16); thirds / wide: also build the
@@ -94,6 +95,7 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
     for (int f = 0; f < SCT_NFAM; f++) slot_total += (size_t)sct_family_nkeys(f) + 1;
     T.slot.assign(slot_total, 0ull);
     T.grp.assign((size_t)SCT_NFAM * SCT_GRP_PER_FAM, 0u);
+    T.max_bucket = 0;
     size_t long_keys = 0;
     for (int f = 0; f < SCT_NFAM; f++) {
         const SctFamilyRT fam = sct_family_rt(f, bl);
@@ -103,6 +105,7 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
         for (uint32_t g = 0; g < SCT_GRP_PER_FAM; g++) grp[g] = o[(size_t)g << SCT_GRP_SHIFT < SCT_KEYS ? (size_t)g << SCT_GRP_SHIFT : SCT_KEYS];
         for (uint32_t k = 0; k < sct_family_nkeys(f); k++) {
             const uint32_t cnt = o[k + 1] - o[k];
+            if (cnt > T.max_bucket) T.max_bucket = cnt;
             const uint32_t within = o[k] - grp[k >> SCT_GRP_SHIFT];
             // (a short bucket behind thousands of entries of its own group cannot say where it starts: it is listed as a long one)
             if (cnt <= 3 && within <= SCT_SLOT_WITHIN_MAX) {

@@ -191,6 +191,7 @@ struct sct_ctx {
     // barcodes
     int n_bc = 0, bl = 0, np = 0;
     bool have_bc = false, have_tables = false, have_thirds = false, have_wide = false;
+    uint32_t max_bucket = 0;  // longest bucket of the quarter families (SLOTS_MAX_BUCKET)
     int tables_nfam = 0;   // families the seed tables hold (entry indices run up to tables_nfam * np)
     FamTables ft{};
     DevBuf pat, tab_off, tab_ent, tab_code, tab_slot, tab_grp, tab_ent16;
@@ -449,6 +450,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             FamTables ft{};
             for (int f = 0; f < SCT_NFAM_TABLES; f++) ft.off_base[f] = tb.off_base[f];
             c->long_share = tb.long_share;
+            c->max_bucket = tb.max_bucket;
             if (tb.slot.size() != SLOT_TOTAL) {
                 rc = fail(SCT_E_STATE, "seed tables: unexpected slot count");
                 break;
@@ -515,7 +517,8 @@ static int batch_params(sct_ctx *c, int32_t max_err, int32_t threads, int count_
     bp.use_thirds = bp.filter_ok && c->have_thirds && max_err <= 1 && !c->no_thirds;
     bp.use_wide = bp.filter_ok && c->have_wide && max_err == 2 && c->wide_mode != 0;
     bp.use_slots = c->bl == 16 && !bp.use_thirds && !bp.use_wide &&
-                   (c->slots_mode < 0 ? c->long_share <= (max_err <= 1 ? SLOTS_MAX_LONG_SHARE_E1 : SLOTS_MAX_LONG_SHARE_E2) : c->slots_mode == 1);
+                   (c->slots_mode < 0 ? c->long_share <= (max_err <= 1 ? SLOTS_MAX_LONG_SHARE_E1 : SLOTS_MAX_LONG_SHARE_E2) && c->max_bucket <= SLOTS_MAX_BUCKET
+                                       : c->slots_mode == 1);
     bp.count_format = count_format;
     return SCT_OK;
 }
