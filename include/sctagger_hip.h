@@ -177,7 +177,15 @@ int sct_last_timing_ex(sct_ctx *ctx, const char **names, float *ms, int32_t *lau
 
 /* Counters of the last sct_run / sct_match_stream / sct_match: [0] segments on the seed-filter path, [1] segments on the exhaustive
  * path, [2] segments on the restricted-start (non-ACGT, k>0) path, [3] total hits, [4] segments the filter path
- * retried with larger lists (more than 6 or 8 verified matches, by the seed tables in use). Returns count or <0. */
+ * retried with larger lists (more than 6 or 8 verified matches, by the seed tables in use), [5] the seed scheme the filter path
+ * used (SCT_SCHEME_*). Fills up to cap entries; returns the number of counters there are (6), or <0. */
+enum {
+    SCT_SCHEME_NONE = 0,            /* no seed filter: every row went to the exhaustive scan / restricted-start DP */
+    SCT_SCHEME_QUARTER_SLOTS = 1,   /* six 16-bit quarter-pair families answered from 8-byte bucket slots (small barcode sets) */
+    SCT_SCHEME_QUARTER_TABLES = 2,  /* the same families through offset / entry tables (larger sets, barcode lengths 8..15) */
+    SCT_SCHEME_THIRDS = 3,          /* 20/22-bit families over barcode thirds (max_err <= 1, >= 2^19 patterns) */
+    SCT_SCHEME_WIDE = 4             /* sixteen 20-bit families, quarter pair + half a quarter (max_err = 2, >= 2^20 patterns) */
+};
 int sct_last_stats(sct_ctx *ctx, int64_t *out, int cap);
 
 /*

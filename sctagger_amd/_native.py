@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsctagger_hip.so")
+SCHEME_NAMES = {0: "none", 1: "quarter_slots", 2: "quarter_tables", 3: "thirds", 4: "wide"}  # SCT_SCHEME_* (sct_last_stats [5])
 
 NO_HIT = 0xFF
 MAX_BL = 32
@@ -334,8 +335,9 @@ class Matcher:
         return strand[:n], dist[:n], loc_offs, locs
 
     def last_stats(self):
-        out = (ctypes.c_int64 * 5)()
-        k = self._lib.sct_last_stats(self._ctx, out, 5)
+        out = (ctypes.c_int64 * 6)()
+        k = self._lib.sct_last_stats(self._ctx, out, 6)
         if k < 0:
             self._check(k)
-        return {"filter": out[0], "exhaustive": out[1], "restricted_start": out[2], "hits": out[3], "retried": out[4]}
+        return {"filter": out[0], "exhaustive": out[1], "restricted_start": out[2], "hits": out[3], "retried": out[4],
+                "scheme": SCHEME_NAMES.get(int(out[5]), str(out[5]))}

@@ -192,6 +192,7 @@ struct sct_ctx {
     int n_bc = 0, bl = 0, np = 0;
     bool have_bc = false, have_tables = false, have_thirds = false, have_wide = false;
     uint32_t max_bucket = 0;  // longest bucket of the quarter families (SLOTS_MAX_BUCKET)
+    int last_scheme = SCT_SCHEME_NONE;  // seed scheme of the last match call (sct_last_stats [5])
     int tables_nfam = 0;   // families the seed tables hold (entry indices run up to tables_nfam * np)
     FamTables ft{};
     DevBuf pat, tab_off, tab_ent, tab_code, tab_slot, tab_grp, tab_ent16;
@@ -520,6 +521,8 @@ static int batch_params(sct_ctx *c, int32_t max_err, int32_t threads, int count_
                    (c->slots_mode < 0 ? c->long_share <= (max_err <= 1 ? SLOTS_MAX_LONG_SHARE_E1 : SLOTS_MAX_LONG_SHARE_E2) && c->max_bucket <= SLOTS_MAX_BUCKET
                                        : c->slots_mode == 1);
     bp.count_format = count_format;
+    c->last_scheme = !bp.filter_ok ? SCT_SCHEME_NONE : bp.use_thirds ? SCT_SCHEME_THIRDS : bp.use_wide ? SCT_SCHEME_WIDE
+                     : (bp.use_slots && !bp.rt_families) ? SCT_SCHEME_QUARTER_SLOTS : SCT_SCHEME_QUARTER_TABLES;
     return SCT_OK;
 }
 
@@ -1333,7 +1336,8 @@ extern "C" int sct_last_timing(sct_ctx *c, const char **names, float *ms, int ca
 extern "C" int sct_last_stats(sct_ctx *c, int64_t *out, int cap) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
     for (int i = 0; i < 5 && i < cap; i++) out[i] = c->stats[i];
-    return 5;
+    if (cap > 5) out[5] = c->last_scheme;
+    return 6;
 }
 
 // ------------------------------------------------------------------------------------------------------------

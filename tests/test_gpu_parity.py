@@ -387,8 +387,12 @@ def test_bucket_longer_than_the_slot_length_field(m, e):
         m.set_option("slots", sl)
         a = m.match(segs, offs, e, 1)
         util.assert_same(a, want, "filter path, slots=%d" % sl)
-        assert m.last_stats()["filter"] > 0
+        st = m.last_stats()
+        assert st["filter"] > 0 and st["scheme"] == ("quarter_slots" if sl else "quarter_tables"), st
     m.set_option("slots", -1)
+    # left to itself the library does not use the slots for such a set (the slot kernels re-read a bucket per verified hit)
+    util.assert_same(m.match(segs, offs, e, 1), want, "filter path, default tables")
+    assert m.last_stats()["scheme"] == "quarter_tables"
 
 
 def test_context_reuse_across_table_kinds(m):
@@ -555,10 +559,11 @@ def test_wide_scheme_equals_quarters(m):
     segs, offs = ragged(6000, bc, 23, 60)
     m.set_barcodes(bc)
     a = m.match(segs, offs, 2, 16)
-    assert m.last_stats()["exhaustive"] == 0
+    assert m.last_stats()["exhaustive"] == 0 and m.last_stats()["scheme"] == "wide"
     m.set_option("wide", 0)
     try:
         b = m.match(segs, offs, 2, 16)
+        assert m.last_stats()["scheme"] == "quarter_tables"
     finally:
         m.set_option("wide", -1)
     util.assert_same(a, b, "wide vs quarters")
@@ -576,8 +581,10 @@ def test_thirds_scheme_equals_quarters(m, e):
     m.set_barcodes(bc)
     m.set_option("no_thirds", 0)
     a = m.match(segs, offs, e, 16)
+    assert m.last_stats()["scheme"] == "thirds"
     m.set_option("no_thirds", 1)
     b = m.match(segs, offs, e, 16)
+    assert m.last_stats()["scheme"] == "quarter_tables"
     m.set_option("no_thirds", 0)
     util.assert_same(a, b, "thirds vs quarters")
     k = 400
