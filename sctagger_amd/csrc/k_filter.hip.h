@@ -950,7 +950,11 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         constexpr int PER = (int)((CAP + 63) / 64);
         constexpr uint32_t SENT = 0xFFFFFFFFu;
         const bool ovf = SL ? nc > CAP : FW::overflowed(hc, L.best[lane]);
+#ifdef SCT_ABLATE_FINISH  // timing-only build: the lists are cut to one entry before they are folded (results are wrong)
+        const uint32_t n_own = (active && !ovf) ? (nc < 1u ? nc : 1u) : 0u;
+#else
         const uint32_t n_own = (active && !ovf) ? (nc < CAP ? nc : CAP) : 0u;
+#endif
         // pass A, row after row: strike what is not at the row's minimum, strike duplicates, count what is left
         uint32_t my_cnt = 0;
         for (int row = 0; row < RPW; row++) {
