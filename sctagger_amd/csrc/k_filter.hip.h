@@ -164,6 +164,7 @@ static constexpr uint32_t LOC_INLINE = 1u << 29;         // locator of an inline
 // concatenated entry tables (family f's entries start at f * np)
 struct FamTables {
     uint32_t off_base[SCT_NFAM_TABLES];
+    uint32_t fb_base[3];   // thirds families: where each one's fixed buckets start in tab_fb (16-bit entries)
     uint32_t pid16;  // the pattern ids are also held in 16 bits (fewer than 65 536 patterns): half the footprint
 };
 
@@ -218,7 +219,7 @@ struct EmLds {
 static constexpr uint32_t QM_INLINE = 0x80000000u;
 static constexpr size_t SLOT_TOTAL = (size_t)SCT_NFAM * (SCT_KEYS + 1);  // slots of the six quarter families
 
-template <int E, typename W, int HM, bool SL, int RPW = 64, bool WIDE = false>
+template <int E, typename W, int HM, bool SL, int RPW = 64, bool WIDE = false, bool THIRDS = false>
 struct FilterWave {
     static constexpr int HMAX = HM;
     // hit list entries per row: the LDS array hlist[HM][64] is shared out among the wave's RPW rows, entry k of row r at
@@ -226,6 +227,9 @@ struct FilterWave {
     static constexpr int CAP = HM * 64 / RPW;
     __device__ __forceinline__ uint32_t &hl(uint32_t k, uint32_t row) { return (&L.hlist[0][0])[k * (uint32_t)RPW + row]; }
     static constexpr int QCAP = QueueCap<SL, HM, W>::value;
+    // an inline locator is LOC_INLINE | (index of the key among all offsets) << LOC_J_BITS | position in the bucket: 3 entries
+    // per bucket slot, 16 per fixed bucket
+    static constexpr int LOC_J_BITS = THIRDS ? 5 : 2;
     FilterWaveLds<W, HM, QCAP, WIDE> &L;
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
@@ -233,6 +237,7 @@ struct FilterWave {
     const uint2 *__restrict__ tab_slot;     // bucket slots, indexed like tab_off
     const uint32_t *__restrict__ tab_grp;   // entry index at the first key of every group of 64 keys (quarter families)
     const uint16_t *__restrict__ tab_ent16; // tab_ent in 16 bits (fewer than 65 536 patterns)
+    const uint16_t *__restrict__ tab_fb;    // fixed buckets of the thirds families (NULL: not built / switched off)
     FamTables ft;
     int lane;
     bool active;
@@ -350,7 +355,7 @@ struct FilterWave {
             const bool vy = 2u * (uint32_t)lane + 1u < nq;
             uint32_t gx = L.qk[i0], gy = vy ? L.qk[i0 + 1] : gx;
             const uint32_t mx = L.qm[i0], my = vy ? L.qm[i0 + 1] : mx;
-            const bool ix = SL && (mx & QM_INLINE) != 0u, iy = SL && (my & QM_INLINE) != 0u;
+            const bool ix = (SL || THIRDS) && (mx & QM_INLINE) != 0u, iy = (SL || THIRDS) && (my & QM_INLINE) != 0u;
             uint32_t rx = gx, ry = gy;  // an inline entry carries its rest characters (bits above them are ignored)
             if (!ix) rx = sct_rest_of(fam, tab_code[gx]);
             if (!iy) ry = sct_rest_of(fam, tab_code[gy]);
@@ -363,14 +368,14 @@ struct FilterWave {
             // what is kept is the entry's LOCATOR; the pattern ids are read once, when the segment is finished
             if (dx <= (uint32_t)E) {
                 if (ix)
-                    gx = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[sx].lo, L.pl[sx].hi, tx, t2x)) << 2) |
-                         ((mx >> 24) & 3u);
+                    gx = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[sx].lo, L.pl[sx].hi, tx, t2x)) << LOC_J_BITS) |
+                         ((mx >> 24) & ((1u << LOC_J_BITS) - 1u));
                 insert_hit(sx, dx, gx);
             }
             if (vy && dy <= (uint32_t)E) {
                 if (iy)
-                    gy = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[sy].lo, L.pl[sy].hi, ty, t2y)) << 2) |
-                         ((my >> 24) & 3u);
+                    gy = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[sy].lo, L.pl[sy].hi, ty, t2y)) << LOC_J_BITS) |
+                         ((my >> 24) & ((1u << LOC_J_BITS) - 1u));
                 insert_hit(sy, dy, gy);
             }
         }
@@ -384,6 +389,10 @@ struct FilterWave {
     // misses were 60 % of the kernel's memory-side traffic.
     __device__ __forceinline__ uint32_t resolve(uint32_t loc) const {
         uint32_t idx = loc;
+        if (THIRDS && (loc & LOC_INLINE)) {   // entry j of the key's bucket: the offsets say where the bucket starts
+            const uint32_t l = loc & (LOC_INLINE - 1u);
+            idx = tab_off[l >> LOC_J_BITS] + (l & ((1u << LOC_J_BITS) - 1u));
+        }
         if (SL && (loc & LOC_INLINE)) {
             const uint32_t l = loc & (LOC_INLINE - 1u), oi = l >> 2, j = l & 3u;
             const uint32_t f = oi / (uint32_t)(SCT_KEYS + 1), key = oi - f * (uint32_t)(SCT_KEYS + 1);
@@ -648,6 +657,111 @@ struct FilterWave {
         }
     }
 
+    // One family of the thirds scheme through its FIXED BUCKETS (sct_tables.h): every key owns room for CAPE 16-bit entries
+    // — rest characters | 0x8000 — in one aligned block, so a lookup reads ONE line and has everything a verification
+    // needs; offsets and entry tables are read only for a verified match (its pattern id) and for the rare bucket that holds more
+    // than CAPE entries (first entry = 0x4000).  With offsets + codes every lookup cost two lines nothing else had touched:
+    // 81 missed lines per segment at 3.6 M barcodes, 3.4 TB/s of random reads (profiles/r02e_cfg5_counters.json).
+    template <int CAPW>
+    struct FbBucket {
+        uint32_t w[CAPW];  // two entries per word
+    };
+    template <typename Fam, int CAPW>
+    __device__ __forceinline__ void push_fb(const Fam &fam, const FbBucket<CAPW> &bk, uint32_t meta, const uint32_t *off) {
+        const bool over = (bk.w[0] & 0x4000u) != 0u;
+#pragma unroll
+        for (int j = 0; j < 2 * CAPW; j++) {
+            const uint32_t e = (bk.w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            const bool has = (e & 0x8000u) != 0u;
+            const uint64_t m = __ballot(has);
+            if (m == 0) break;  // a bucket is filled from its first place on
+            if (has) {
+                const uint32_t idx = (tail + lane_rank(m)) & (QCAP - 1);
+                L.qk[idx] = e & 0x0FFFu;
+                L.qm[idx] = meta | ((uint32_t)j << 24) | QM_INLINE;
+            }
+            tail += (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (tail - head >= 128u) {
+                verify2w(fam, 128u);
+                head += 128u;
+            }
+        }
+        if (__ballot(over) != 0) {  // more entries than a fixed bucket holds: through the offsets, entry by entry
+            uint32_t a = 0, b = 0;
+            if (over) {
+                const uint32_t sl = meta & 63u;
+                const int t = (int)((meta >> 8) & 63u), t2 = (int)((meta >> 16) & 63u);
+                const OffPair op = *reinterpret_cast<const OffPair *>(off + sct_key_of<W>(fam, L.pl[sl].lo, L.pl[sl].hi, t, t2));
+                a = op.a;
+                b = op.b;
+            }
+            push_range(fam, a, b, meta);
+        }
+    }
+    template <typename Fam>
+    __device__ __forceinline__ void run_family_fb(const Fam &fam, int maxlen) {
+        static_assert(THIRDS && !SL, "fixed buckets belong to the thirds families");
+        constexpr int CAPW = SCT_FB_CAP(Fam::KEYCH) / 2;  // T01 (20-bit keys): 16 entries, T12 / T02 (22-bit keys): 8
+        const uint64_t am = __ballot(active);
+        if (am == 0) return;
+        const int A = (int)__popcll(am);
+        if (active) L.alist[lane_rank(am)] = (uint8_t)lane;
+        int P = 0;
+#pragma unroll
+        for (int d = -fam.SLACK; d <= fam.SLACK; d++) {
+            const int c = maxlen - fam.GAP - d - fam.LB + 1;
+            if (c > 0) {
+                for (int t = lane; t < c; t += 64) L.ptab[P + t] = (uint16_t)(t | ((t + fam.GAP + d) << 8));
+                P += c;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (P == 0) return;
+        const uint32_t inv = 65536u / (uint32_t)A + 1u;
+        int p = (int)(((uint32_t)lane * inv) >> 16);
+        const int a = lane - p * A;
+        const int dp = 64 / A;
+        const bool worker = p < dp;
+        const int passes = (P + dp - 1) / dp;
+        const uint32_t sl = L.alist[a];
+        const W slo = L.pl[sl].lo, shi = L.pl[sl].hi;
+        const int slen = (int)L.slen[sl];
+        const uint32_t *off = tab_off + ft.off_base[fam.INDEX];
+        const uint4 *fb = reinterpret_cast<const uint4 *>(tab_fb + ft.fb_base[Fam::INDEX - SCT_F_T01]);
+        FbBucket<CAPW> prev{};
+        uint32_t pmeta = 0;
+        bool pend = false;
+        for (int pass = 0; pass < passes; pass++) {
+            FbBucket<CAPW> cur{};
+            uint32_t meta = 0;
+            if (worker && p < P) {
+                const uint32_t tt = L.ptab[p];
+                const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
+                if (sct_valid_of(fam, t2, slen)) {
+                    const uint32_t key = sct_key_of<W>(fam, slo, shi, t, t2);
+#pragma unroll
+                    for (int q = 0; q < CAPW / 4; q++) {
+                        const uint4 v = fb[(size_t)key * (CAPW / 4) + q];
+                        cur.w[4 * q + 0] = v.x;
+                        cur.w[4 * q + 1] = v.y;
+                        cur.w[4 * q + 2] = v.z;
+                        cur.w[4 * q + 3] = v.w;
+                    }
+                    meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
+                }
+            }
+            p += dp;
+            if (pend) push_fb(fam, prev, pmeta, off);
+            pend = true;
+            prev = cur;
+            pmeta = meta;
+        }
+        if (pend) push_fb(fam, prev, pmeta, off);
+        if (tail != head) verify2w(fam, tail - head);
+        head = tail = 0;
+    }
+
     // One family of the wide scheme (sct_core.h, SctWide<WF>): the lookups of run_family's table variant with a third piece in
     // the key — placements are (t, t2, u) —; what is queued and how it is verified is the quarter pair's business (Base).
     template <int WF>
@@ -740,6 +854,7 @@ struct FilterArgs {
     const uint2 *tab_slot;
     const uint32_t *tab_grp;
     const uint16_t *tab_ent16;
+    const uint16_t *tab_fb;       // fixed buckets of the thirds families, or NULL
     FamTables ft;
     uint8_t *min_e;
     uint8_t *cnt8;                // NULL, or where the rows' hit counts go as one byte each (the caller's compact format)
@@ -851,7 +966,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     constexpr bool THIRDS = SCHEME == SCHEME_THIRDS, WIDE = SCHEME == SCHEME_WIDE;
     static_assert(!(SL && (SCHEME != SCHEME_QUARTERS || RT)), "bucket slots exist for the 16-character quarter families only");
     static_assert(!WIDE || (E == 2 && !RT), "the wide families are those of max_err = 2 and 16-character barcodes");
-    FilterWave<E, W, HM, SL, RPW, WIDE> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.ft, lane, active, len, lo, hi};
+    FilterWave<E, W, HM, SL, RPW, WIDE, THIRDS> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.tab_fb, a.ft, lane, active, len, lo, hi};
 #define RUN_FAMILY(FID)                                                         \
     do {                                                                        \
         if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \
@@ -882,12 +997,21 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         W_.template run_family_wide<13>(maxlen);
         W_.template run_family_wide<14>(maxlen);
         W_.template run_family_wide<15>(maxlen);
-    } else if (THIRDS) {
-        RUN_FAMILY(SCT_F_T01);
-        if (E >= 1) {
-            W_.settle(0);
-            RUN_FAMILY(SCT_F_T12);
-            RUN_FAMILY(SCT_F_T02);
+    } else if constexpr (THIRDS) {
+        if (a.tab_fb != nullptr) {
+            W_.run_family_fb(SctFamily<SCT_F_T01>{}, maxlen);
+            if (E >= 1) {
+                W_.settle(0);
+                W_.run_family_fb(SctFamily<SCT_F_T12>{}, maxlen);
+                W_.run_family_fb(SctFamily<SCT_F_T02>{}, maxlen);
+            }
+        } else {
+            RUN_FAMILY(SCT_F_T01);
+            if (E >= 1) {
+                W_.settle(0);
+                RUN_FAMILY(SCT_F_T12);
+                RUN_FAMILY(SCT_F_T02);
+            }
         }
     } else {
         RUN_FAMILY(SCT_F_H1);
@@ -910,7 +1034,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
 #undef RUN_FAMILY
     // Locators -> pattern ids, in place, by all lanes of the wave: with RPW rows per wave, 64 / RPW lanes share a row's
     // list, up to four table reads in flight per lane.
-    using FW = FilterWave<E, W, HM, SL, RPW, WIDE>;
+    using FW = FilterWave<E, W, HM, SL, RPW, WIDE, THIRDS>;
     constexpr uint32_t CAP = (uint32_t)FW::CAP;
     {
         constexpr int PARTS = 64 / RPW;

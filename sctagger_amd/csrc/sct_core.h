@@ -351,6 +351,11 @@ SCT_HD void sct_for_each_wide_placement(int len, Fn &&fn) {
 }
 SCT_HD bool sct_wide_valid(int t2, int u, int len) { return t2 + 4 <= len && u + 2 <= len; }
 
+// Fixed buckets of the thirds families (sct_tables.h, k_filter.hip.h run_family_fb): 16-bit entries per key, by key length
+#define SCT_FB_CAP(keych) ((keych) == 10 ? 16 : 8)
+#define SCT_FB_VALID 0x8000u     // entry: rest characters (at most 6 = 12 bits) | SCT_FB_VALID
+#define SCT_FB_OVERFLOW 0x4000u  // first entry of a key with more entries than its bucket holds: use the offsets
+
 // Seed placements: the pair of text positions (t, t2) at which the two pieces are looked for.  A placement is
 // valid for a text of length L iff the second piece ends inside it: t2 + LB <= L.  Kernels walk the placements
 // wave-uniformly up to the longest length in the wave and test validity per lane; the host-side completeness

@@ -4,6 +4,7 @@
 // Per family f that is built (sct_core.h; the six quarter families always, the thirds and the wide families on request): an
 // offsets array of nkeys(f) + 1 entries holding ABSOLUTE indices into the entry tables (the families' entries follow one
 // another, np each), the entries as pattern ids (ascending inside a bucket) and as 2-bit codes, and
+// — for the thirds families — fixed buckets (the rest characters of up to SCT_FB_CAP entries per key in one aligned block), and
 // — for the six quarter families — one 8-byte bucket slot per key (sct_slot_*), indexed like the offsets, and the entry
 // index at the start of every group of 64 keys (an inline slot says where its entries start inside its group).
 #pragma once
@@ -23,6 +24,8 @@ struct SctSeedTables {
     std::vector<uint32_t> grp;             // per quarter family SCT_GRP_PER_FAM words: entry index at the first key of every group of 64 keys
     double long_share = 1.0;               // share of the quarter families' keys whose bucket does not fit a slot
     uint32_t max_bucket = 0;               // entries in the longest bucket of the quarter families
+    std::vector<uint16_t> fb;              // thirds families: fixed buckets (SCT_FB_CAP entries per key), family after family
+    uint32_t fb_base[3] = {0, 0, 0};       // where each thirds family's buckets start in fb (entries)
 };
 
 // pat[p].x / .y: bit-planes of pattern p (np patterns of bl characters, 8 <= bl <= 16); thirds / wide: also build the
@@ -90,6 +93,48 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
         for (unsigned i = 1; i < nt; i++) th.emplace_back(worker);
         worker();
         for (auto &t : th) t.join();
+    }
+    // fixed buckets of the thirds families: the rest characters of up to SCT_FB_CAP entries per key in one aligned block, in the
+    // order of the entry tables (entry j of the block is entry off[key] + j)
+    T.fb.clear();
+    if (thirds) {
+        size_t total = 0;
+        for (int f = SCT_NFAM; f < SCT_NFAM_ALL; f++) {
+            const int keych = f == SCT_F_T01 ? 10 : 11;
+            if (total > 0xFFFFFFFFull) return false;
+            T.fb_base[f - SCT_NFAM] = (uint32_t)total;
+            total += (size_t)sct_family_nkeys(f) * SCT_FB_CAP(keych);
+        }
+        T.fb.assign(total, (uint16_t)0);
+        auto fill = [&](int f) {
+            const int keych = f == SCT_F_T01 ? 10 : 11;
+            const uint32_t cap = SCT_FB_CAP(keych), nk = sct_family_nkeys(f);
+            const uint32_t *o = T.off.data() + T.off_base[f];
+            uint16_t *out = T.fb.data() + T.fb_base[f - SCT_NFAM];
+            for (uint32_t k = 0; k < nk; k++) {
+                const uint32_t b = o[k], n = o[k + 1] - b;
+                uint16_t *blk = out + (size_t)k * cap;
+                if (n > cap) {
+                    blk[0] = (uint16_t)SCT_FB_OVERFLOW;
+                    continue;
+                }
+                for (uint32_t j = 0; j < n; j++) {
+                    uint32_t rest;
+                    if (f == SCT_F_T01) rest = sct_rest_of(SctFamily<SCT_F_T01>{}, T.code[b + j]);
+                    else if (f == SCT_F_T12) rest = sct_rest_of(SctFamily<SCT_F_T12>{}, T.code[b + j]);
+                    else rest = sct_rest_of(SctFamily<SCT_F_T02>{}, T.code[b + j]);
+                    blk[j] = (uint16_t)((rest & 0x0FFFu) | SCT_FB_VALID);
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        if (np >= 100000) {
+            for (int f = SCT_NFAM + 1; f < SCT_NFAM_ALL; f++) th.emplace_back(fill, f);
+            fill(SCT_NFAM);
+            for (auto &t : th) t.join();
+        } else {
+            for (int f = SCT_NFAM; f < SCT_NFAM_ALL; f++) fill(f);
+        }
     }
     size_t slot_total = 0;
     for (int f = 0; f < SCT_NFAM; f++) slot_total += (size_t)sct_family_nkeys(f) + 1;

@@ -190,12 +190,12 @@ struct sct_ctx {
     int device = 0;
     // barcodes
     int n_bc = 0, bl = 0, np = 0;
-    bool have_bc = false, have_tables = false, have_thirds = false, have_wide = false;
+    bool have_bc = false, have_tables = false, have_thirds = false, have_wide = false, have_fb = false;
     uint32_t max_bucket = 0;  // longest bucket of the quarter families (SLOTS_MAX_BUCKET)
     int last_scheme = SCT_SCHEME_NONE;  // seed scheme of the last match call (sct_last_stats [5])
     int tables_nfam = 0;   // families the seed tables hold (entry indices run up to tables_nfam * np)
     FamTables ft{};
-    DevBuf pat, tab_off, tab_ent, tab_code, tab_slot, tab_grp, tab_ent16;
+    DevBuf pat, tab_off, tab_ent, tab_code, tab_slot, tab_grp, tab_ent16, tab_fb;
     std::vector<Lane *> lanes;  // lanes[0] always exists
     // stream API: page-locked result buffer, owned by the context, valid until the next stream call
     uint32_t *h_hits = nullptr;
@@ -207,6 +207,8 @@ struct sct_ctx {
     int32_t wl_n = -1;
     // options
     bool force_exhaustive = false, timing = true, no_thirds = false;
+    int thirds_mode = -1;  // -1 = thirds tables by the size of the set, 1 = built whatever the size (next sct_set_barcodes)
+    int fb_mode = -1;      // thirds families: -1 / 1 = lookups read the fixed buckets, 0 = offsets + codes
     int wide_mode = -1;    // -1 = by the size of the barcode set, 0 = never, 1 = build and use the wide families whatever the size
     int slots_mode = -1;       // -1 = by the share of long buckets, 0 = never, 1 = whenever the tables hold them
     double long_share = 1.0;   // share of the seed keys whose bucket does not fit a slot (sct_set_barcodes)
@@ -335,7 +337,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
         l->release();
         delete l;
     }
-    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->tab_slot, &c->tab_grp, &c->tab_ent16, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip,
+    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->tab_slot, &c->tab_grp, &c->tab_ent16, &c->tab_fb, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip,
                       &c->ad_peq, &c->ad_strand, &c->ad_dist, &c->ad_locs, &c->ad_first, &c->ad_last};
     for (DevBuf *b : bufs) b->release();
     if (c->h_hits) (void)hipHostFree(c->h_hits);
@@ -373,6 +375,8 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "force_exhaustive")) c->force_exhaustive = value != 0;
     else if (!strcmp(key, "timing")) c->timing = value != 0;
     else if (!strcmp(key, "no_thirds")) c->no_thirds = value != 0;
+    else if (!strcmp(key, "thirds")) c->thirds_mode = value < 0 ? -1 : (value != 0);
+    else if (!strcmp(key, "fixed_buckets")) c->fb_mode = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "wide")) c->wide_mode = value < 0 ? -1 : (value != 0);  // takes effect at the next sct_set_barcodes
     else if (!strcmp(key, "slots")) c->slots_mode = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "chunk_rows")) {
@@ -415,6 +419,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
     c->have_tables = false;
     c->have_thirds = false;
     c->have_wide = false;
+    c->have_fb = false;
     const int np = 2 * n;
     std::vector<uint2> pat((size_t)np);
     for (int i = 0; i < n; i++) {
@@ -438,7 +443,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
         // seed tables (sct_tables.h): counting sort of the pattern ids by key, per family, plus the bucket slots.
         // The thirds families (20/22-bit keys) are only worth their 38 MB of offsets for very large barcode sets.
         // Likewise the wide families of max_err = 2 (sixteen tables of np entries and 4 MB of offsets each).
-        const bool thirds = bl == 16 && np >= THIRDS_MIN_PATTERNS;
+        const bool thirds = bl == 16 && np > 0 && (c->thirds_mode < 0 ? np >= THIRDS_MIN_PATTERNS : c->thirds_mode == 1);
         const bool wide = bl == 16 && np > 0 && (c->wide_mode < 0 ? np >= WIDE_MIN_PATTERNS : c->wide_mode == 1);
         SctSeedTables tb;
         std::vector<uint16_t> pid16;
@@ -450,6 +455,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             }
             FamTables ft{};
             for (int f = 0; f < SCT_NFAM_TABLES; f++) ft.off_base[f] = tb.off_base[f];
+            for (int f = 0; f < 3; f++) ft.fb_base[f] = tb.fb_base[f];
             c->long_share = tb.long_share;
             c->max_bucket = tb.max_bucket;
             if (tb.slot.size() != SLOT_TOTAL) {
@@ -460,7 +466,8 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             if (ft.pid16) pid16.assign(tb.ent.begin(), tb.ent.end());
             if (c->tab_slot.ensure(tb.slot.size() * sizeof(uint64_t)) || c->tab_grp.ensure(tb.grp.size() * sizeof(uint32_t)) ||
                 c->tab_ent16.ensure(pid16.size() * sizeof(uint16_t) + 16) || c->tab_off.ensure(tb.off.size() * sizeof(uint32_t) + 16) ||
-                c->tab_ent.ensure(tb.ent.size() * sizeof(uint32_t)) || c->tab_code.ensure(tb.code.size() * sizeof(uint32_t))) {
+                c->tab_ent.ensure(tb.ent.size() * sizeof(uint32_t)) || c->tab_code.ensure(tb.code.size() * sizeof(uint32_t)) ||
+                c->tab_fb.ensure(tb.fb.size() * sizeof(uint16_t) + 16)) {
                 rc = SCT_E_HIP;
                 break;
             }
@@ -471,6 +478,8 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             if (e == hipSuccess) e = hipMemcpyAsync(c->tab_code.p, tb.code.data(), tb.code.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipMemcpyAsync(c->tab_off.p, tb.off.data(), tb.off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipMemcpyAsync(c->tab_ent.p, tb.ent.data(), tb.ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess && !tb.fb.empty())
+                e = hipMemcpyAsync(c->tab_fb.p, tb.fb.data(), tb.fb.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st);
             const hipError_t es = hipStreamSynchronize(st);  // also on failure: the vectors above are about to go away
             if (e == hipSuccess) e = es;
             if (e != hipSuccess) {
@@ -481,6 +490,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             c->have_tables = true;
             c->have_thirds = thirds;
             c->have_wide = wide;
+            c->have_fb = thirds && !tb.fb.empty();
             c->tables_nfam = tb.nfam;
         } while (0);
         if (rc) {
@@ -585,6 +595,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.tab_slot = c->tab_slot.as<uint2>();
     fa.tab_grp = c->tab_grp.as<uint32_t>();
     fa.tab_ent16 = c->tab_ent16.as<uint16_t>();
+    fa.tab_fb = (c->have_fb && c->fb_mode != 0) ? c->tab_fb.as<uint16_t>() : nullptr;
     fa.ft = c->ft;
     fa.min_e = l.min_e_ptr;
     fa.cnt8 = l.cnt8_ptr;  // the filter launches write the one-byte counts themselves (queue_batch leaves them out of k_offsets)

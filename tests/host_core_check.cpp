@@ -690,6 +690,11 @@ int main() {
         const int np = 120000;
         std::vector<PatPlanes> pp((size_t)np);
         for (auto &q : pp) q = {(uint32_t)(rng() & 0xFFFFu), (uint32_t)(rng() & 0xFFFFu)};
+        // keys with more entries than a fixed bucket holds: 40 patterns under one T01 key (characters 0..9), 20 under one T12 key
+        // (5..15), 20 under one T02 key (0..4 and 10..15)
+        for (int i = 1; i < 40; i++) pp[i] = {(pp[0].x & 0x03FFu) | (pp[i].x & 0xFC00u), (pp[0].y & 0x03FFu) | (pp[i].y & 0xFC00u)};
+        for (int i = 41; i < 60; i++) pp[i] = {(pp[40].x & 0xFFE0u) | (pp[i].x & 0x001Fu), (pp[40].y & 0xFFE0u) | (pp[i].y & 0x001Fu)};
+        for (int i = 61; i < 80; i++) pp[i] = {(pp[60].x & 0xFC1Fu) | (pp[i].x & 0x03E0u), (pp[60].y & 0xFC1Fu) | (pp[i].y & 0x03E0u)};
         SctSeedTables T;
         if (!sct_build_tables(pp.data(), np, 16, true, true, T) || T.nfam != SCT_NFAM_TABLES) { printf("FAIL threaded build\n"); return 1; }
         for (int f = 0; f < SCT_NFAM_TABLES; f++) {
@@ -709,6 +714,31 @@ int main() {
             }
             checked += np;
         }
+        // the fixed buckets of the thirds families repeat the rest characters of the entry tables, entry j of a key at place j;
+        // a key with more entries than its bucket holds says so in its first place
+        int overflowing = 0;
+        for (int f = SCT_F_T01; f <= SCT_F_T02; f++) {
+            const uint32_t nk = sct_family_nkeys(f), cap = SCT_FB_CAP(f == SCT_F_T01 ? 10 : 11);
+            const uint32_t *o = T.off.data() + T.off_base[f];
+            const uint16_t *fb = T.fb.data() + T.fb_base[f - SCT_F_T01];
+            for (uint32_t k = 0; k < nk; k++) {
+                const uint32_t n = o[k + 1] - o[k];
+                for (uint32_t j = 0; j < cap; j++) {
+                    uint32_t want = 0;
+                    if (n > cap) { want = j == 0 ? SCT_FB_OVERFLOW : 0; overflowing += j == 0; }
+                    else if (j < n) {
+                        const uint32_t code = T.code[o[k] + j];
+                        const uint32_t rest = f == SCT_F_T01 ? sct_rest_of(SctFamily<SCT_F_T01>{}, code)
+                                              : f == SCT_F_T12 ? sct_rest_of(SctFamily<SCT_F_T12>{}, code) : sct_rest_of(SctFamily<SCT_F_T02>{}, code);
+                        if (rest > 0x0FFFu) { printf("FAIL fixed buckets: rest of family %d has more than 12 bits\n", f); return 1; }
+                        want = rest | SCT_FB_VALID;
+                    }
+                    if (fb[(size_t)k * cap + j] != want) { printf("FAIL fixed buckets: family %d key %u place %u\n", f, k, j); return 1; }
+                }
+            }
+            checked += nk;
+        }
+        if (overflowing < 3) { printf("FAIL fixed buckets: the overflowing keys of the test set are not marked\n"); return 1; }
     }
     // 2. transposed Wu-Manber + seed completeness, bl = 16, texts 0..31, planted copies with 0..3 edits
     for (int it = 0; it < 300000; it++) {

@@ -552,6 +552,40 @@ def test_cfg5_scale_barcode_set(m):
     assert np.array_equal(a[0][:k], want[0]) and np.array_equal(a[2][:a[1][k]], want[2])
 
 
+def test_thirds_keys_with_more_entries_than_a_fixed_bucket(m):
+    """The thirds families keep up to 16 / 8 entries of a key in a fixed bucket; a key with more falls back to offsets + codes.
+    40 barcodes under one T01 key (characters 0..9), 20 under one T12 key (5..15), 20 under one T02 key (0..4 + 10..15), thirds
+    tables forced on the small set; planted rows with up to one edit against the oracle and the exhaustive scan."""
+    rng = np.random.default_rng(31)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    base = rng.integers(0, 4, size=(3, 16))
+    rows = []
+    for i in range(40):
+        r = base[0].copy(); r[10:] = rng.integers(0, 4, size=6); rows.append(r)
+    for i in range(20):
+        r = base[1].copy(); r[:5] = rng.integers(0, 4, size=5); rows.append(r)
+    for i in range(20):
+        r = base[2].copy(); r[5:10] = rng.integers(0, 4, size=5); rows.append(r)
+    bc = np.unique(acgt[np.array(rows)], axis=0)
+    bc = np.concatenate([bc, synth.make_barcodes(300, seed=32)])
+    segs, offs = synth.make_segments(3000, bc, seed=33)
+    m.set_option("thirds", 1)
+    try:
+        for e in (0, 1):
+            want = trie_oracle.match(bc, segs, offs, e, threads=16, workers=8)
+            m.set_barcodes(bc)
+            a = m.match(segs, offs, e, 16)
+            st = m.last_stats()
+            assert st["scheme"] == "thirds" and st["exhaustive"] == 0, st
+            util.assert_same(a, want, "thirds with overflowing fixed buckets, e=%d" % e)
+            m.set_option("fixed_buckets", 0)
+            util.assert_same(m.match(segs, offs, e, 16), want, "thirds through offsets, e=%d" % e)
+            m.set_option("fixed_buckets", -1)
+    finally:
+        m.set_option("thirds", -1)
+        m.set_option("fixed_buckets", -1)
+
+
 def test_wide_scheme_equals_quarters(m):
     """From 2^20 patterns on, max_err = 2 uses the sixteen 20-bit 'wide' seed families (sct_core.h); they must agree with the
     16-bit quarter families (option wide = 0) and with the oracle — ragged rows, both mask widths, ties by the dozen."""
@@ -582,6 +616,11 @@ def test_thirds_scheme_equals_quarters(m, e):
     m.set_option("no_thirds", 0)
     a = m.match(segs, offs, e, 16)
     assert m.last_stats()["scheme"] == "thirds"
+    m.set_option("fixed_buckets", 0)        # lookups through offsets + codes instead of the fixed buckets
+    try:
+        util.assert_same(m.match(segs, offs, e, 16), a, "thirds: offsets + codes vs fixed buckets")
+    finally:
+        m.set_option("fixed_buckets", -1)
     m.set_option("no_thirds", 1)
     b = m.match(segs, offs, e, 16)
     assert m.last_stats()["scheme"] == "quarter_tables"

@@ -13,6 +13,10 @@ segs, offs = bench.make_batch(n, bc, 5)
 m = _native.Matcher(0)
 if os.environ.get("SCT_WIDE"):   # -1 = by size, 0 = never, 1 = always
     m.set_option("wide", int(os.environ["SCT_WIDE"]))
+if os.environ.get("SCT_THIRDS"):  # -1 = by size, 0 = never, 1 = always
+    m.set_option("thirds", int(os.environ["SCT_THIRDS"]))
+if os.environ.get("SCT_FB"):     # thirds families: 0 = offsets + codes instead of the fixed buckets
+    m.set_option("fixed_buckets", int(os.environ["SCT_FB"]))
 t0 = time.perf_counter()
 m.set_barcodes(bc)
 t_set = time.perf_counter() - t0
@@ -21,7 +25,7 @@ m.run(e, 16)
 t0 = time.perf_counter(); m.run(e, 16); dt = time.perf_counter() - t0
 a = m.download()
 cnt = np.diff(a[1])
-print(json.dumps({"segments": n, "barcodes": nbc, "max_err": e, "set_barcodes_s": round(t_set, 3), "wide": os.environ.get("SCT_WIDE", "auto"), "seconds": round(dt, 4), "segments_per_s": n / dt, "stats": m.last_stats(),
+print(json.dumps({"segments": n, "barcodes": nbc, "max_err": e, "set_barcodes_s": round(t_set, 3), "wide": os.environ.get("SCT_WIDE", "auto"), "fixed_buckets": os.environ.get("SCT_FB", "auto"), "seconds": round(dt, 4), "segments_per_s": n / dt, "stats": m.last_stats(),
                   "timing_ms": {k: round(v, 3) for k, v in m.last_timing()},
                   "ties_percentiles_50_90_99_999_max": [int(np.percentile(cnt, q)) for q in (50, 90, 99, 99.9)] + [int(cnt.max())],
                   "share_rows_with_more_than_8_32_240_ties": [float((cnt > k).mean()) for k in (8, 32, 240)],
