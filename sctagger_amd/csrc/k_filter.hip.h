@@ -229,7 +229,15 @@ struct FilterWave {
     static constexpr int QCAP = QueueCap<SL, HM, W>::value;
     // an inline locator is LOC_INLINE | (index of the key among all offsets) << LOC_J_BITS | position in the bucket: 3 entries
     // per bucket slot, 16 per fixed bucket
-    static constexpr int LOC_J_BITS = THIRDS ? 5 : 2;
+    static constexpr int LOC_J_BITS = (THIRDS || WIDE) ? 5 : 2;
+    // wide families: bits 6-7 and 14-15 of a queue entry's meta word carry the key's four half bits (lo plane, hi plane)
+    __device__ static __forceinline__ uint32_t meta_kb4(uint32_t mx) { return ((mx >> 6) & 3u) | (((mx >> 14) & 3u) << 2); }
+    template <typename Fam>
+    __device__ __forceinline__ uint32_t inline_locator(const Fam &fam, uint32_t mx, uint32_t sx, int tx, int t2x) const {
+        const uint32_t key = sct_key_of<W>(fam, L.pl[sx].lo, L.pl[sx].hi, tx, t2x), j = (mx >> 24) & ((1u << LOC_J_BITS) - 1u);
+        if constexpr (WIDE) return LOC_INLINE | ((((wf_ << 20) | (meta_kb4(mx) << 16) | key) << LOC_J_BITS) | j);
+        else return LOC_INLINE | ((ft.off_base[fam.INDEX] + key) << LOC_J_BITS) | j;
+    }
     FilterWaveLds<W, HM, QCAP, WIDE> &L;
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
@@ -238,12 +246,14 @@ struct FilterWave {
     const uint32_t *__restrict__ tab_grp;   // entry index at the first key of every group of 64 keys (quarter families)
     const uint16_t *__restrict__ tab_ent16; // tab_ent in 16 bits (fewer than 65 536 patterns)
     const uint16_t *__restrict__ tab_fb;    // fixed buckets of the thirds families (NULL: not built / switched off)
+    const uint16_t *__restrict__ tab_wfb;   // fixed buckets of the wide families (NULL: not built / switched off)
     FamTables ft;
     int lane;
     bool active;
     int len;
     W lo, hi;
     uint32_t head = 0, tail = 0;  // wave-uniform
+    uint32_t wf_ = 0;             // the wide family whose candidates are in the queue (their inline locators carry it)
 
     // PK (bucket slots, texts of at most 31 characters): the queue holds ONE word per candidate and a lane verifies TWO
     // candidates at once, one in each 16-bit half of the automaton's words (wm_anchored_pair, sct_core.h), 128 per
@@ -355,7 +365,7 @@ struct FilterWave {
             const bool vy = 2u * (uint32_t)lane + 1u < nq;
             uint32_t gx = L.qk[i0], gy = vy ? L.qk[i0 + 1] : gx;
             const uint32_t mx = L.qm[i0], my = vy ? L.qm[i0 + 1] : mx;
-            const bool ix = (SL || THIRDS) && (mx & QM_INLINE) != 0u, iy = (SL || THIRDS) && (my & QM_INLINE) != 0u;
+            const bool ix = (SL || THIRDS || WIDE) && (mx & QM_INLINE) != 0u, iy = (SL || THIRDS || WIDE) && (my & QM_INLINE) != 0u;
             uint32_t rx = gx, ry = gy;  // an inline entry carries its rest characters (bits above them are ignored)
             if (!ix) rx = sct_rest_of(fam, tab_code[gx]);
             if (!iy) ry = sct_rest_of(fam, tab_code[gy]);
@@ -367,15 +377,11 @@ struct FilterWave {
             const uint32_t dx = r & 0xFFFFu, dy = r >> 16;
             // what is kept is the entry's LOCATOR; the pattern ids are read once, when the segment is finished
             if (dx <= (uint32_t)E) {
-                if (ix)
-                    gx = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[sx].lo, L.pl[sx].hi, tx, t2x)) << LOC_J_BITS) |
-                         ((mx >> 24) & ((1u << LOC_J_BITS) - 1u));
+                if (ix) gx = inline_locator(fam, mx, sx, tx, t2x);
                 insert_hit(sx, dx, gx);
             }
             if (vy && dy <= (uint32_t)E) {
-                if (iy)
-                    gy = LOC_INLINE | ((ft.off_base[fam.INDEX] + sct_key_of<W>(fam, L.pl[sy].lo, L.pl[sy].hi, ty, t2y)) << LOC_J_BITS) |
-                         ((my >> 24) & ((1u << LOC_J_BITS) - 1u));
+                if (iy) gy = inline_locator(fam, my, sy, ty, t2y);
                 insert_hit(sy, dy, gy);
             }
         }
@@ -389,6 +395,10 @@ struct FilterWave {
     // misses were 60 % of the kernel's memory-side traffic.
     __device__ __forceinline__ uint32_t resolve(uint32_t loc) const {
         uint32_t idx = loc;
+        if (WIDE && (loc & LOC_INLINE)) {     // (wide family, key, j): the families' offsets follow one another, nkeys + 1 each
+            const uint32_t l = loc & (LOC_INLINE - 1u), kk = l >> LOC_J_BITS;
+            idx = tab_off[ft.off_base[SCT_F_WIDE0] + (kk >> 20) * (SCT_WIDE_KEYS + 1u) + (kk & (SCT_WIDE_KEYS - 1u))] + (l & ((1u << LOC_J_BITS) - 1u));
+        }
         if (THIRDS && (loc & LOC_INLINE)) {   // entry j of the key's bucket: the offsets say where the bucket starts
             const uint32_t l = loc & (LOC_INLINE - 1u);
             idx = tab_off[l >> LOC_J_BITS] + (l & ((1u << LOC_J_BITS) - 1u));
@@ -764,11 +774,51 @@ struct FilterWave {
 
     // One family of the wide scheme (sct_core.h, SctWide<WF>): the lookups of run_family's table variant with a third piece in
     // the key — placements are (t, t2, u) —; what is queued and how it is verified is the quarter pair's business (Base).
+    // Fixed buckets as for the thirds: 16 entries per key, each the SIX rest characters that are not in the key; the half's two
+    // characters come back from the key when the entry is queued (sct_wide_rest16), so the automaton sees the pair's usual rest.
+    template <int WF, typename Fam>
+    __device__ __forceinline__ void push_wfb(const Fam &fam, const FbBucket<8> &bk, uint32_t meta, const uint32_t *off) {
+        constexpr int POS = SctWide<WF>::POS;
+        const bool over = (bk.w[0] & SCT_FB_OVERFLOW) != 0u;
+        const uint32_t kb4 = meta_kb4(meta);
+        // plane bits (character 0 and 1 of the half: lo bits 0-1, hi bits 2-3) -> two 2-bit codes
+        const uint32_t half4 = (kb4 & 1u) | (((kb4 >> 2) & 1u) << 1) | (((kb4 >> 1) & 1u) << 2) | (((kb4 >> 3) & 1u) << 3);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t e = (bk.w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            const bool has = (e & SCT_FB_VALID) != 0u;
+            const uint64_t m = __ballot(has);
+            if (m == 0) break;
+            if (has) {
+                const uint32_t idx = (tail + lane_rank(m)) & (QCAP - 1);
+                L.qk[idx] = sct_wide_rest16(e & 0x0FFFu, half4, POS);
+                L.qm[idx] = meta | ((uint32_t)j << 24) | QM_INLINE;
+            }
+            tail += (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (tail - head >= 128u) {
+                verify2w(fam, 128u);
+                head += 128u;
+            }
+        }
+        if (__ballot(over) != 0) {
+            uint32_t a = 0, b = 0;
+            if (over) {
+                const uint32_t sl = meta & 63u;
+                const int t = (int)((meta >> 8) & 63u), t2 = (int)((meta >> 16) & 63u);
+                const OffPair op = *reinterpret_cast<const OffPair *>(off + (sct_key_of<W>(fam, L.pl[sl].lo, L.pl[sl].hi, t, t2) | (kb4 << 16)));
+                a = op.a;
+                b = op.b;
+            }
+            push_range(fam, a, b, meta);
+        }
+    }
     template <int WF>
-    __device__ __forceinline__ void run_family_wide(int maxlen) {
+    __device__ __forceinline__ void run_family_wide_fb(int maxlen) {
         static_assert(WIDE && !SL, "the wide families come with the plain tables");
         using F = SctWide<WF>;
         const typename F::Base fam{};
+        wf_ = (uint32_t)WF;
         const uint64_t am = __ballot(active);
         if (am == 0) return;
         const int A = (int)__popcll(am);
@@ -802,29 +852,37 @@ struct FilterWave {
         const W slo = L.pl[sl].lo, shi = L.pl[sl].hi;
         const int slen = (int)L.slen[sl];
         const uint32_t *off = tab_off + ft.off_base[F::INDEX];
-        uint32_t ps = 0, pe = 0, pmeta = 0;
+        const uint4 *fb = reinterpret_cast<const uint4 *>(tab_wfb + ((size_t)WF * SCT_WIDE_KEYS) * SCT_WIDE_FB_CAP);
+        FbBucket<8> prev{};
+        uint32_t pmeta = 0;
         bool pend = false;
         for (int pass = 0; pass < passes; pass++) {
-            uint32_t s = 0, e = 0, meta = 0;
+            FbBucket<8> cur{};
+            uint32_t meta = 0;
             if (worker && p < P) {
                 const uint32_t tt = L.ptab[p];
                 const int t = (int)(tt & 0xFFu), t2 = (int)((tt >> 8) & 0xFFu), u = (int)(tt >> 16);
                 if (sct_wide_valid(t2, u, slen)) {
                     const uint32_t key = sct_wide_key<WF, W>(slo, shi, t, t2, u);
-                    const OffPair op = *reinterpret_cast<const OffPair *>(off + key);
-                    s = op.a;
-                    e = op.b;
-                    meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const uint4 v = fb[(size_t)key * 2 + q];
+                        cur.w[4 * q + 0] = v.x;
+                        cur.w[4 * q + 1] = v.y;
+                        cur.w[4 * q + 2] = v.z;
+                        cur.w[4 * q + 3] = v.w;
+                    }
+                    const uint32_t kb4 = key >> 16;
+                    meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16) | ((kb4 & 3u) << 6) | ((kb4 >> 2) << 14);
                 }
             }
             p += dp;
-            if (pend) push_range(fam, ps, pe, pmeta);
+            if (pend) push_wfb<WF>(fam, prev, pmeta, off);
             pend = true;
-            ps = s;
-            pe = e;
+            prev = cur;
             pmeta = meta;
         }
-        if (pend) push_range(fam, ps, pe, pmeta);
+        if (pend) push_wfb<WF>(fam, prev, pmeta, off);
         if (tail != head) verify2w(fam, tail - head);
         head = tail = 0;
     }
@@ -855,6 +913,7 @@ struct FilterArgs {
     const uint32_t *tab_grp;
     const uint16_t *tab_ent16;
     const uint16_t *tab_fb;       // fixed buckets of the thirds families, or NULL
+    const uint16_t *tab_wfb;      // fixed buckets of the wide families, or NULL
     FamTables ft;
     uint8_t *min_e;
     uint8_t *cnt8;                // NULL, or where the rows' hit counts go as one byte each (the caller's compact format)
@@ -966,37 +1025,39 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     constexpr bool THIRDS = SCHEME == SCHEME_THIRDS, WIDE = SCHEME == SCHEME_WIDE;
     static_assert(!(SL && (SCHEME != SCHEME_QUARTERS || RT)), "bucket slots exist for the 16-character quarter families only");
     static_assert(!WIDE || (E == 2 && !RT), "the wide families are those of max_err = 2 and 16-character barcodes");
-    FilterWave<E, W, HM, SL, RPW, WIDE, THIRDS> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.tab_fb, a.ft, lane, active, len, lo, hi};
+    FilterWave<E, W, HM, SL, RPW, WIDE, THIRDS> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.tab_fb, a.tab_wfb, a.ft, lane, active, len, lo, hi};
 #define RUN_FAMILY(FID)                                                         \
     do {                                                                        \
         if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \
         else W_.run_family(SctFamily<FID>{}, maxlen);                           \
     } while (0)
     if constexpr (WIDE) {
-        W_.template run_family_wide<0>(maxlen);
+      {   // (the wide families are only reached through their fixed buckets: the host never launches this variant without them)
+        W_.template run_family_wide_fb<0>(maxlen);
         W_.settle(0);
-        W_.template run_family_wide<1>(maxlen);
-        W_.template run_family_wide<3>(maxlen);
-        W_.template run_family_wide<4>(maxlen);
+        W_.template run_family_wide_fb<1>(maxlen);
+        W_.template run_family_wide_fb<3>(maxlen);
+        W_.template run_family_wide_fb<4>(maxlen);
         W_.settle(1);
         W_.give_up();
-        W_.template run_family_wide<2>(maxlen);
+        W_.template run_family_wide_fb<2>(maxlen);
         W_.give_up();
-        W_.template run_family_wide<5>(maxlen);
+        W_.template run_family_wide_fb<5>(maxlen);
         W_.give_up();
-        W_.template run_family_wide<6>(maxlen);
-        W_.template run_family_wide<7>(maxlen);
-        W_.template run_family_wide<8>(maxlen);
+        W_.template run_family_wide_fb<6>(maxlen);
+        W_.template run_family_wide_fb<7>(maxlen);
+        W_.template run_family_wide_fb<8>(maxlen);
         W_.give_up();
-        W_.template run_family_wide<9>(maxlen);
-        W_.template run_family_wide<10>(maxlen);
+        W_.template run_family_wide_fb<9>(maxlen);
+        W_.template run_family_wide_fb<10>(maxlen);
         W_.give_up();
-        W_.template run_family_wide<11>(maxlen);
-        W_.template run_family_wide<12>(maxlen);
+        W_.template run_family_wide_fb<11>(maxlen);
+        W_.template run_family_wide_fb<12>(maxlen);
         W_.give_up();
-        W_.template run_family_wide<13>(maxlen);
-        W_.template run_family_wide<14>(maxlen);
-        W_.template run_family_wide<15>(maxlen);
+        W_.template run_family_wide_fb<13>(maxlen);
+        W_.template run_family_wide_fb<14>(maxlen);
+        W_.template run_family_wide_fb<15>(maxlen);
+      }
     } else if constexpr (THIRDS) {
         if (a.tab_fb != nullptr) {
             W_.run_family_fb(SctFamily<SCT_F_T01>{}, maxlen);

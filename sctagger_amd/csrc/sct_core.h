@@ -19,6 +19,7 @@
 
 SCT_HD uint32_t sct_code(uint8_t b) { return b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 0u; }
 SCT_HD bool sct_is_acgt(uint8_t b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
+SCT_HD uint32_t sct_low_bits(int k) { return k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u); }
 
 // ---------------------------------------------------------------------------------------------------
 // Four ASCII bytes at once (one aligned 32-bit word of a segment) -> three nibbles, bit j = byte j of the word:
@@ -305,7 +306,24 @@ struct SctWide {
     static constexpr bool COUPLED = WF == 15;
     static constexpr int INDEX = SCT_F_WIDE0 + WF;
     static constexpr uint32_t NKEYS = SCT_WIDE_KEYS;
+    // where the half sits among the 8 characters outside the quarter pair (the pair's `rest`, in barcode order)
+    static constexpr int POS = PC - (Base::PA < PC ? 4 : 0) - (Base::PB < PC ? 4 : 0);
 };
+// the pair's 16-bit rest without / with the half's two characters (the half is part of the key: a fixed bucket keeps the other six)
+SCT_HD uint32_t sct_wide_rest12(uint32_t r16, int pos) { return (r16 & sct_low_bits(2 * pos)) | ((r16 >> (2 * pos + 4)) << (2 * pos)); }
+SCT_HD uint32_t sct_wide_rest16(uint32_t r12, uint32_t half4, int pos) {
+    return (r12 & sct_low_bits(2 * pos)) | (half4 << (2 * pos)) | ((r12 >> (2 * pos)) << (2 * pos + 4));
+}
+SCT_HD int sct_wide_pos(int wf) {
+    switch (wf) {
+    case 0: return SctWide<0>::POS; case 1: return SctWide<1>::POS; case 2: return SctWide<2>::POS; case 3: return SctWide<3>::POS;
+    case 4: return SctWide<4>::POS; case 5: return SctWide<5>::POS; case 6: return SctWide<6>::POS; case 7: return SctWide<7>::POS;
+    case 8: return SctWide<8>::POS; case 9: return SctWide<9>::POS; case 10: return SctWide<10>::POS; case 11: return SctWide<11>::POS;
+    case 12: return SctWide<12>::POS; case 13: return SctWide<13>::POS; case 14: return SctWide<14>::POS; default: return SctWide<15>::POS;
+    }
+}
+SCT_HD int sct_wide_base(int wf) { return wf < 3 ? SCT_F_H1 : wf < 6 ? SCT_F_H2 : wf < 9 ? SCT_F_MID : wf < 11 ? SCT_F_02 : wf < 13 ? SCT_F_13 : SCT_F_03; }
+#define SCT_WIDE_FB_CAP 16
 // key: the pair's 16 bits, then the half's two lo-plane bits and its two hi-plane bits
 template <int WF, typename W>
 SCT_HD uint32_t sct_wide_key(W lo, W hi, int t, int t2, int u) {
@@ -455,7 +473,6 @@ SCT_HD W sct_valid_mask(int len) {
 // The characters of a barcode OUTSIDE the two pieces of `fam`, in barcode order, 2 bits each from bit 0 (at most 8
 // characters for the quarter families of any length 8..16): all the automaton below needs of a candidate, since the
 // piece characters are the key it was found under.
-SCT_HD uint32_t sct_low_bits(int k) { return k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u); }
 template <typename Fam>
 SCT_HD uint32_t sct_rest_of(const Fam &fam, uint32_t code) {
     const int n0 = fam.PA, s1 = fam.PA + fam.LA, n1 = fam.PB - s1, s2 = fam.PB + fam.LB, n2 = fam.BL - s2;

@@ -26,6 +26,7 @@ struct SctSeedTables {
     uint32_t max_bucket = 0;               // entries in the longest bucket of the quarter families
     std::vector<uint16_t> fb;              // thirds families: fixed buckets (SCT_FB_CAP entries per key), family after family
     uint32_t fb_base[3] = {0, 0, 0};       // where each thirds family's buckets start in fb (entries)
+    std::vector<uint16_t> wfb;             // wide families: fixed buckets, SCT_WIDE_FB_CAP entries per key, family wf at wf << 24
 };
 
 // pat[p].x / .y: bit-planes of pattern p (np patterns of bl characters, 8 <= bl <= 16); thirds / wide: also build the
@@ -134,6 +135,41 @@ static inline bool sct_build_tables(const Pat *pat, int np, int bl, bool thirds,
             for (auto &t : th) t.join();
         } else {
             for (int f = SCT_NFAM; f < SCT_NFAM_ALL; f++) fill(f);
+        }
+    }
+    // fixed buckets of the wide families: the six rest characters that are not in the key (sct_wide_rest12)
+    T.wfb.clear();
+    if (wide) {
+        T.wfb.assign((size_t)SCT_NWIDE * SCT_WIDE_KEYS * SCT_WIDE_FB_CAP, (uint16_t)0);
+        auto fill = [&](int wf) {
+            const int f = SCT_F_WIDE0 + wf, pos = sct_wide_pos(wf);
+            const SctFamilyRT base = sct_family_rt(sct_wide_base(wf), 16);
+            const uint32_t *o = T.off.data() + T.off_base[f];
+            uint16_t *out = T.wfb.data() + ((size_t)wf * SCT_WIDE_KEYS) * SCT_WIDE_FB_CAP;
+            for (uint32_t k = 0; k < SCT_WIDE_KEYS; k++) {
+                const uint32_t b = o[k], n = o[k + 1] - b;
+                uint16_t *blk = out + (size_t)k * SCT_WIDE_FB_CAP;
+                if (n > SCT_WIDE_FB_CAP) {
+                    blk[0] = (uint16_t)SCT_FB_OVERFLOW;
+                    continue;
+                }
+                for (uint32_t j = 0; j < n; j++)
+                    blk[j] = (uint16_t)(sct_wide_rest12(sct_rest_of(base, T.code[b + j]) & 0xFFFFu, pos) | SCT_FB_VALID);
+            }
+        };
+        if (np >= 100000) {
+            unsigned nt = std::thread::hardware_concurrency();
+            nt = nt < 1u ? 1u : (nt > 8u ? 8u : nt);
+            std::atomic<int> next{0};
+            auto worker = [&]() {
+                for (int wf = next.fetch_add(1); wf < SCT_NWIDE; wf = next.fetch_add(1)) fill(wf);
+            };
+            std::vector<std::thread> th;
+            for (unsigned i = 1; i < nt; i++) th.emplace_back(worker);
+            worker();
+            for (auto &t : th) t.join();
+        } else {
+            for (int wf = 0; wf < SCT_NWIDE; wf++) fill(wf);
         }
     }
     size_t slot_total = 0;

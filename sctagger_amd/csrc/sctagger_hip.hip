@@ -190,12 +190,12 @@ struct sct_ctx {
     int device = 0;
     // barcodes
     int n_bc = 0, bl = 0, np = 0;
-    bool have_bc = false, have_tables = false, have_thirds = false, have_wide = false, have_fb = false;
+    bool have_bc = false, have_tables = false, have_thirds = false, have_wide = false, have_fb = false, have_wfb = false;
     uint32_t max_bucket = 0;  // longest bucket of the quarter families (SLOTS_MAX_BUCKET)
     int last_scheme = SCT_SCHEME_NONE;  // seed scheme of the last match call (sct_last_stats [5])
     int tables_nfam = 0;   // families the seed tables hold (entry indices run up to tables_nfam * np)
     FamTables ft{};
-    DevBuf pat, tab_off, tab_ent, tab_code, tab_slot, tab_grp, tab_ent16, tab_fb;
+    DevBuf pat, tab_off, tab_ent, tab_code, tab_slot, tab_grp, tab_ent16, tab_fb, tab_wfb;
     std::vector<Lane *> lanes;  // lanes[0] always exists
     // stream API: page-locked result buffer, owned by the context, valid until the next stream call
     uint32_t *h_hits = nullptr;
@@ -337,7 +337,7 @@ extern "C" void sct_destroy(sct_ctx *c) {
         l->release();
         delete l;
     }
-    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->tab_slot, &c->tab_grp, &c->tab_ent16, &c->tab_fb, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip,
+    DevBuf *bufs[] = {&c->pat, &c->tab_off, &c->tab_ent, &c->tab_code, &c->tab_slot, &c->tab_grp, &c->tab_ent16, &c->tab_fb, &c->tab_wfb, &c->wl_table, &c->wl_counts, &c->wl_first, &c->wl_skip,
                       &c->ad_peq, &c->ad_strand, &c->ad_dist, &c->ad_locs, &c->ad_first, &c->ad_last};
     for (DevBuf *b : bufs) b->release();
     if (c->h_hits) (void)hipHostFree(c->h_hits);
@@ -420,6 +420,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
     c->have_thirds = false;
     c->have_wide = false;
     c->have_fb = false;
+    c->have_wfb = false;
     const int np = 2 * n;
     std::vector<uint2> pat((size_t)np);
     for (int i = 0; i < n; i++) {
@@ -467,7 +468,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             if (c->tab_slot.ensure(tb.slot.size() * sizeof(uint64_t)) || c->tab_grp.ensure(tb.grp.size() * sizeof(uint32_t)) ||
                 c->tab_ent16.ensure(pid16.size() * sizeof(uint16_t) + 16) || c->tab_off.ensure(tb.off.size() * sizeof(uint32_t) + 16) ||
                 c->tab_ent.ensure(tb.ent.size() * sizeof(uint32_t)) || c->tab_code.ensure(tb.code.size() * sizeof(uint32_t)) ||
-                c->tab_fb.ensure(tb.fb.size() * sizeof(uint16_t) + 16)) {
+                c->tab_fb.ensure(tb.fb.size() * sizeof(uint16_t) + 16) || c->tab_wfb.ensure(tb.wfb.size() * sizeof(uint16_t) + 16)) {
                 rc = SCT_E_HIP;
                 break;
             }
@@ -480,6 +481,8 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             if (e == hipSuccess) e = hipMemcpyAsync(c->tab_ent.p, tb.ent.data(), tb.ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
             if (e == hipSuccess && !tb.fb.empty())
                 e = hipMemcpyAsync(c->tab_fb.p, tb.fb.data(), tb.fb.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess && !tb.wfb.empty())
+                e = hipMemcpyAsync(c->tab_wfb.p, tb.wfb.data(), tb.wfb.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st);
             const hipError_t es = hipStreamSynchronize(st);  // also on failure: the vectors above are about to go away
             if (e == hipSuccess) e = es;
             if (e != hipSuccess) {
@@ -491,6 +494,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
             c->have_thirds = thirds;
             c->have_wide = wide;
             c->have_fb = thirds && !tb.fb.empty();
+            c->have_wfb = wide && !tb.wfb.empty();
             c->tables_nfam = tb.nfam;
         } while (0);
         if (rc) {
@@ -526,7 +530,7 @@ static int batch_params(sct_ctx *c, int32_t max_err, int32_t threads, int count_
     bp.filter_ok = c->have_tables && max_err <= 2 && !c->force_exhaustive && c->np > 0 && (uint64_t)c->tables_nfam * (uint64_t)c->np < LOC_INLINE;
     bp.rt_families = c->bl != 16;  // quarter families with run-time piece boundaries
     bp.use_thirds = bp.filter_ok && c->have_thirds && max_err <= 1 && !c->no_thirds;
-    bp.use_wide = bp.filter_ok && c->have_wide && max_err == 2 && c->wide_mode != 0;
+    bp.use_wide = bp.filter_ok && c->have_wide && c->have_wfb && max_err == 2 && c->wide_mode != 0;
     bp.use_slots = c->bl == 16 && !bp.use_thirds && !bp.use_wide &&
                    (c->slots_mode < 0 ? c->long_share <= (max_err <= 1 ? SLOTS_MAX_LONG_SHARE_E1 : SLOTS_MAX_LONG_SHARE_E2) && c->max_bucket <= SLOTS_MAX_BUCKET
                                        : c->slots_mode == 1);
@@ -596,6 +600,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.tab_grp = c->tab_grp.as<uint32_t>();
     fa.tab_ent16 = c->tab_ent16.as<uint16_t>();
     fa.tab_fb = (c->have_fb && c->fb_mode != 0) ? c->tab_fb.as<uint16_t>() : nullptr;
+    fa.tab_wfb = c->have_wfb ? c->tab_wfb.as<uint16_t>() : nullptr;
     fa.ft = c->ft;
     fa.min_e = l.min_e_ptr;
     fa.cnt8 = l.cnt8_ptr;  // the filter launches write the one-byte counts themselves (queue_batch leaves them out of k_offsets)

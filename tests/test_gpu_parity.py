@@ -586,6 +586,32 @@ def test_thirds_keys_with_more_entries_than_a_fixed_bucket(m):
         m.set_option("fixed_buckets", -1)
 
 
+def test_wide_keys_with_more_entries_than_a_fixed_bucket(m):
+    """The same for the wide families of max_err = 2 (16 entries per key): 40 barcodes that share characters 0..9 (the key of W0),
+    30 that share 6..15 (W3), wide tables forced on the small set."""
+    rng = np.random.default_rng(41)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    base = rng.integers(0, 4, size=(2, 16))
+    rows = []
+    for i in range(40):
+        r = base[0].copy(); r[10:] = rng.integers(0, 4, size=6); rows.append(r)
+    for i in range(30):
+        r = base[1].copy(); r[:6] = rng.integers(0, 4, size=6); rows.append(r)
+    bc = np.unique(acgt[np.array(rows)], axis=0)
+    bc = np.concatenate([bc, synth.make_barcodes(300, seed=42)])
+    segs, offs = synth.make_segments(3000, bc, seed=43)
+    want = trie_oracle.match(bc, segs, offs, 2, threads=16, workers=8)
+    m.set_option("wide", 1)
+    try:
+        m.set_barcodes(bc)
+        a = m.match(segs, offs, 2, 16)
+        st = m.last_stats()
+        assert st["scheme"] == "wide" and st["exhaustive"] == 0, st
+        util.assert_same(a, want, "wide with overflowing fixed buckets")
+    finally:
+        m.set_option("wide", -1)
+
+
 def test_wide_scheme_equals_quarters(m):
     """From 2^20 patterns on, max_err = 2 uses the sixteen 20-bit 'wide' seed families (sct_core.h); they must agree with the
     16-bit quarter families (option wide = 0) and with the oracle — ragged rows, both mask widths, ties by the dozen."""
