@@ -654,7 +654,7 @@ int main() {
             pp[p] = {(uint32_t)lo, (uint32_t)hi};
         }
         SctSeedTables T;
-        const bool wide = bl == 16 && it % 4 == 1;  // every other 16-character set (16 x 4 MB of offsets to clear each time)
+        const bool wide = bl == 16 && it % 20 == 1;  // now and then (64 MB of offsets and 512 MB of fixed buckets to clear each time)
         if (!sct_build_tables(pp.data(), (int)pp.size(), bl, false, wide, T)) { printf("FAIL build\n"); return 1; }
         for (int k = 0; k < 30; k++) {
             std::vector<int> t;
@@ -739,6 +739,33 @@ int main() {
             checked += nk;
         }
         if (overflowing < 3) { printf("FAIL fixed buckets: the overflowing keys of the test set are not marked\n"); return 1; }
+        // wide families: a bucket entry holds the six rest characters outside the key; with the half's two characters taken from the
+        // key (plane bits -> codes, as push_wfb does) it is the quarter pair's rest again
+        int wide_over = 0;
+        for (int wf = 0; wf < SCT_NWIDE; wf++) {
+            const SctFamilyRT base = sct_family_rt(sct_wide_base(wf), 16);
+            const int pos = sct_wide_pos(wf);
+            const uint32_t *o = T.off.data() + T.off_base[SCT_F_WIDE0 + wf];
+            const uint16_t *fb = T.wfb.data() + ((size_t)wf * SCT_WIDE_KEYS) * SCT_WIDE_FB_CAP;
+            for (uint32_t k = 0; k < SCT_WIDE_KEYS; k++) {
+                const uint32_t n = o[k + 1] - o[k], kb4 = k >> 16;
+                const uint32_t half4 = (kb4 & 1u) | (((kb4 >> 2) & 1u) << 1) | (((kb4 >> 1) & 1u) << 2) | (((kb4 >> 3) & 1u) << 3);
+                for (uint32_t j = 0; j < SCT_WIDE_FB_CAP; j++) {
+                    const uint32_t e = fb[(size_t)k * SCT_WIDE_FB_CAP + j];
+                    if (n > SCT_WIDE_FB_CAP) {
+                        wide_over += j == 0;
+                        if (e != (j == 0 ? SCT_FB_OVERFLOW : 0u)) { printf("FAIL wide buckets: overflow mark, family %d\n", wf); return 1; }
+                    } else if (j >= n) {
+                        if (e != 0) { printf("FAIL wide buckets: stray entry, family %d\n", wf); return 1; }
+                    } else if (!(e & SCT_FB_VALID) || sct_wide_rest16(e & 0x0FFFu, half4, pos) != (sct_rest_of(base, T.code[o[k] + j]) & 0xFFFFu)) {
+                        printf("FAIL wide buckets: family %d key %u place %u\n", wf, k, j);
+                        return 1;
+                    }
+                }
+            }
+            checked += SCT_WIDE_KEYS;
+        }
+        if (wide_over < 1) { printf("FAIL wide buckets: no overflowing key in the test set\n"); return 1; }
     }
     // 2. transposed Wu-Manber + seed completeness, bl = 16, texts 0..31, planted copies with 0..3 edits
     for (int it = 0; it < 300000; it++) {
