@@ -393,7 +393,9 @@ static bool emulate_filter_wide(const SctSeedTables &T, const std::vector<std::v
     return want == best && want_hits == hits;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    // argv[1]: divisor of the random-case counts of sections 2 - 2c (the sanitizer build runs a quarter of them)
+    const int scale = argc > 1 && atoi(argv[1]) > 0 ? atoi(argv[1]) : 1;
     std::mt19937_64 rng(12345);
     auto rnd = [&](int n) { return (int)(rng() % (uint64_t)n); };
     long checked = 0;
@@ -768,7 +770,7 @@ int main() {
         if (wide_over < 1) { printf("FAIL wide buckets: no overflowing key in the test set\n"); return 1; }
     }
     // 2. transposed Wu-Manber + seed completeness, bl = 16, texts 0..31, planted copies with 0..3 edits
-    for (int it = 0; it < 300000; it++) {
+    for (int it = 0; it < 300000 / scale; it++) {
         const int m = 16, alpha = (it % 7 == 0) ? 2 : 4;
         int n = rnd(32);
         std::vector<int> p(m), t;
@@ -806,7 +808,7 @@ int main() {
         checked++;
     }
     // 2b. the 64-bit variant of the anchored automaton: texts of 0..63 characters
-    for (int it = 0; it < 120000; it++) {
+    for (int it = 0; it < 120000 / scale; it++) {
         const int m = 16, alpha = (it % 7 == 0) ? 2 : 4;
         int n = rnd(64);
         std::vector<int> p(m), t;
@@ -833,7 +835,7 @@ int main() {
         checked++;
     }
     // 2c. run-time piece boundaries: barcode lengths 8..16, texts 0..31
-    for (int it = 0; it < 200000; it++) {
+    for (int it = 0; it < 200000 / scale; it++) {
         const int m = 8 + rnd(9), alpha = (it % 7 == 0) ? 2 : 4;
         int n = rnd(32);
         std::vector<int> p(m), t;

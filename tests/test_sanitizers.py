@@ -42,6 +42,6 @@ def test_core_header_and_table_builder_under_asan_ubsan():
     exe = os.path.join(build, "host_core_check_asan")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-o", exe, os.path.join(util.HERE, "host_core_check.cpp")])
-    r = subprocess.run([exe], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"), timeout=1200)
+    r = subprocess.run([exe, "4"], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"), timeout=1200)
     out = r.stdout.decode() + r.stderr.decode()
     assert r.returncode == 0 and out.startswith("OK") and "runtime error" not in out, out[-4000:]
