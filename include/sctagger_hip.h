@@ -152,7 +152,7 @@ int sct_sync(sct_ctx *ctx);
  *   "thirds"          -1|0|1 -1 (default) = the thirds families are built from 2^19 patterns on, 1 = whatever the size, 0 = not built
  *                            (takes effect at the next sct_set_barcodes; "no_thirds" switches their USE off and on at any time)
  *   "fixed_buckets"   -1|0|1 thirds families: 1 / -1 (default) = a lookup reads the key's fixed bucket (one line: the rest characters of
- *                            up to 16 / 8 entries), 0 = offsets and codes (two lines).  (The wide families always use theirs.)
+ *                            up to 16 / 8 entries), 0 = offsets and codes (two lines).  (The main launch of the wide families always uses theirs.)
  *   "wide"            -1|0|1 the sixteen 20-bit seed families of max_err = 2 (sct_core.h): -1 = built and used from 2^20 patterns
  *                            (524 288 barcodes) on (default), 0 = not used, 1 = built whatever the size (takes effect at the
  *                            next sct_set_barcodes) and used

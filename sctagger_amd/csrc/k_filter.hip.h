@@ -678,11 +678,14 @@ struct FilterWave {
     };
     template <typename Fam, int CAPW>
     __device__ __forceinline__ void push_fb(const Fam &fam, const FbBucket<CAPW> &bk, uint32_t meta, const uint32_t *off) {
-        const bool over = (bk.w[0] & 0x4000u) != 0u;
-#pragma unroll
+        const bool over = (bk.w[0] & SCT_FB_OVERFLOW) != 0u;
+        FbBucket<CAPW> bb = bk;
+        // (a rolled loop that shifts the bucket down by one entry per round: unrolled, every round carries its own copy of the
+        // verification and the translation unit takes half an hour to compile)
+#pragma unroll 1
         for (int j = 0; j < 2 * CAPW; j++) {
-            const uint32_t e = (bk.w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-            const bool has = (e & 0x8000u) != 0u;
+            const uint32_t e = bb.w[0] & 0xFFFFu;
+            const bool has = (e & SCT_FB_VALID) != 0u;
             const uint64_t m = __ballot(has);
             if (m == 0) break;  // a bucket is filled from its first place on
             if (has) {
@@ -696,6 +699,9 @@ struct FilterWave {
                 verify2w(fam, 128u);
                 head += 128u;
             }
+#pragma unroll
+            for (int q = 0; q + 1 < CAPW; q++) bb.w[q] = __builtin_amdgcn_alignbit(bb.w[q + 1], bb.w[q], 16);
+            bb.w[CAPW - 1] >>= 16;
         }
         if (__ballot(over) != 0) {  // more entries than a fixed bucket holds: through the offsets, entry by entry
             uint32_t a = 0, b = 0;
@@ -783,9 +789,10 @@ struct FilterWave {
         const uint32_t kb4 = meta_kb4(meta);
         // plane bits (character 0 and 1 of the half: lo bits 0-1, hi bits 2-3) -> two 2-bit codes
         const uint32_t half4 = (kb4 & 1u) | (((kb4 >> 2) & 1u) << 1) | (((kb4 >> 1) & 1u) << 2) | (((kb4 >> 3) & 1u) << 3);
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t e = (bk.w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        FbBucket<8> bb = bk;
+#pragma unroll 1
+        for (int j = 0; j < 16; j++) {  // rolled, as in push_fb
+            const uint32_t e = bb.w[0] & 0xFFFFu;
             const bool has = (e & SCT_FB_VALID) != 0u;
             const uint64_t m = __ballot(has);
             if (m == 0) break;
@@ -800,6 +807,9 @@ struct FilterWave {
                 verify2w(fam, 128u);
                 head += 128u;
             }
+#pragma unroll
+            for (int q = 0; q + 1 < 8; q++) bb.w[q] = __builtin_amdgcn_alignbit(bb.w[q + 1], bb.w[q], 16);
+            bb.w[7] >>= 16;
         }
         if (__ballot(over) != 0) {
             uint32_t a = 0, b = 0;
@@ -883,6 +893,74 @@ struct FilterWave {
             pmeta = meta;
         }
         if (pend) push_wfb<WF>(fam, prev, pmeta, off);
+        if (tail != head) verify2w(fam, tail - head);
+        head = tail = 0;
+    }
+
+    // The same family through offsets and entry tables (two lines per lookup, fewer instructions per queued entry): what the
+    // RETRY launch uses — it is bound by its instruction count, not by the table reads (fixed buckets: 4.1 -> 4.5 ms per 1 M rows
+    // at 3.6 M barcodes, while the main launch, bound by the reads, goes 3.4 -> 2.6 ms).
+    template <int WF>
+    __device__ __forceinline__ void run_family_wide(int maxlen) {
+        static_assert(WIDE && !SL, "the wide families come with the plain tables");
+        using F = SctWide<WF>;
+        const typename F::Base fam{};
+        const uint64_t am = __ballot(active);
+        if (am == 0) return;
+        const int A = (int)__popcll(am);
+        if (active) L.alist[lane_rank(am)] = (uint8_t)lane;
+        int P = 0;
+#pragma unroll
+        for (int s = -F::SMAX; s <= F::SMAX; s++) {
+#pragma unroll
+            for (int x = -F::DMAX; x <= F::DMAX; x++) {
+                const int d = F::COUPLED ? s + x : x;
+                const int t2o = fam.GAP + d, uo = (F::FROM_B ? t2o : 0) + F::OFFC + s;
+                const int t0 = uo < 0 ? -uo : 0;
+                const int ext = t2o + fam.LB > uo + 2 ? t2o + fam.LB : uo + 2;
+                const int c = maxlen - ext - t0 + 1;
+                if (c > 0) {
+                    for (int i = lane; i < c; i += 64)
+                        L.ptab[P + i] = (uint32_t)(t0 + i) | ((uint32_t)(t0 + i + t2o) << 8) | ((uint32_t)(t0 + i + uo) << 16);
+                    P += c;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (P == 0) return;
+        const uint32_t inv = 65536u / (uint32_t)A + 1u;
+        int p = (int)(((uint32_t)lane * inv) >> 16);
+        const int a = lane - p * A;
+        const int dp = 64 / A;
+        const bool worker = p < dp;
+        const int passes = (P + dp - 1) / dp;
+        const uint32_t sl = L.alist[a];
+        const W slo = L.pl[sl].lo, shi = L.pl[sl].hi;
+        const int slen = (int)L.slen[sl];
+        const uint32_t *off = tab_off + ft.off_base[F::INDEX];
+        uint32_t ps = 0, pe = 0, pmeta = 0;
+        bool pend = false;
+        for (int pass = 0; pass < passes; pass++) {
+            uint32_t s = 0, e = 0, meta = 0;
+            if (worker && p < P) {
+                const uint32_t tt = L.ptab[p];
+                const int t = (int)(tt & 0xFFu), t2 = (int)((tt >> 8) & 0xFFu), u = (int)(tt >> 16);
+                if (sct_wide_valid(t2, u, slen)) {
+                    const uint32_t key = sct_wide_key<WF, W>(slo, shi, t, t2, u);
+                    const OffPair op = *reinterpret_cast<const OffPair *>(off + key);
+                    s = op.a;
+                    e = op.b;
+                    meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
+                }
+            }
+            p += dp;
+            if (pend) push_range(fam, ps, pe, pmeta);
+            pend = true;
+            ps = s;
+            pe = e;
+            pmeta = meta;
+        }
+        if (pend) push_range(fam, ps, pe, pmeta);
         if (tail != head) verify2w(fam, tail - head);
         head = tail = 0;
     }
@@ -1032,7 +1110,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         else W_.run_family(SctFamily<FID>{}, maxlen);                           \
     } while (0)
     if constexpr (WIDE) {
-      {   // (the wide families are only reached through their fixed buckets: the host never launches this variant without them)
+      if constexpr (RPW == 64) {   // main launch: fixed buckets (bound by the table reads); retry launch: offsets + entries
         W_.template run_family_wide_fb<0>(maxlen);
         W_.settle(0);
         W_.template run_family_wide_fb<1>(maxlen);
@@ -1057,6 +1135,31 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         W_.template run_family_wide_fb<13>(maxlen);
         W_.template run_family_wide_fb<14>(maxlen);
         W_.template run_family_wide_fb<15>(maxlen);
+      } else {
+        W_.template run_family_wide<0>(maxlen);
+        W_.settle(0);
+        W_.template run_family_wide<1>(maxlen);
+        W_.template run_family_wide<3>(maxlen);
+        W_.template run_family_wide<4>(maxlen);
+        W_.settle(1);
+        W_.give_up();
+        W_.template run_family_wide<2>(maxlen);
+        W_.give_up();
+        W_.template run_family_wide<5>(maxlen);
+        W_.give_up();
+        W_.template run_family_wide<6>(maxlen);
+        W_.template run_family_wide<7>(maxlen);
+        W_.template run_family_wide<8>(maxlen);
+        W_.give_up();
+        W_.template run_family_wide<9>(maxlen);
+        W_.template run_family_wide<10>(maxlen);
+        W_.give_up();
+        W_.template run_family_wide<11>(maxlen);
+        W_.template run_family_wide<12>(maxlen);
+        W_.give_up();
+        W_.template run_family_wide<13>(maxlen);
+        W_.template run_family_wide<14>(maxlen);
+        W_.template run_family_wide<15>(maxlen);
       }
     } else if constexpr (THIRDS) {
         if (a.tab_fb != nullptr) {
