@@ -88,6 +88,15 @@ def test_gpu_fuzz_all_paths():
             m.set_option("force_exhaustive", 0)
             m.set_option("chunk_rows", 0)
             m.set_option("slots", -1)
+            if bl == 16 and e <= 1 and n_bc > 0:   # the thirds families of large sets, forced on the small one: fixed buckets, then offsets
+                m.set_option("thirds", 1)
+                m.set_barcodes(bc, bl)
+                for fb in (-1, 0):
+                    m.set_option("fixed_buckets", fb)
+                    util.assert_same(m.match(segs, offs, e, t), want, "trial %d thirds families n_bc=%d fixed_buckets=%d" % (trial, n_bc, fb))
+                    assert m.last_stats()["scheme"] == "thirds"
+                m.set_option("fixed_buckets", -1)
+                m.set_option("thirds", -1)
             if bl == 16 and e == 2 and n_bc > 0:   # the wide seed families of large sets, forced on the small one
                 m.set_option("wide", 1)
                 m.set_barcodes(bc, bl)
