@@ -102,3 +102,14 @@ def test_gpu_fuzz_all_paths():
                 m.set_barcodes(bc, bl)
                 util.assert_same(m.match(segs, offs, e, t), want, "trial %d wide families n_bc=%d" % (trial, n_bc))
                 m.set_option("wide", -1)
+
+
+@pytest.mark.gpu
+def test_gpu_every_seed_scheme_against_the_exhaustive_scan():
+    """tools/soak.py, a few trials: slots, plain tables, thirds (fixed buckets and offsets) and wide families forced in turn on random
+    sets of up to 400 000 barcodes with ragged rows, each against the exhaustive scan of the same context."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(util.HERE), "tools", "soak.py"), os.environ.get("SCT_SOAK_TRIALS", "8"), "5"],
+                       capture_output=True, timeout=900)
+    out = r.stdout.decode() + r.stderr.decode()
+    assert r.returncode == 0 and out.strip().splitlines()[-1].startswith("OK"), out[-3000:]
