@@ -1348,8 +1348,10 @@ struct FilterWavesPerBlock {
     static constexpr int value = (RPW == 64 && sizeof(W) == 4) ? 4 : 1;
 };
 
+// The retry launch without slots waits for table reads at one-wave blocks: four waves per SIMD (at most 128 VGPRs) instead of the
+// three its 160-odd registers would allow.
 template <int E, typename W, int SCHEME, int KS, int HM, int RPW, bool RT, bool SL, typename OffT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RPW < 64 && !SL && sizeof(W) == 4) ? 4 : 1)))
 k_filter(const FilterArgs<OffT> a) {
     constexpr int WPB = FilterWavesPerBlock<W, RPW>::value;
     __shared__ FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE> lds[WPB];
