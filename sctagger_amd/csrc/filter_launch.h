@@ -1,7 +1,7 @@
 // filter_launch.h — host entry points of the seed-filter translation units (filter_e0/1/2.hip), called by sctagger_hip.hip.
 #pragma once
 struct SctFilterVariant {
-    bool retry;   // the retry launch (larger lists, 16 or 4 listed rows per wave) instead of the main one
+    bool retry;   // the retry launch (larger lists, 4 listed rows per wave) instead of the main one
     bool rt;      // barcode length other than 16: piece boundaries computed at run time
     bool slots;   // lookups read the 8-byte bucket slots
     bool thirds;  // the 20/22-bit families of very large barcode sets (max_err <= 1)

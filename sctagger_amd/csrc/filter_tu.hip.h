@@ -61,8 +61,8 @@ void launch(const SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, un
                 k_filter<E, uint64_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.slots) {
-            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, 16, false, true, OffT><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, 16, false, true, OffT><<<g64, 64, 0, st>>>(fa);
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, RETRY_RPW_SL, false, true, OffT><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, RETRY_RPW_SL, false, true, OffT><<<g64, 64, 0, st>>>(fa);
         } else {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g, 64, 0, st>>>(fa);
             k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);

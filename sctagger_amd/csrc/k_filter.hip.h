@@ -151,7 +151,9 @@ struct QueueCap {
 // 24 % instead of 16 % of the rows retried with 6).
 static constexpr int HMAX = 8, HMAX_SL = 6;  // main launch
 static constexpr int K_RETRY = 32, H_RETRY = 80;  // retry launch: 80 x 256 B of LDS hold 320 hit-list entries for each of a wave's 16 rows
-static constexpr int H_RETRY_SL = H_RETRY;
+// retry launch with slots: 4 rows per wave as well (cfg3's 8 854 retried rows: 0.105 ms with 16 rows per wave, 0.073 with 4, 0.116 with 2)
+static constexpr int RETRY_RPW_SL = 4;
+static constexpr int H_RETRY_SL = H_RETRY * RETRY_RPW_SL / 16;
 // without slots (larger barcode sets): the same 320 entries per row for 4 rows per wave — a quarter of the LDS per (one-wave) block,
 // four times the waves per CU; these launches wait for table reads and are short of waves, not of lanes.  Retry launch per 1 M
 // rows with 16 / 8 / 4 rows per wave: 3.6 M barcodes wide scheme 5.4 / 4.0 / 4.1 ms, 1 M wide 5.0 / 5.0 / 4.7, 3.6 M quarters
@@ -971,7 +973,7 @@ struct FilterWave {
 // THIRDS = true (max_err <= 1 only) walks the 20/22-bit families of the thirds scheme instead of the quarters.
 // KS / HM: ties kept per segment / verified matches kept per segment before the row is deferred.  The main launch
 // (KS 8, HM 16) covers all rows; rows it defers are retried by a launch with KS 32, HM 64 over the list `rows`
-// (16 listed rows per wave with slots, 4 without), and only what that launch defers again goes to the exhaustive scan.
+// (4 listed rows per wave), and only what that launch defers again goes to the exhaustive scan.
 // RT = true: barcode length `bl` (8..16) other than 16, piece boundaries computed at run time (sct_family_rt).
 // SL = true: lookups read bucket slots (FilterWave); chosen by the host while few buckets are longer than a slot.
 // OffT: type of the CSR offsets (FilterArgs).
@@ -1335,7 +1337,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     }
 }
 
-// RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 16 rows (4 without slots), so that the pair compaction of
+// RPW rows per wave: 64 in the main launch; the retry launch gives a wave only 4 rows, so that the pair compaction of
 // run_family spreads each row's lookups over four lanes and the few retried rows finish sooner.  The waves
 // of the retry launch — whose row count only exists on the device when it is queued — and of the 64-bit instantiation —
 // which usually has nothing to do — come as a small fixed grid and stride over the rows.

@@ -639,7 +639,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.list_defer = l.list_scan.as<int32_t>();
         fa.defer_count = ctr + CTR_SCAN;
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR_RETRY);
-        launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), capped((n + 3) / 4), st);  // one wave of 16 (slots) or 4 rows per block, striding
+        launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), capped((n + 3) / 4), st);  // one wave of 4 rows per block, striding
     }
 }
 
