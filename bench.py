@@ -15,10 +15,16 @@ collective: weak scaling) with seeds 40+rank as SURVEY.md §8(d) prescribes for 
 shard, 12.5 M segments per GPU.  Every rank reports its own times (`per_rank`): a scaling loss can only come from the
 host side (page-locked memory bandwidth shared by the ranks, NUMA placement) and shows there.
 
-Launch: `python bench.py` (N=1) or
+Launch: `python bench.py` (N=1); `python bench.py --gpus N` starts its own N ranks as child processes (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE set as torchrun sets them; the parent never touches the GPU and only relays their exit
+status — the reference's `Pool(threads)` fan-out, /root/reference/scTagger.py:703-715, as one process per device); under
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+the ranks are torchrun's.  Every rank checks WORLD_SIZE == --gpus and fails otherwise.
 torch is used only for the barrier / max-over-ranks of the timing (gloo); the product path is ctypes -> HIP.
+
+At N = 1 the line also carries `other_configs`: BASELINE.json configs[1] (cfg2, 1 M x 5 k, e<=2) and configs[4] (cfg5,
+10 M x 3.6 M, e<=1) through the same two loops, with a roofline object each; `value` stays cfg3.
 """
 import argparse
 import json
@@ -39,7 +45,9 @@ WORKLOADS = {
     "cfg2": (1_000_000, 5_000, 16, 2),
     "cfg3": (10_000_000, 25_000, 16, 2),
     "cfg4": (12_500_000, 25_000, 16, 2),   # one GPU's shard of the 100 M-segment configuration
+    "cfg5": (10_000_000, 3_600_000, 16, 1),  # extract_sr_bc_from_lr scale: the 10x whitelist's size, seed 5
 }
+SEEDS = {"cfg2": 2, "cfg3": 3, "cfg5": 5}   # SURVEY.md 8(d); cfg4: 40 + rank
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PCIE_PEAK_GBS = 63.0   # MI355X_MICROARCH.md: PCIe Gen5 x16 (spec); 57 GB/s measured (profiles/r02_pcie_probe.json)
 # Integer VALU ceiling, measured (tools/valu_peak.hip -> profiles/r02_valu_issue_rates.md): shifts, three-operand and
@@ -62,14 +70,17 @@ def baseline_metric():
         return "LR segments matched/sec (whole node), 25k barcodes e<=2, at 1/2/4/8 MI355X"
 
 
-def pmc_quote(workload_desc):
+def pmc_quote(workload_desc, fname="k_filter_counters.json"):
     """Per-launch counters of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if they
     were taken on this workload.  bench.py cannot collect PMC counters itself; it only quotes them."""
-    path = os.path.join(ROOT, "profiles", "k_filter_counters.json")
+    path = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(path):
         return None
     q = json.load(open(path))
-    return q if q.get("workload") == workload_desc else None
+
+    def shape(d):   # everything but the row count: counters of a launch over fewer rows are scaled per row by the caller
+        return d.split(":")[0], d.split(" LR segments x ")[-1]
+    return q if shape(q.get("workload", "")) == shape(workload_desc) else None
 
 
 def make_batch(n, bc, seed, chunk=1_000_000, seg_len=22):
@@ -94,23 +105,225 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(bc, segs, offs, max_err, sample):
-    """The oracle (C restatement of the reference's trie + prefix tasks) timed on this host's cores on a
-    bounded sample of the same workload.  A reported baseline; never the product path."""
-    from oracle import trie_oracle
-    trie_oracle.load()
+def host_cores():
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    return cores
+
+
+def cpu_baseline(bc, segs, offs, max_err, sample, threads=16, workers=None):
+    """The oracle (C restatement of the reference's trie + prefix tasks) timed on this host's cores on a
+    bounded sample of the same workload.  `threads` is the reference's -t (number of prefix tasks = 4^k >= t,
+    /root/reference/scTagger.py:689-698), `workers` the size of its Pool (:703).  A reported baseline; never the product path."""
+    from oracle import trie_oracle
+    trie_oracle.load()
+    cores = host_cores()
+    workers = min(cores, workers or threads)
     n = min(sample, offs.size - 1)
     t0 = time.perf_counter()
-    trie_oracle.match(bc, segs[:offs[n]], offs[:n + 1], max_err, threads=16, workers=min(cores, 16))
+    trie_oracle.match(bc, segs[:offs[n]], offs[:n + 1], max_err, threads=threads, workers=workers)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "segments/s", "cores": min(cores, 16), "cpu": cpu_model(), "kind": "port",
-            "sample": "first %d segments of the batch x %d barcodes, e<=%d, reference -t 16 (16 prefix tasks)" % (
-                n, bc.shape[0], max_err), "seconds": round(dt, 2)}
+    return {"value": n / dt, "unit": "segments/s", "cores": workers, "host_cores": cores, "cpu": cpu_model(), "kind": "port",
+            "sample": "first %d segments of the batch x %d barcodes, e<=%d, reference -t %d (%d prefix tasks on %d workers)" % (
+                n, bc.shape[0], max_err, threads, 4 ** _native.prefix_len(threads), workers), "seconds": round(dt, 2)}
+
+
+class Loops:
+    """The two timed loops over one batch on one Matcher: figure (ii) (sct_match_stream on page-locked host buffers) and
+    figure (i) (sct_run on the batch resident in HBM)."""
+
+    def __init__(self, m, bc, segs, offs, max_err, dist=None):
+        self.m, self.bc, self.segs, self.offs, self.max_err, self.dist = m, bc, segs, offs, max_err, dist
+        self.n_seg = offs.size - 1
+        self.psegs = m.host_array(segs.size, np.uint8)
+        self.psegs[:] = segs
+        self.pme = m.host_array(self.n_seg, np.uint8)
+        self.hits = 0
+
+    def barrier(self):
+        shard.barrier(self.dist)
+
+    def device_sync(self):
+        self.m.sync()                 # the library's own streams (torch.cuda.synchronize would not see them)
+        if self.dist is not None:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+            except Exception:
+                pass
+
+    def e2e(self, steps, warmup, index_format, count_format, hits_format, zero_copy=True):
+        m, n_seg = self.m, self.n_seg
+        ifmt, cfmt = IDX[index_format], CNT[count_format]
+        if 2 * self.bc.shape[0] > 65536:
+            hits_format = "u32"
+        hfmt = HITS[hits_format]
+        lens = np.diff(self.offs)
+        index = {"len8": lambda: lens.astype(np.uint8), "len16": lambda: lens.astype(np.uint16),
+                 "offs32": lambda: self.offs.astype(np.int32), "offs64": lambda: self.offs}[index_format]()
+        pidx = m.host_array(index.size, index.dtype)
+        pidx[:] = index
+        pcnt = m.host_array(n_seg + 1, _native._CNT_DTYPE[cfmt])
+
+        def step():
+            return m.match_stream(self.psegs, pidx, self.max_err, 1, index_format=ifmt, count_format=cfmt, min_e=self.pme, counts=pcnt,
+                                  copy_hits=False, hits_format=hfmt)
+        for _ in range(warmup):
+            step()
+        self.device_sync()
+        self.barrier()
+        spans = {}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = step()
+            for name, ms, k in m.last_timing_ex():
+                spans.setdefault(name, []).append((ms, k))
+        self.device_sync()
+        elapsed = time.perf_counter() - t0
+        self.barrier()
+        self.hits = int(r[2].size)
+        h2d_bytes = int(self.segs.size + index.nbytes)
+        d2h_bytes = int(n_seg + pcnt[:n_seg + (1 if cfmt == _native.CNT_OFFS64 else 0)].nbytes + r[2].itemsize * self.hits)
+        avg = {k: float(np.mean([x[0] for x in v])) for k, v in spans.items()}
+        launches = {k: int(v[-1][1]) for k, v in spans.items()}
+        e2e = {"ms_per_step": 1e3 * elapsed / max(steps, 1), "index_format": index_format, "count_format": count_format,
+               "hits_format": hits_format, "host_to_device_bytes": h2d_bytes, "device_to_host_bytes": d2h_bytes,
+               "zero_copy": bool(zero_copy), "chunks": launches.get("k_filter", 0),
+               "spans_ms": {k: round(v, 4) for k, v in avg.items()}}
+        if zero_copy and "k_filter" in avg:
+            e2e["k_filter_input_GBps"] = round(self.segs.size / (avg["k_filter"] * 1e-3) / 1e9, 1)
+            e2e["pcie_peak_GBps"] = PCIE_PEAK_GBS
+        return e2e, elapsed
+
+    def resident(self, steps, warmup):
+        m = self.m
+        m.upload_segments(self.psegs, self.offs)
+        for _ in range(max(1, min(warmup, 2))):
+            m.run(self.max_err, threads=1)
+        self.device_sync()
+        self.barrier()
+        per_kernel = {}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.hits = m.run(self.max_err, threads=1)
+            for name, ms in m.last_timing():
+                per_kernel.setdefault(name, []).append(ms)
+        self.device_sync()
+        elapsed = time.perf_counter() - t0
+        self.barrier()
+        return {"ms_per_step": 1e3 * elapsed / max(steps, 1)}, {k: float(np.mean(v)) for k, v in per_kernel.items()}, elapsed
+
+    def algorithmic_bytes(self):
+        """per segment (L + 4) in + (1 + 4 + 4 h) out, plus the barcode set read once per launch."""
+        h = self.hits / float(self.n_seg)
+        per_seg = (float(self.offs[-1]) / self.n_seg + 4) + (1 + 4 + 4 * h)
+        return per_seg, per_seg * self.n_seg + self.bc.size, h
+
+
+def hbm_roofline(loops, avg, desc, quote_file, exhaustive=False):
+    """The roofline object of the dominant kernel of the resident loop (one launch over the whole batch)."""
+    if not avg:
+        return None
+    dominant = max(avg, key=avg.get)
+    per_seg, alg_bytes, h = loops.algorithmic_bytes()
+    achieved = alg_bytes / (avg[dominant] * 1e-3) / 1e9
+    bl = loops.bc.shape[1]
+    cells = synth_seg_len(loops.offs) * bl * loops.bc.shape[0] * 2
+    roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            "kernel_ms": round(avg[dominant], 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+            "bytes_per_segment": round(per_seg, 2),
+            "measured_in": "the resident loop: one launch of the kernel over the whole batch, HIP events on its stream",
+            "dp_cells_per_segment": int(cells),
+            "gcups_equivalent": round(loops.n_seg * cells / (avg[dominant] * 1e-3) / 1e9, 1)}
+    q = pmc_quote(desc, quote_file) if not exhaustive else None
+    if q and q.get("kernel_ms_at_profile") and abs(avg[dominant] / q["kernel_ms_at_profile"] - 1.0) > 0.15:
+        q = None   # the committed counters belong to a different build of the kernel: do not quote them
+    if q:
+        scale = loops.n_seg / float(q.get("segments_per_launch") or loops.n_seg)   # counters are per profiled launch
+        rd, wr = (q.get("hbm_read_bytes") or 0) * scale, (q.get("hbm_write_bytes") or 0) * scale
+        roof["traffic"] = int(rd + wr)
+        roof["traffic_over_algorithmic"] = round((rd + wr) / alg_bytes, 2)
+        roof["traffic_quoted"] = {"source": q["source"], "hbm_read_bytes": q.get("hbm_read_bytes"), "hbm_write_bytes": q.get("hbm_write_bytes"),
+                                  "segments_per_profiled_launch": q.get("segments_per_launch"), "note": q.get("note")}
+        if q.get("hbm_read_bytes"):
+            roof["traffic_quoted"]["missed_64B_lines_per_segment"] = round(q["hbm_read_bytes"] / 64.0 / q["segments_per_launch"], 2)
+            tb = (rd + wr) / (avg[dominant] * 1e-3) / 1e9
+            roof["traffic_GBps"] = round(tb, 1)
+            roof["traffic_frac_of_peak"] = round(tb / HBM_PEAK_GBS, 4)
+        if q.get("l2_requests_per_launch"):
+            # the seed lookups are random 8-byte reads: one 128-byte L2 request each, whatever the bytes used
+            r = q["l2_requests_per_launch"] * scale / (avg[dominant] * 1e-3)
+            roof["l2_quoted"] = {"requests_per_segment": round(q["l2_requests_per_launch"] / q["segments_per_launch"], 1),
+                                 "achieved_requests_per_s": r, "peak_requests_per_s": L2_PEAK_REQ_S,
+                                 "frac": round(r / L2_PEAK_REQ_S, 3), "hit_rate": q.get("l2_hit_rate"),
+                                 "note": "peak = 16 channels x 8 XCDs x 1 request/clk at 2.4 GHz (34.5 TB/s / 128 B lines)"}
+        if q.get("valu_insts_per_launch"):
+            w = q["valu_insts_per_launch"] * scale / (avg[dominant] * 1e-3)
+            share_full = q.get("valu_full_rate_share")
+            v = {"insts_per_segment": round(q["valu_insts_per_launch"] / q["segments_per_launch"], 1),
+                 "achieved_wave_insts_per_s": w, "peak_if_all_half_rate_ops": VALU_PEAK_WINST_S,
+                 "peak_if_all_full_rate_ops": VALU_PEAK_FULL_RATE_WINST_S}
+            if share_full is not None:
+                # ceiling of THIS instruction mix: the harmonic mean of the two measured issue rates, weighted by the dynamic share
+                # of each class (profiles/r03_valu_mix.json)
+                peak = 1.0 / ((1.0 - share_full) / VALU_PEAK_WINST_S + share_full / VALU_PEAK_FULL_RATE_WINST_S)
+                v.update({"full_rate_share": share_full, "peak_wave_insts_per_s": peak, "frac": round(min(w / peak, 1.0), 3),
+                          "frac_uncapped": round(w / peak, 3), "mix_source": q.get("valu_mix_source")})
+            else:
+                v.update({"peak_wave_insts_per_s": VALU_PEAK_WINST_S, "frac": round(min(w / VALU_PEAK_WINST_S, 1.0), 3),
+                          "frac_uncapped": round(w / VALU_PEAK_WINST_S, 3)})
+            v["note"] = ("instruction count from the PMC pass, duration measured live; issue rates measured by tools/valu_peak.hip "
+                         "(profiles/r02_valu_issue_rates.md): shifts / 3-operand / packed 16-bit integer ops one wave64 instruction per "
+                         "4.1 cycles per SIMD, plain and / xor / add per 2.2; this is the binding resource at the 25 k-barcode configurations")
+            roof["valu_quoted"] = v
+    return roof
+
+
+def pcie_roofline(e2e, seg_bytes):
+    """figure (ii)'s dominant kernel reads the segment bytes over the link while it computes: it is link-bound."""
+    if not e2e or "k_filter" not in e2e["spans_ms"] or not e2e["zero_copy"]:
+        return None
+    ms = e2e["spans_ms"]["k_filter"]
+    ach = seg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "pcie", "kernel": "k_filter<..., unsigned int> (zero-copy stream instantiation)", "achieved": round(ach, 2), "peak": PCIE_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / PCIE_PEAK_GBS, 4), "kernel_ms": round(ms, 4), "bytes_over_the_link_per_launch": int(seg_bytes),
+            "peak_measured_GBps": 57.0,
+            "note": "segment bytes read in place from page-locked host memory inside the kernel; peak = PCIe Gen5 x16 spec, 57 GB/s is what a "
+                    "plain streaming kernel or hipMemcpy reaches on this box (profiles/r02_pcie_probe.json)"}
+
+
+def other_config(name, device, steps, warmup):
+    """One more BASELINE configuration through both loops on a context of its own -> its entry of `other_configs`."""
+    n_seg, n_bc, bl, max_err = WORKLOADS[name]
+    t0 = time.perf_counter()
+    bc = synth.make_barcodes(n_bc, bl=bl, seed=SEEDS[name])
+    segs, offs = make_batch(n_seg, bc, SEEDS[name])
+    t_gen = time.perf_counter() - t0
+    desc = "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, 22-bp segments (SURVEY 8(d))" % (name, n_seg, n_bc, bl, max_err)
+    m = _native.Matcher(device)
+    try:
+        t0 = time.perf_counter()
+        m.set_barcodes(bc)
+        t_tables = time.perf_counter() - t0
+        loops = Loops(m, bc, segs, offs, max_err)
+        e2e, e2e_elapsed = loops.e2e(steps, warmup, "len8", "u8", "u16")
+        res, avg, _ = loops.resident(steps, warmup)
+        per_seg, alg_bytes, h = loops.algorithmic_bytes()
+        return {"workload": desc, "seed": SEEDS[name],
+                "value_device_e2e": n_seg / (e2e["ms_per_step"] * 1e-3), "ms_per_step": e2e["ms_per_step"],
+                "value_resident": n_seg / (res["ms_per_step"] * 1e-3), "ms_per_step_resident": res["ms_per_step"],
+                "steps": steps, "warmup": warmup, "hits_per_segment": round(h, 4), "paths": m.last_stats(),
+                "device_e2e": e2e, "kernels_ms": {k: round(v, 4) for k, v in avg.items()},
+                "roofline": hbm_roofline(loops, avg, desc, "k_filter_counters_%s.json" % name),
+                "roofline_e2e": pcie_roofline(e2e, segs.size),
+                "setup_s": {"synthetic_inputs": round(t_gen, 2), "sct_set_barcodes": round(t_tables, 2)}}
+    finally:
+        m.close()
 
 
 def main():
@@ -134,11 +347,23 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI end-to-end timing (figure (iii))")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip cfg2 / cfg5 (`other_configs`)")
     ap.add_argument("--cli-rows", type=int, default=10_000_000)
     ap.add_argument("--force-exhaustive", action="store_true", help="time the all-barcodes scan instead of the seed filter")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="sct_set_option before the barcodes are set (exploration)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: start the N ranks ourselves.  This process has not touched the GPU (nothing above loads the
+        # HIP library) and never will: it waits for its children and passes their status on.
+        sys.exit(shard.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+
     rank, local_rank, world = shard.rank_info()
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: start one rank per GPU (python bench.py --gpus N does)\n" % (args.gpus, world))
+        sys.exit(2)
     dist = shard.init_dist()
 
     wl = args.workload or ("cfg4" if world == 8 else "cfg3")
@@ -155,11 +380,15 @@ def main():
     ndev = max(1, _native.device_count())
     device = local_rank % ndev
     numa = shard.bind_to_device_numa(device) if world > 1 else None
-    bc = synth.make_barcodes(n_bc, bl=bl, seed=3)
-    seed = 3 if world == 1 else 40 + rank
+    bc_seed = SEEDS.get(wl, 3)
+    bc = synth.make_barcodes(n_bc, bl=bl, seed=bc_seed)
+    seed = SEEDS.get(wl, 3) if world == 1 else 40 + rank   # cfg4's shards are seeds 40..47
     segs, offs = make_batch(n_seg, bc, seed, seg_len=args.seg_len)
 
     m = _native.Matcher(device)
+    for kv in args.option:
+        k, _, v = kv.partition("=")
+        m.set_option(k, int(v))
     m.set_barcodes(bc)
     if args.force_exhaustive:
         m.set_option("force_exhaustive", 1)
@@ -168,88 +397,28 @@ def main():
     m.set_option("chunk_rows", args.chunk_rows)
     m.set_option("zero_copy", args.zero_copy)
 
-    def barrier():
-        shard.barrier(dist)
-
-    def device_sync():
-        m.sync()                      # the library's own streams (torch.cuda.synchronize would not see them)
-        if dist is not None:
-            try:
-                import torch
-                if torch.cuda.is_available():
-                    torch.cuda.synchronize()
-            except Exception:
-                pass
-
+    loops = Loops(m, bc, segs, offs, max_err, dist)
     # ---- figure (ii): the seam, page-locked host memory -> device -> page-locked host memory -----------------------
-    ifmt, cfmt = IDX[args.index_format], CNT[args.count_format]
-    hits_format = args.hits_format if 2 * n_bc <= 65536 else "u32"
-    hfmt = HITS[hits_format]
-    lens = np.diff(offs)
-    index = {"len8": lambda: lens.astype(np.uint8), "len16": lambda: lens.astype(np.uint16),
-             "offs32": lambda: offs.astype(np.int32), "offs64": lambda: offs}[args.index_format]()
-    psegs = m.host_array(segs.size, np.uint8)
-    psegs[:] = segs
-    pidx = m.host_array(index.size, index.dtype)
-    pidx[:] = index
-    pme = m.host_array(n_seg, np.uint8)
-    pcnt = m.host_array(n_seg + 1, _native._CNT_DTYPE[cfmt])
-    e2e = None
-    e2e_elapsed = None
-    hits = 0
+    e2e = e2e_elapsed = None
     if args.mode in ("both", "e2e"):
-        def step():
-            return m.match_stream(psegs, pidx, max_err, 1, index_format=ifmt, count_format=cfmt, min_e=pme, counts=pcnt, copy_hits=False,
-                                  hits_format=hfmt)
-        for _ in range(args.warmup):
-            step()
-        device_sync()
-        barrier()
-        spans = {}
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            r = step()
-            for name, ms, k in m.last_timing_ex():
-                spans.setdefault(name, []).append((ms, k))
-        device_sync()
-        e2e_elapsed = time.perf_counter() - t0
-        barrier()
-        hits = int(r[2].size)
-        h2d_bytes = int(segs.size + index.nbytes)
-        d2h_bytes = int(n_seg + pcnt[:n_seg + (1 if cfmt == _native.CNT_OFFS64 else 0)].nbytes + r[2].itemsize * hits)
-        avg = {k: float(np.mean([x[0] for x in v])) for k, v in spans.items()}
-        launches = {k: int(v[-1][1]) for k, v in spans.items()}
-        e2e = {"ms_per_step": 1e3 * e2e_elapsed / max(args.steps, 1), "index_format": args.index_format, "count_format": args.count_format,
-               "hits_format": hits_format,
-               "host_to_device_bytes": h2d_bytes, "device_to_host_bytes": d2h_bytes,
-               "zero_copy": bool(args.zero_copy), "chunks": launches.get("k_filter", 0),
-               "spans_ms": {k: round(v, 4) for k, v in avg.items()},
-               "spans_note": "device time per step by kernel name (HIP events on the kernel's stream, summed over the step's launches). "
+        e2e, e2e_elapsed = loops.e2e(args.steps, args.warmup, args.index_format, args.count_format, args.hits_format, args.zero_copy)
+        e2e["spans_note"] = ("device time per step by kernel name (HIP events on the kernel's stream, summed over the step's launches). "
                              "With zero_copy the input crosses PCIe INSIDE k_index (row lengths) and k_filter (segment bytes), min_e is "
-                             "written to host memory by k_filter together with the one-byte counts and the hit lists by k_fill / k_narrow_hits: there are no "
-                             "separate copies to time; host_queue / host_wait are the calling thread's own time"}
-        if args.zero_copy and "k_filter" in avg:
-            e2e["k_filter_input_GBps"] = round(segs.size / (avg["k_filter"] * 1e-3) / 1e9, 1)
-            e2e["pcie_peak_GBps"] = PCIE_PEAK_GBS
+                             "written to host memory by k_filter together with the one-byte counts and the hit lists by k_fill: there are no "
+                             "separate copies to time; host_queue / host_wait are the calling thread's own time")
+    hits_format = e2e["hits_format"] if e2e else args.hits_format
+    # the same step with the reference's own index type (lr_segs_idxs = RawArray('i'), /root/reference/scTagger.py:618)
+    e2e_offs32 = None
+    if args.mode == "both" and world == 1 and args.index_format != "offs32" and offs[-1] < 2 ** 31:
+        e2e_offs32, _ = loops.e2e(args.steps, args.warmup, "offs32", args.count_format, args.hits_format, args.zero_copy)
 
     # ---- figure (i): the same kernels on a batch that is resident in HBM (roofline of the dominant kernel) -------------
     res = None
-    per_kernel = {}
+    avg = {}
+    res_elapsed = None
     if args.mode in ("both", "resident"):
-        m.upload_segments(psegs, offs)
-        for _ in range(max(1, min(args.warmup, 2))):
-            m.run(max_err, threads=1)
-        device_sync()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            hits = m.run(max_err, threads=1)
-            for name, ms in m.last_timing():
-                per_kernel.setdefault(name, []).append(ms)
-        device_sync()
-        res_elapsed = time.perf_counter() - t0
-        barrier()
-        res = {"ms_per_step": 1e3 * res_elapsed / max(args.steps, 1)}
+        res, avg, res_elapsed = loops.resident(args.steps, args.warmup)
+    hits = loops.hits
 
     # ---- the serial three-step path beside it (upload / kernels / download as separate, synchronised steps) --------------
     serial = None
@@ -260,9 +429,9 @@ def main():
         poffs[:] = offs
         best = None
         for _ in range(2):
-            t0 = time.perf_counter(); m.upload_segments(psegs, poffs); t1 = time.perf_counter()
+            t0 = time.perf_counter(); m.upload_segments(loops.psegs, poffs); t1 = time.perf_counter()
             m.run(max_err, threads=1); t2 = time.perf_counter()
-            m.download_into(pme, pho, phi); t3 = time.perf_counter()
+            m.download_into(loops.pme, pho, phi); t3 = time.perf_counter()
             cur = (t1 - t0, t2 - t1, t3 - t2)
             best = cur if best is None or sum(cur) < sum(best) else best
         serial = {"h2d_ms": round(1e3 * best[0], 3), "kernels_ms": round(1e3 * best[1], 3), "d2h_ms": round(1e3 * best[2], 3),
@@ -272,61 +441,22 @@ def main():
 
     headline_elapsed = e2e_elapsed if e2e_elapsed is not None else res_elapsed
     headline_elapsed, total_segments = shard.reduce_timing(dist, headline_elapsed, n_seg)
-    mine = {"rank": rank, "device": device, "numa_node": numa, "segments": n_seg,
+    mine = {"rank": rank, "device": device, "numa_node": numa, "segments": n_seg, "seed": seed, "workload": wl,
             "e2e_ms_per_step": round(e2e["ms_per_step"], 4) if e2e else None,
             "resident_ms_per_step": round(res["ms_per_step"], 4) if res else None,
             "e2e_spans_ms": e2e["spans_ms"] if e2e else None}
     per_rank = shard.gather_objects(dist, mine)
     res_all = None
     if res is not None:
-        res_max, _ = shard.reduce_timing(dist, res["ms_per_step"], n_seg)
-        res_all = res_max
+        res_all, _ = shard.reduce_timing(dist, res["ms_per_step"], n_seg)
 
     if rank == 0:
         ms_per_step = 1e3 * headline_elapsed / max(args.steps, 1)
         value = total_segments / (ms_per_step / 1e3)
-        avg = {k: float(np.mean(v)) for k, v in per_kernel.items()}
-        dominant = max(avg, key=avg.get) if avg else None
         h = hits / float(n_seg)
-        bytes_per_seg = (float(offs[-1]) / n_seg + 4) + (1 + 4 + 4 * h)   # in L+4, out 1+4+4h
-        alg_bytes = bytes_per_seg * n_seg + bc.size                   # + barcode set read once per launch
-        roof = None
         workload_desc = "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, %d-bp segments (SURVEY 8(d))" % (
             wl, n_seg, n_bc, bl, max_err, args.seg_len)
-        if dominant:
-            achieved = alg_bytes / (avg[dominant] * 1e-3) / 1e9
-            cells = synth_seg_len(offs) * bl * n_bc * 2
-            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                    "kernel_ms": round(avg[dominant], 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                    "bytes_per_segment": round(bytes_per_seg, 2),
-                    "measured_in": "the resident loop: one launch of the kernel over the whole batch (k_filter<..., long>), HIP events on its stream",
-                    # the binding resource is integer VALU issue, not HBM: all-pairs DP cells credited
-                    "dp_cells_per_segment": int(cells),
-                    "gcups_equivalent": round(n_seg * cells / (avg[dominant] * 1e-3) / 1e9, 1)}
-            q = pmc_quote(workload_desc) if not args.force_exhaustive else None
-            if q and q.get("kernel_ms_at_profile") and abs(avg[dominant] / q["kernel_ms_at_profile"] - 1.0) > 0.15:
-                q = None   # the committed counters belong to a different build of the kernel: do not quote them
-            if q:
-                roof["traffic"] = int((q.get("hbm_read_bytes") or 0) + (q.get("hbm_write_bytes") or 0))
-                roof["traffic_quoted"] = {"source": q["source"], "hbm_read_bytes": q.get("hbm_read_bytes"),
-                                          "hbm_write_bytes": q.get("hbm_write_bytes"), "note": q.get("note")}
-                if q.get("l2_requests_per_launch"):
-                    # the seed lookups are random 8-byte reads: one 128-byte L2 request each, whatever the bytes used
-                    r = q["l2_requests_per_launch"] / (avg[dominant] * 1e-3)
-                    roof["l2_quoted"] = {"requests_per_segment": round(q["l2_requests_per_launch"] / q["segments_per_launch"], 1),
-                                         "achieved_requests_per_s": r, "peak_requests_per_s": L2_PEAK_REQ_S,
-                                         "frac": round(r / L2_PEAK_REQ_S, 3), "hit_rate": q.get("l2_hit_rate"),
-                                         "note": "peak = 16 channels x 8 XCDs x 1 request/clk at 2.4 GHz (34.5 TB/s / 128 B lines)"}
-                if q.get("valu_insts_per_launch"):
-                    w = q["valu_insts_per_launch"] / (avg[dominant] * 1e-3)
-                    roof["valu_quoted"] = {"insts_per_segment": round(q["valu_insts_per_launch"] / q["segments_per_launch"], 1),
-                                           "achieved_wave_insts_per_s": w, "peak_wave_insts_per_s": VALU_PEAK_WINST_S,
-                                           "frac": round(w / VALU_PEAK_WINST_S, 3),
-                                           "peak_if_all_full_rate_ops": VALU_PEAK_FULL_RATE_WINST_S,
-                                           "note": "instruction count from the PMC pass, duration measured live; peak = the measured issue "
-                                                   "rate of shifts / 3-operand / packed 16-bit integer ops (profiles/r02_valu_issue_rates.md), "
-                                                   "the class the automaton is made of; this is the binding resource"}
+        roof = hbm_roofline(loops, avg, workload_desc, "k_filter_counters.json", args.force_exhaustive)
         out = {
             "metric": baseline_metric() if wl in ("cfg3", "cfg4") and not args.segments else "LR segments matched/sec (whole node)",
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -340,19 +470,34 @@ def main():
                          "the timed region)") if e2e else "resident: SURVEY 8(d) figure (i) — inputs already in HBM",
             "value_device_e2e": (total_segments / (ms_per_step / 1e3)) if e2e else None,
             "value_resident": (total_segments / (res_all / 1e3)) if res_all else None,
+            "value_device_e2e_offs32": (n_seg / (e2e_offs32["ms_per_step"] * 1e-3)) if e2e_offs32 else None,
             "ms_per_step_resident": res_all,
             "hits_per_segment": round(h, 4),
             "device_e2e": e2e,
+            "device_e2e_offs32": e2e_offs32,
             "three_step_serial": serial,
             "kernels_ms": {k: round(v, 4) for k, v in avg.items()},
             "roofline": roof,
+            "roofline_e2e": pcie_roofline(e2e, segs.size),
             "per_rank": per_rank,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(bc, segs, offs, max_err, args.cpu_sample)
+            cores = host_cores()
+            if cores > 16:
+                # the reference's pool at -t = core count (north_star: "on the GPU box's host cores"): 4^k >= t prefix tasks
+                out["cpu_baseline_all_cores"] = cpu_baseline(bc, segs, offs, max_err, args.cpu_sample, threads=cores, workers=cores)
+        m.close()
+        m = None
+        if world == 1 and not args.no_other_configs and args.mode == "both" and not args.segments and wl == "cfg3":
+            oc = {}
+            for name in ("cfg2", "cfg5"):
+                try:
+                    oc[name] = other_config(name, device, max(2, min(args.steps, 5)), 1)
+                except Exception as e:   # informative; the bench line must come out
+                    oc[name] = {"error": repr(e)}
+            out["other_configs"] = oc
         if world == 1 and not args.no_cli and args.mode == "both":
-            m.close()
-            m = None
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import cli_e2e
@@ -361,7 +506,7 @@ def main():
                                              segs=segs[:offs[k]], offs=offs[:k + 1], quiet=True)
             except Exception as e:   # the figure is informative; the bench line must come out
                 out["cli_e2e"] = {"error": repr(e)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if m is not None:
         m.close()
     if dist is not None:

@@ -2,6 +2,51 @@
 collective.  torch.distributed is imported only when WORLD_SIZE > 1 and only for the
 barrier and two scalar reductions of the benchmark (gloo: CPU scalars; nothing moves over xGMI)."""
 import os
+import socket
+import subprocess
+import sys
+
+
+def launch_ranks(n, script, argv, env=None, timeout=None):
+    """Start `n` ranks of `script argv...` as CHILD processes of this one (the reference's `Pool(threads)` fan-out,
+    /root/reference/scTagger.py:703-704, as one process per GPU) and wait for them: RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT in each child's environment as torchrun would set them, stdout and stderr inherited (rank 0
+    prints the result line).  The caller must not have touched the GPU: it only waits.  Nothing is exec'ed in place.
+    -> the first non-zero exit status of a rank (the others are then terminated), or 0."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=dict(base, RANK=str(r), LOCAL_RANK=str(r))))
+    import time
+    deadline = None if timeout is None else time.monotonic() + timeout
+    status = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and status == 0:
+                status = rc
+        if status != 0 or (deadline is not None and time.monotonic() > deadline):
+            for p in live:            # a rank failed (or time ran out): the others would wait in the barrier for ever
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            return status or 124
+        if live:
+            time.sleep(0.02)
+    return status
 
 
 def rank_info():

@@ -81,3 +81,73 @@ def test_two_ranks_on_the_device(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["value_resident"] > 0
     assert [r["rank"] for r in d["per_rank"]] == [0, 1] and all(r["e2e_ms_per_step"] > 0 for r in d["per_rank"])
     assert d["config"]["paths"]["filter"] == 300000
+
+
+def test_launch_ranks_starts_eight_children(tmp_path):
+    """`bench.py --gpus N` outside torchrun starts its own N ranks (shard.launch_ranks): eight children with the torchrun
+    environment, one of them failing makes the call fail and takes the others down."""
+    from sctagger_amd import shard
+    w = tmp_path / "w.py"
+    w.write_text("import os, sys, time\n"
+                 "open(os.path.join(sys.argv[1], 'r' + os.environ['RANK']), 'w').write(' '.join(os.environ[k] for k in "
+                 "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')))\n"
+                 "if len(sys.argv) > 2 and os.environ['RANK'] == sys.argv[2]: sys.exit(7)\n"
+                 "if len(sys.argv) > 2: time.sleep(60)\n")
+    assert shard.launch_ranks(8, str(w), [str(tmp_path)]) == 0
+    got = [open(tmp_path / ("r%d" % r)).read().split() for r in range(8)]
+    assert [g[:4] for g in got] == [[str(r), str(r), "8", "127.0.0.1"] for r in range(8)]
+    assert len({g[4] for g in got}) == 1
+    import time
+    t0 = time.time()
+    assert shard.launch_ranks(3, str(w), [str(tmp_path), "1"]) == 7     # rank 1 exits with 7; ranks 0 and 2 would sleep a minute
+    assert time.time() - t0 < 30
+
+
+def test_bench_gpus_flag_is_live():
+    """--gpus is not a label: with N > 1 and no torchrun environment bench.py starts N ranks itself (here they fail for want of
+    a device — loudly, and the parent passes the failure on); under a launcher whose world size differs it refuses to run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--segments", "1000", "--steps", "1"], env=env,
+                         capture_output=True, timeout=300)
+    if out.returncode == 0:     # a GPU is present: two ranks ran
+        d = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == 2 and len(d["per_rank"]) == 2
+    else:
+        assert b"no HIP device" in out.stderr and not [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--segments", "1000"],
+                         env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), capture_output=True, timeout=300)
+    assert out.returncode == 2 and b"WORLD_SIZE is 3" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus 2` with no torchrun around it: two child ranks, one line, both ranks in it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--segments", "300000"],
+                         capture_output=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1] and [r["seed"] for r in d["per_rank"]] == [40, 41]
+
+
+@pytest.mark.gpu
+def test_cfg4_shard_rehearsal_on_one_device(tmp_path):
+    """cfg4's launch shape on the one GPU of the box: the shard workload, seeds 40 + rank, the NUMA node every rank bound itself
+    to.  Four ranks, not eight: a GPU box of this pool allows at most six processes on its card (the test runner is one)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "cfg4", "--segments", "250000", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, timeout=900, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    d = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["config"]["segments_per_gpu"] == 250000 and d["config"]["barcodes"] == 25000
+    assert [r["seed"] for r in d["per_rank"]] == [40, 41, 42, 43] and all(r["workload"] == "cfg4" for r in d["per_rank"])
+    assert all("numa_node" in r and r["e2e_ms_per_step"] > 0 and r["resident_ms_per_step"] > 0 for r in d["per_rank"])
+    assert abs(d["value"] - 4 * 250000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_world_eight_selects_the_cfg4_shard():
+    import bench
+    assert bench.WORKLOADS["cfg4"][0] * 8 == 100_000_000 and bench.WORKLOADS["cfg5"] == (10_000_000, 3_600_000, 16, 1)
