@@ -28,12 +28,13 @@ typedef struct sct_ctx sct_ctx;
 
 enum {
     SCT_OK = 0,
-    SCT_E_ARG = -1,         /* bad argument (NULL, negative size, bl/max_err out of range, byte >= 128) */
+    SCT_E_ARG = -1,         /* bad argument (NULL, negative size, bl/max_err out of range, byte >= 128 where the reference maps it) */
     SCT_E_HIP = -2,         /* a HIP runtime call failed */
     SCT_E_NODEV = -3,       /* no usable device */
     SCT_E_STATE = -4,       /* call order (e.g. match before set_barcodes) */
     SCT_E_UNSUPPORTED = -5, /* barcode length above SCT_MAX_BL; a -t whose window prefix is not below bl - max_err */
-    SCT_E_RANGE = -6        /* a value does not fit the compact output format that was asked for */
+    SCT_E_RANGE = -6,       /* a value does not fit the compact output format that was asked for */
+    SCT_E_NOMEM = -7        /* out of device memory (hipMalloc), page-locked host memory or host heap */
 };
 
 #define SCT_MAX_BL 32       /* barcode length limit of the bit-parallel kernels */
@@ -89,11 +90,26 @@ int sct_match(sct_ctx *ctx, const char *segs, const int64_t *offs, int64_t n, in
 void sct_free_hits(sct_ctx *ctx, uint32_t *hits);
 
 /*
- * The same seam for callers that care about the PCIe link: compact transfer formats and a pipelined engine.  The rows
- * are cut into chunks (option "chunk_rows") that move through several streams (option "lanes"), so that the upload of chunk
- * k+1, the kernels of chunk k and the download of chunk k-1 overlap; sct_match above is this call with 64-bit offsets
- * both ways.  Page-locked buffers (sct_host_alloc) for segs / index / min_e / counts are read and written in place by the
- * kernels; pageable ones are page-locked for the duration of the call when they are large (option "register"), else copied.
+ * The same seam for callers that care about the PCIe link: compact transfer formats and an engine that keeps the link busy;
+ * sct_match above is this call with 64-bit offsets both ways.
+ *   Page-locked buffers (sct_host_alloc, or any hipHostMalloc / hipHostRegister memory) for segs / index / min_e / counts are
+ *   read and written IN PLACE by the kernels through their device mapping ("zero copy", option "zero_copy"): nothing is
+ *   uploaded, the rows cross the link inside the filter kernel while it computes, and the call runs as ONE chunk of up to 2^24
+ *   rows (more rows: several such chunks one after the other; a chunk also ends before 3 GiB of segment bytes, the offsets on
+ *   the device being 32-bit and relative to the chunk).  Large pageable buffers are page-locked for the duration of the call
+ *   (option "register") and take the same route.  What cannot be mapped is uploaded in chunks (option "chunk_rows") that move
+ *   through several streams (option "lanes") so that the upload of chunk k+1, the kernels of chunk k and the download of chunk
+ *   k-1 overlap.
+ *   Limits: row counts, seg_bytes, hit offsets and the hit total are 64-bit throughout (the reference's own c_int index,
+ *   scTagger.py:618, ends at 2^31 segment bytes); sct_upload_segments takes at most 2^31 - 16 rows per call.  Tested: 20 M rows
+ *   in one call at the default chunking and 4.5 GB of segment bytes in one call (tests/test_gpu_limits.py).  NOT tested: more
+ *   than 2^32 hits in one call (that is more than 16 GiB of page-locked result buffer).
+ *   Bytes >= 128: the reference raises (UnicodeDecodeError / IndexError, scTagger.py:682, :555, :512-516) when it inserts a
+ *   window that contains one, and never looks at a byte no inserted window covers (:677-682: windows shorter than
+ *   bl - max_err, and with -t > 1 windows whose first k raw bytes are not all in ACGT, are not inserted).  This library fails
+ *   with SCT_E_ARG in exactly those cases and ignores such a byte in exactly those cases — in particular anywhere in a row of
+ *   fewer than bl - max_err characters.  The same rule holds for sct_match and for sct_upload_segments + sct_run: the check
+ *   is made by the kernel that reads the row.
  *   segs, seg_bytes   the reference's lr_segs (scTagger.py:616-627) and its size
  *   index             where each row lies in segs, in one of four forms (index_format):
  *       SCT_IDX_OFFS64  int64 offs[n+1]   CSR offsets, offs[0] == 0, offs[n] == seg_bytes
@@ -122,7 +138,8 @@ int sct_match_stream(sct_ctx *ctx, const char *segs, int64_t seg_bytes, const vo
 
 /*
  * The same path in three steps, for pipelining and for measuring with the inputs resident in HBM:
- *   sct_upload_segments  host -> device copy of segs/offs (kept until the next upload)
+ *   sct_upload_segments  host -> device copy of segs/offs (kept until the next upload); the offsets are validated here
+ *                        (SCT_E_ARG), bytes >= 128 by sct_run under the rule stated for sct_match_stream
  *   sct_run              every kernel of the path on the resident segments; results stay on the device;
  *                        *n_hits receives the total hit count (one host synchronisation and one 64-byte read per run)
  *   sct_download         device -> host copy of the results of the last sct_run; hits must hold
@@ -158,8 +175,9 @@ int sct_sync(sct_ctx *ctx);
  *                            next sct_set_barcodes) and used
  *   "slots"           -1|0|1 8-byte bucket slots of the 16-character seed tables: -1 = used while few keys hold more
  *                            than three barcodes (3.5 % at max_err 2, 10 % below; default), 0 = never, 1 = always
- *   "chunk_rows"       n     rows per chunk of sct_match_stream / sct_match; 0 (default) = 2^20 when segs is page-locked
- *                            memory, 2^24 when it is pageable (staged copies do not overlap with anything)
+ *   "chunk_rows"       n     rows per chunk of sct_match_stream / sct_match; 0 (default) = 2^24 when segs is read in place
+ *                            (page-locked or registered, "zero_copy" on), 2^20 when it is page-locked but uploaded ("zero_copy"
+ *                            off), 2^24 when it is pageable and could not be registered (staged copies do not overlap with anything)
  *   "lanes"            1..8  chunks of a stream call in flight at once, each on a stream of its own (default 5)
  *   "zero_copy"        0|1   1 (default): sct_match_stream's kernels read page-locked segs / index buffers in place over the
  *                            host link; 0: they are uploaded first

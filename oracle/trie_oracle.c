@@ -113,9 +113,13 @@ static void trie_append_rid(trie_t *t, int64_t nid, int32_t rid) {
 }
 
 /* Trie.insert (scTagger.py:550-564): walk/create the path of `word`; append read_id to every
- * node at 0-based index >= barcode_length - max_error - 1 (duplicates allowed). */
-static void trie_insert(trie_t *t, const char *word, int len, int32_t read_id) {
+ * node at 0-based index >= barcode_length - max_error - 1 (duplicates allowed).
+ * Returns -1 if the word holds a byte >= 128: the reference raises before it inserts anything of such a word
+ * (`sub_segment.decode()`, :682 — UnicodeDecodeError — or, for a valid multi-byte sequence, `map_char[ord(char)]`, :555). */
+static int trie_insert(trie_t *t, const char *word, int len, int32_t read_id) {
     int64_t nid = 0;
+    for (int index = 0; index < len; index++)
+        if ((unsigned char)word[index] >= 128) return -1;
     for (int index = 0; index < len; index++) {
         int cid = map_char((unsigned char)word[index]);
         if (t->child[nid * ALPHABET + cid] == 0) {
@@ -128,6 +132,7 @@ static void trie_insert(trie_t *t, const char *word, int len, int32_t read_id) {
         nid = t->child[nid * ALPHABET + cid];
         if (index >= t->barcode_length - t->max_error - 1) trie_append_rid(t, nid, read_id);
     }
+    return 0;
 }
 
 /* Trie.dfs (scTagger.py:566-588): delete, then per child: match / mutation / insert. */
@@ -213,7 +218,10 @@ static fold_t *get_matches_prefix(const char *bc, const char *bc_rc, int n_bc, i
         for (int64_t i = 0; i < len; i++) {
             int64_t sl = len - i < bl + max_error ? len - i : bl + max_error;
             if (sl >= plen && memcmp(segment + i, prefix, (size_t)plen) == 0 && sl >= bl - max_error)
-                trie_insert(t, segment + i, (int)sl, (int32_t)rid);
+                if (trie_insert(t, segment + i, (int)sl, (int32_t)rid) != 0) { /* the worker raises; the pool re-raises it in the parent (:704) */
+                    trie_free(t);
+                    return NULL;
+                }
         }
     }
     fold_t *f = fold_new(n_seg, bl);
@@ -270,7 +278,7 @@ int orc_prefix_len(int threads) {
 int orc_match(const char *bc, int n_bc, int bl, const char *segs, const int64_t *offs, int64_t n_seg, int max_error,
               int threads, int workers, uint8_t *min_e, int64_t *hit_offs, uint32_t **hits, int64_t *n_hits) {
     for (int64_t i = 0; i < (int64_t)n_bc * bl; i++) if ((unsigned char)bc[i] >= 128) return -1;
-    for (int64_t i = 0; i < offs[n_seg]; i++) if ((unsigned char)segs[i] >= 128) return -1;
+    /* a segment byte >= 128 is an error only where the reference reads it: in a window it inserts (get_matches_prefix) */
     char *bc_rc = (char *)malloc((size_t)n_bc * bl + 1);
     for (int b = 0; b < n_bc; b++) rev_compl(bc + (size_t)b * bl, bl, bc_rc + (size_t)b * bl);
 
@@ -297,6 +305,13 @@ int orc_match(const char *bc, int n_bc, int bl, const char *segs, const int64_t 
     for (int w = 1; w < workers; w++) pthread_join(th[w], NULL);
     free(th);
 
+    int raised = 0;
+    for (int k = 0; k < n_tasks; k++) if (!j.out[k]) raised = 1;
+    if (raised) {
+        for (int k = 0; k < n_tasks; k++) if (j.out[k]) fold_free(j.out[k]);
+        free(j.out); free(prefixes); free(bc_rc);
+        return -1;
+    }
     /* merge (scTagger.py:705-715): min e per rid, union of the sets at that minimum */
     fold_t *m = fold_new(n_seg, bl);
     for (int k = 0; k < n_tasks; k++) {
@@ -334,7 +349,7 @@ void orc_free(void *p) { free(p); }
 /* ---- unit-level entry points for the Trie golden vectors (tests/golden/g4.trie_unit.json) ---- */
 void *orc_trie_new(int max_error, int barcode_length) { return trie_new(max_error, barcode_length, 64); }
 void orc_trie_free(void *t) { trie_free((trie_t *)t); }
-void orc_trie_insert(void *t, const char *word, int len, int32_t rid) { trie_insert((trie_t *)t, word, len, rid); }
+void orc_trie_insert(void *t, const char *word, int len, int32_t rid) { (void)trie_insert((trie_t *)t, word, len, rid); }
 int64_t orc_trie_size(void *t) { return ((trie_t *)t)->size; }
 /* query -> flat list: counts[d] entries for d = 0..max_error, concatenated into out (capacity cap). Returns total or -1. */
 int64_t orc_trie_query(void *tv, const char *barcode, int blen, int64_t *counts, int32_t *out, int64_t cap) {

@@ -31,6 +31,7 @@ HITS_U32, HITS_U16 = 0, 1
 _IDX_DTYPE = {IDX_OFFS64: np.int64, IDX_OFFS32: np.int32, IDX_LEN8: np.uint8, IDX_LEN16: np.uint16}
 _CNT_DTYPE = {CNT_OFFS64: np.int64, CNT_U32: np.uint32, CNT_U8: np.uint8}
 E_RANGE = -6
+E_NOMEM = -7
 
 _lib = None
 

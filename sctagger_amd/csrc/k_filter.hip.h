@@ -1047,10 +1047,10 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
             sct_decode_row<W>(a.segs, start, len, lo, hi, nonacgt);
     }
     if (__ballot(nonacgt) != 0) {
-        // rare: is one of the offending bytes >= 128?  The reference indexes map_char with it (scTagger.py:512-516, :555) and raises
+        // rare: is one of the offending bytes >= 128?  The reference raises when it reads one (sct_byte_is_read, sct_core.h)
         if (nonacgt) {
             for (int i = 0; i < len; i++)
-                if (a.segs[start + i] >= 128) {
+                if (a.segs[start + i] >= 128 && sct_byte_is_read(a.segs + start, len, i, bl, E, a.prefix_len)) {
                     atomicMin(reinterpret_cast<unsigned long long *>(a.ctr + CTR_BAD_BYTE), (unsigned long long)(start + i));
                     break;
                 }

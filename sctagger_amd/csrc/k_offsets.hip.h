@@ -255,10 +255,17 @@ k_route_all(const uint8_t *__restrict__ segs, const OffT *__restrict__ offs, int
         cnt[r] = 0;
         return;
     }
+    // a row the reference inserts windows of: it raises on a byte >= 128 in any of them (sct_byte_is_read, sct_core.h)
     bool nonacgt = false;
-    if (prefix_len > 0)
-        for (int64_t i = 0; i < len; i++) nonacgt |= !sct_is_acgt(segs[b0 + i]);
-    if (nonacgt) list_dp[atomicAdd(&ctr[CTR_DP], 1u)] = (int32_t)r;
+    for (int64_t i = 0; i < len; i++) {
+        const uint8_t b = segs[b0 + i];
+        nonacgt |= !sct_is_acgt(b);
+        if (b >= 128 && sct_byte_is_read(segs + b0, len, i, bl, max_err, prefix_len)) {
+            atomicMin(reinterpret_cast<unsigned long long *>(ctr + CTR_BAD_BYTE), (unsigned long long)(b0 + i));
+            break;
+        }
+    }
+    if (nonacgt && prefix_len > 0) list_dp[atomicAdd(&ctr[CTR_DP], 1u)] = (int32_t)r;
     else list_scan[atomicAdd(&ctr[CTR_SCAN], 1u)] = (int32_t)r;
     cnt[r] = CNT_DEFER;
 }

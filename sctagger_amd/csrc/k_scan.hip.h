@@ -298,17 +298,22 @@ k_scan_reduce(const int32_t *__restrict__ list, int64_t n_list, int n_slices, in
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_route_long(const uint8_t *__restrict__ segs, const int64_t *__restrict__ offs, int64_t seg_bytes, const int32_t *__restrict__ list_long,
-             int64_t n_long, int prefix_len, int32_t *__restrict__ list_scan, int32_t *__restrict__ list_dp, uint32_t *__restrict__ ctr) {
+             int64_t n_long, int bl, int max_err, int prefix_len, int32_t *__restrict__ list_scan, int32_t *__restrict__ list_dp, uint32_t *__restrict__ ctr) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t li = wave; li < n_long; li += n_waves) {
         const int64_t r = list_long[li];
         bool bad = false;
-        if (prefix_len > 0) {
+        {
             int64_t b0, len;
             sct_row_span(offs, r, seg_bytes, b0, len);
-            for (int64_t i = lane; i < len; i += 64) bad |= !sct_is_acgt(segs[b0 + i]);
+            for (int64_t i = lane; i < len; i += 64) {
+                const uint8_t b = segs[b0 + i];
+                bad |= prefix_len > 0 && !sct_is_acgt(b);
+                // (a row of more than PLANE_MAX characters: the reference raises on a byte >= 128 in any window it inserts)
+                if (b >= 128 && sct_byte_is_read(segs + b0, len, i, bl, max_err, prefix_len)) atomicMin(reinterpret_cast<unsigned long long *>(ctr + CTR_BAD_BYTE), (unsigned long long)(b0 + i));
+            }
         }
         const bool dp = __ballot(bad) != 0;
         if (lane == 0) {

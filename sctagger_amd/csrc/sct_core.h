@@ -19,6 +19,22 @@
 
 SCT_HD uint32_t sct_code(uint8_t b) { return b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 0u; }
 SCT_HD bool sct_is_acgt(uint8_t b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
+
+// Does the reference ever read byte j of a row (row = the row's `len` bytes)?  It reads a byte when it inserts a window that
+// contains it (scTagger.py:677-682: sub = segment[i : i + bl + e], inserted iff it starts with the task's prefix — over all
+// 4^k tasks: iff its first k raw bytes are all in ACGT — and holds at least bl - e characters), decodes and maps every byte of
+// such a window (:682, :555) and raises on one >= 128.  A byte no inserted window covers is never looked at.
+SCT_HD bool sct_byte_is_read(const uint8_t *row, int64_t len, int64_t j, int bl, int max_err, int k) {
+    const int64_t last = len - (bl - max_err);          // last window start that is long enough
+    int64_t i = j - (bl + max_err) + 1;
+    if (i < 0) i = 0;
+    for (; i <= j && i <= last; i++) {
+        bool ok = true;
+        for (int q = 0; q < k; q++) ok = ok && sct_is_acgt(row[i + q]);   // (i + k <= i + bl - e <= len)
+        if (ok) return true;
+    }
+    return false;
+}
 SCT_HD uint32_t sct_low_bits(int k) { return k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u); }
 
 // ---------------------------------------------------------------------------------------------------

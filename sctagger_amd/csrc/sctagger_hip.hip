@@ -13,8 +13,8 @@
 //   seed tables (bl 8..16): per family 8-byte bucket slots and an offsets array (65537 entries; 2^20+1 / 2^22+1
 //              offsets, no slots, for the thirds scheme of large barcode sets) and np entries as pattern ids and as
 //              2-bit codes, see sct_core.h and k_filter.hip.h
-//   per LANE (a stream with its own buffers; lane 0 serves the resident three-step API, lanes 0..2 the chunks of the
-//   stream API in turn):
+//   per LANE (a stream with its own buffers; lane 0 serves the resident three-step API and the one zero-copy chunk a stream
+//   call on page-locked buffers normally is; lanes 0..L-1, option "lanes", the chunks of a stream call that has to upload):
 //     segments   the rows' ASCII bytes + CSR offsets (int64 as uploaded, or uint32 relative to the chunk)
 //     results    min_e u8[n], cnt u32[n], wave_base u64[n/64] (+ slot_off u64[n] for retried rows) + dense slots u32[] (filter path), hit_offs i64[n+1],
 //                hits u32[total], and a 64-byte counter record (CTR_*) the host reads back once per batch
@@ -58,6 +58,7 @@
 // error plumbing
 // ------------------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+static thread_local int g_code = SCT_OK;  // the code of the last fail(): what a failed DevBuf::ensure makes its caller return
 static int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -65,6 +66,7 @@ static int fail(int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_err = buf;
+    g_code = code;
     return code;
 }
 #define HIPCHK(expr)                                                                                         \
@@ -101,7 +103,10 @@ struct DevBuf {
         cap = 0;
         const size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) return fail(SCT_E_HIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(e == hipErrorOutOfMemory ? SCT_E_NOMEM : SCT_E_HIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        }
         cap = want;
         return 0;
     }
@@ -437,7 +442,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
         pat[(size_t)2 * i + 0] = make_uint2(rlo, rhi);  // strand 0 = reverse complement (False sorts first)
         pat[(size_t)2 * i + 1] = make_uint2(flo, fhi);  // strand 1 = forward
     }
-    if (c->pat.ensure(sizeof(uint2) * (size_t)(np ? np : 1))) return SCT_E_HIP;
+    if (c->pat.ensure(sizeof(uint2) * (size_t)(np ? np : 1))) return g_code;
     // every copy below reads a host vector of this scope: each path out of the function synchronises the stream first
     if (np) HIPCHK(hipMemcpyAsync(c->pat.p, pat.data(), sizeof(uint2) * (size_t)np, hipMemcpyHostToDevice, st));
     if (bl >= 8 && bl <= 16) {
@@ -469,7 +474,7 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
                 c->tab_ent16.ensure(pid16.size() * sizeof(uint16_t) + 16) || c->tab_off.ensure(tb.off.size() * sizeof(uint32_t) + 16) ||
                 c->tab_ent.ensure(tb.ent.size() * sizeof(uint32_t)) || c->tab_code.ensure(tb.code.size() * sizeof(uint32_t)) ||
                 c->tab_fb.ensure(tb.fb.size() * sizeof(uint16_t) + 16) || c->tab_wfb.ensure(tb.wfb.size() * sizeof(uint16_t) + 16)) {
-                rc = SCT_E_HIP;
+                rc = g_code;
                 break;
             }
             hipError_t e = hipMemcpyAsync(c->tab_slot.p, tb.slot.data(), tb.slot.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
@@ -545,11 +550,11 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
     const size_t n1 = (size_t)(n ? n : 1);
     if (l.min_e.ensure(n1) || l.cnt.ensure(4 * n1) || l.list_long.ensure(4 * n1) || l.list_scan.ensure(4 * n1) || l.list_dp.ensure(4 * n1) ||
         l.counters.ensure(sizeof(uint32_t) * CTR_WORDS) || l.hit_offs.ensure(8 * (n1 + 1)))
-        return SCT_E_HIP;
+        return g_code;
     const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    if (l.sums.ensure(8 * (size_t)(nb ? nb : 1))) return SCT_E_HIP;
-    if (bp.count_format == SCT_CNT_U8 && l.cnt_out.ensure(n1)) return SCT_E_HIP;
-    if (bp.count_format == SCT_CNT_U32 && l.cnt_out.ensure(4 * n1)) return SCT_E_HIP;
+    if (l.sums.ensure(8 * (size_t)(nb ? nb : 1))) return g_code;
+    if (bp.count_format == SCT_CNT_U8 && l.cnt_out.ensure(n1)) return g_code;
+    if (bp.count_format == SCT_CNT_U32 && l.cnt_out.ensure(4 * n1)) return g_code;
     l.slots_cap = l.retry_cap = 0;
     if (bp.filter_ok) {
         // the main launch keeps at most K_SLOTS hits per row, the retry launch shares a pool of the same size; the CSR hit
@@ -558,9 +563,9 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
         l.retry_cap = (uint64_t)n1 * K_SLOTS < 65536 ? 65536 : (uint64_t)n1 * K_SLOTS;
         if (l.slots.ensure(4 * l.slots_cap) || l.slots_retry.ensure(4 * l.retry_cap) || l.slot_off.ensure(8 * n1) || l.wave_base.ensure(8 * (n1 / 64 + 2)) ||
             l.list_retry.ensure(4 * n1))
-            return SCT_E_HIP;
+            return g_code;
     }
-    if (l.hits.ensure(4 * (size_t)(l.slots_cap + l.retry_cap + 1))) return SCT_E_HIP;
+    if (l.hits.ensure(4 * (size_t)(l.slots_cap + l.retry_cap + 1))) return g_code;
     l.min_e_ptr = l.min_e.as<uint8_t>();
     l.cnt8_ptr = bp.count_format == SCT_CNT_U8 ? l.cnt_out.as<uint8_t>() : nullptr;
     l.cnt32_ptr = bp.count_format == SCT_CNT_U32 ? l.cnt_out.as<uint32_t>() : nullptr;
@@ -664,7 +669,7 @@ static void queue_offsets(sct_ctx *c, Lane &l, bool counts_done = false) {
 // l.seg_bytes, l.wide) are already on the device or their copies are queued on the same stream.  The counter record must
 // have been reset (reset_counters) before whatever checks the input wrote to it.
 static int reset_counters(Lane &l) {
-    if (l.counters.ensure(sizeof(uint32_t) * CTR_WORDS)) return SCT_E_HIP;
+    if (l.counters.ensure(sizeof(uint32_t) * CTR_WORDS)) return g_code;
     HIPCHK(hipMemsetAsync(l.counters.p, 0, sizeof(uint32_t) * CTR_WORDS, l.stream));
     HIPCHK(hipMemsetAsync(l.ctr() + CTR_BAD_ROW, 0xFF, 16, l.stream));
     return SCT_OK;
@@ -704,6 +709,7 @@ static int queue_batch(sct_ctx *c, Lane &l) {
 }
 
 static int ensure_host_hits(sct_ctx *c, size_t entries);
+static uint32_t *host_hits_device_view(sct_ctx *c);
 static inline uint64_t ctr64(const uint32_t *h, int at) { return (uint64_t)h[at] | ((uint64_t)h[at + 1] << 32); }
 
 // The rows the filter kernels left on the lists: scan kernels, then offsets and fill once more.  Synchronises the lane.
@@ -721,33 +727,28 @@ static int slow_path(sct_ctx *c, Lane &l) {
     }
     if (l.host_segs) {
         // a zero-copy batch: the scan kernels read every listed row once per barcode slice — bring the bytes to the device first
-        if (l.segs.ensure((size_t)l.seg_bytes + 64)) return SCT_E_HIP;
+        if (l.segs.ensure((size_t)l.seg_bytes + 64)) return g_code;
         if (l.seg_bytes) HIPCHK(hipMemcpyAsync(l.segs.p, l.host_segs, (size_t)l.seg_bytes, hipMemcpyHostToDevice, st));
         l.segs_ptr = l.segs.as<uint8_t>();
         l.host_segs = nullptr;
     }
-    if (!l.wide && l.seg_bytes) {
-        // stream batches: the filter kernel looked for bytes >= 128 only in the rows it decoded; the listed rows are checked here
-        k_validate<<<blocks_for((l.seg_bytes + 15) / 16, 256), 256, 0, st>>>(l.segs.as<uint8_t>(), l.seg_bytes, nullptr, 0,
-                                                                           reinterpret_cast<unsigned long long *>(ctr + CTR_BAD_ROW));
-    }
     // the scan kernels take int64 offsets
     if (!l.have_offs64) {
-        if (l.offs64.ensure(8 * (size_t)(n + 1))) return SCT_E_HIP;
+        if (l.offs64.ensure(8 * (size_t)(n + 1))) return g_code;
         k_widen_offs<<<blocks_for(n + 1, 256), 256, 0, st>>>(l.offs32.as<uint32_t>(), n + 1, l.offs64.as<int64_t>());
         l.have_offs64 = true;
     }
     const int64_t *offs = l.offs64.as<int64_t>();
     if (h[CTR_LONG]) {  // rows the filter only listed: exhaustive scan or DP?
         k_route_long<<<blocks_for((int64_t)h[CTR_LONG], 4), 256, 0, st>>>(l.segs_ptr, offs, l.seg_bytes, l.list_long.as<int32_t>(),
-                                                                         (int64_t)h[CTR_LONG], bp.prefix_len, l.list_scan.as<int32_t>(),
+                                                                         (int64_t)h[CTR_LONG], bl, bp.max_err, bp.prefix_len, l.list_scan.as<int32_t>(),
                                                                          l.list_dp.as<int32_t>(), ctr);
         HIPCHK(hipMemcpyAsync(h, l.counters.p, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     const uint32_t n_scan = h[CTR_SCAN], n_dp = h[CTR_DP];
     // remember which rows are deferred: their cnt is about to be overwritten by the count passes (k_fill skips them)
-    if (l.route.ensure(4 * (size_t)(n ? n : 1))) return SCT_E_HIP;
+    if (l.route.ensure(4 * (size_t)(n ? n : 1))) return g_code;
     HIPCHK(hipMemcpyAsync(l.route.p, l.cnt.p, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
     auto slices_for = [&](uint32_t rows) {  // a short list is cut into pattern slices so that the whole chip works on it
         if (rows == 0) return 1;
@@ -766,7 +767,7 @@ static int slow_path(sct_ctx *c, Lane &l) {
     const int sl_scan = slices_for(n_scan), sl_dp = slices_for(n_dp);
     if (l.part_best.ensure(4 * ((size_t)n_scan * sl_scan + (size_t)n_dp * sl_dp + 1)) ||
         l.part_cnt.ensure(4 * ((size_t)n_scan * sl_scan + (size_t)n_dp * sl_dp + 1)))
-        return SCT_E_HIP;
+        return g_code;
     uint32_t *pb_scan = l.part_best.as<uint32_t>(), *pc_scan = l.part_cnt.as<uint32_t>();
     uint32_t *pb_dp = pb_scan + (size_t)n_scan * sl_scan, *pc_dp = pc_scan + (size_t)n_scan * sl_scan;
     const uint8_t *segs = l.segs_ptr;
@@ -799,10 +800,11 @@ static int slow_path(sct_ctx *c, Lane &l) {
     if (l.hits_cap < total) {
         if (l.direct_hits) {
             if (int rc = ensure_host_hits(c, (size_t)total + 1)) return rc;
-            l.hits_ptr = c->h_hits;
+            l.hits_ptr = host_hits_device_view(c);
+            if (!l.hits_ptr) return fail(SCT_E_STATE, "the page-locked result buffer is not mapped into the device");
             l.hits_cap = c->h_hits_cap;
         } else {
-            if (l.hits.ensure(4 * (size_t)(total + 1))) return SCT_E_HIP;
+            if (l.hits.ensure(4 * (size_t)(total + 1))) return g_code;
             l.hits_ptr = l.hits.as<uint32_t>();
             l.hits_cap = l.hits.cap / 4;
         }
@@ -861,7 +863,8 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
     if (l.direct_hits && ctr64(h, CTR_TOTAL) > l.hits_cap) {
         // the fill kernel found the caller-visible hit buffer too small and wrote nothing: enlarge it, fill again
         if (int rc = ensure_host_hits(c, (size_t)ctr64(h, CTR_TOTAL) + 1)) return rc;
-        l.hits_ptr = c->h_hits;
+        l.hits_ptr = host_hits_device_view(c);
+        if (!l.hits_ptr) return fail(SCT_E_STATE, "the page-locked result buffer is not mapped into the device");
         l.hits_cap = c->h_hits_cap;
         if (l.bp.filter_ok && l.n_seg > 0)
             k_fill<<<blocks_for(l.n_seg, 256), 256, 0, l.stream>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
@@ -885,7 +888,8 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
 // ------------------------------------------------------------------------------------------------------------
 // the resident three-step API (lane 0)
 // ------------------------------------------------------------------------------------------------------------
-extern "C" int sct_upload_segments(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n) {
+// check_bytes: refuse any byte >= 128 (the two neighbouring stages); the match_trie path checks the rows it reads instead
+static int upload_segments(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n, bool check_bytes) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
     if (n < 0 || !offs) return fail(SCT_E_ARG, "sct_upload_segments: bad offsets");
     if (n >= 0x7FFFFFF0) return fail(SCT_E_ARG, "at most 2^31-16 segments per call (shard the input)");
@@ -895,19 +899,19 @@ extern "C" int sct_upload_segments(sct_ctx *c, const char *segs, const int64_t *
     if (bytes > 0 && !segs) return fail(SCT_E_ARG, "segs is NULL");
     HIPCHK(hipSetDevice(c->device));
     Lane &l = c->lane0();
-    if (l.segs.ensure((size_t)bytes + 64)) return SCT_E_HIP;
-    if (l.offs64.ensure(sizeof(int64_t) * (size_t)(n + 1))) return SCT_E_HIP;
+    if (l.segs.ensure((size_t)bytes + 64)) return g_code;
+    if (l.offs64.ensure(sizeof(int64_t) * (size_t)(n + 1))) return g_code;
     hipStream_t st = l.stream;
     l.n_seg = -1;
     l.have_result = false;
     if (int rc = reset_counters(l)) return rc;
     if (bytes) HIPCHK(hipMemcpyAsync(l.segs.p, segs, (size_t)bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(l.offs64.p, offs, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, st));
-    // validation on the device, before any kernel trusts the offsets: non-decreasing, inside the byte buffer, and
-    // no byte >= 128 (the reference raises on those); the host only reads back two words
-    const int64_t items = (n + 1) > (bytes + 15) / 16 ? (n + 1) : (bytes + 15) / 16;
+    // validation on the device, before any kernel trusts the offsets: non-decreasing, inside the byte buffer; the host only
+    // reads back two words.  Bytes >= 128: see k_validate.
+    const int64_t items = (!check_bytes || (n + 1) > (bytes + 15) / 16) ? (n + 1) : (bytes + 15) / 16;
     k_validate<<<blocks_for(items, 256), 256, 0, st>>>(l.segs.as<uint8_t>(), bytes, l.offs64.as<int64_t>(), n,
-                                                      reinterpret_cast<unsigned long long *>(l.ctr() + CTR_BAD_ROW));
+                                                      reinterpret_cast<unsigned long long *>(l.ctr() + CTR_BAD_ROW), check_bytes);
     unsigned long long bad[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(bad, l.ctr() + CTR_BAD_ROW, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -922,6 +926,8 @@ extern "C" int sct_upload_segments(sct_ctx *c, const char *segs, const int64_t *
     l.host_segs = nullptr;
     return SCT_OK;
 }
+
+extern "C" int sct_upload_segments(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n) { return upload_segments(c, segs, offs, n, false); }
 
 extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_hits_out) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
@@ -959,13 +965,17 @@ extern "C" int sct_download(sct_ctx *c, uint8_t *min_e, int64_t *hit_offs, uint3
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// the stream API: the seam in one call, rows cut into chunks that move through L lanes (option "lanes", default 5)
+// the stream API: the seam in one call.
+// Page-locked (or registered) caller buffers — the shipped default: ZERO COPY.  The kernels read segs / index and write min_e /
+// counts / hits in the caller's memory through its device mapping; the call is ONE chunk of up to 2^24 rows on lane 0 (more
+// rows, or more than 3 GiB of segment bytes: further chunks, one after the other on lanes 0..L-1):
+//   index -> uint32 offsets (k_index_*) -> filter launches (rows cross the link inside k_filter) -> offsets -> fill -> counters
+// Buffers that cannot be mapped are uploaded: the rows are cut into chunks (option "chunk_rows", default 2^20 for page-locked
+// memory with "zero_copy" off, 2^24 for pageable memory) that move through L lanes (option "lanes", default 5)
 //   lane k mod L:   H2D(chunk k) -> index / byte checks -> filter launches -> offsets -> fill -> D2H(min_e, counts, counters)
 // queued L - 1 chunks ahead of the chunk the host is waiting for, so that while chunk k computes, the chunks after it are on
-// their way to the device and the results of the chunks before it on their way back.  One chunk takes about three times as
-// long from its first byte up to its last byte down as its upload alone (1 M rows: 0.4 ms up, 0.65 ms of kernels, 0.15 ms
-// down, the host's turn-around in between), and a lane is busy for all of that: three lanes leave both the link and the
-// chip idle a third of the time (profiles/r02_stream_timeline_3lanes.txt), five keep the link busy.
+// their way to the device and the results of the chunks before it on their way back (measured: DESIGN.md 5b — the chunked
+// pipeline needs 6.6 - 8.2 ms per 10 M rows where zero copy needs 5.1).
 // ------------------------------------------------------------------------------------------------------------
 static int ensure_host_hits(sct_ctx *c, size_t entries) {
     if (entries <= c->h_hits_cap) return SCT_OK;
@@ -975,7 +985,10 @@ static int ensure_host_hits(sct_ctx *c, size_t entries) {
     while (want < entries) want *= 2;
     uint32_t *p = nullptr;
     hipError_t e = hipHostMalloc((void **)&p, want * sizeof(uint32_t), hipHostMallocDefault);
-    if (e != hipSuccess) return fail(SCT_E_HIP, "hipHostMalloc(%zu) for the hit buffer: %s", want * sizeof(uint32_t), hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? SCT_E_NOMEM : SCT_E_HIP, "hipHostMalloc(%zu) for the hit buffer: %s", want * sizeof(uint32_t), hipGetErrorString(e));
+    }
     if (c->h_hits) {
         memcpy(p, c->h_hits, c->h_hits_cap * sizeof(uint32_t));
         (void)hipHostFree(c->h_hits);
@@ -983,6 +996,17 @@ static int ensure_host_hits(sct_ctx *c, size_t entries) {
     c->h_hits = p;
     c->h_hits_cap = want;
     return SCT_OK;
+}
+
+// the page-locked result buffer as the kernels must address it (hipHostMalloc memory is mapped into the device's address space;
+// on ROCm the two addresses coincide, but that is the runtime's business): NULL if it is not mapped
+static uint32_t *host_hits_device_view(sct_ctx *c) {
+    if (!c->h_hits) return nullptr;
+    hipPointerAttribute_t at;
+    uint32_t *d = nullptr;
+    if (hipPointerGetAttributes(&at, c->h_hits) == hipSuccess && at.type == hipMemoryTypeHost) d = (uint32_t *)at.devicePointer;
+    (void)hipGetLastError();
+    return d;
 }
 
 static inline size_t index_entry_size(int fmt) {
@@ -1104,9 +1128,9 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     }
     if (int rc = ensure_host_hits(c, (size_t)(n < (1 << 18) ? (1 << 18) : n + n / 4))) return rc;
     // a call of one chunk lets the fill kernel write the hits into the page-locked result buffer itself
-    uint32_t *zc_hits = (n_chunks == 1 && !hits16) ? (uint32_t *)device_view(c->h_hits) : nullptr;
+    uint32_t *zc_hits = (n_chunks == 1 && !hits16 && c->zero_copy) ? host_hits_device_view(c) : nullptr;
     // 16-bit hits: the lists are assembled on the device as always and a last kernel writes them, narrowed, into the result buffer
-    uint16_t *zc_hits16 = hits16 ? (uint16_t *)device_view(c->h_hits, true) : nullptr;
+    uint16_t *zc_hits16 = hits16 ? (uint16_t *)host_hits_device_view(c) : nullptr;
     if (hits16 && !zc_hits16) return fail(SCT_E_STATE, "the page-locked result buffer is not mapped into the device");
     std::vector<ChunkPlan> plan((size_t)n_chunks);
     const size_t isz = index_entry_size(index_format);
@@ -1174,9 +1198,9 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
             l.hits_cap = 2 * (uint64_t)c->h_hits_cap;
             cp.narrow_cap = l.hits_cap;
         }
-        if (l.offs32.ensure(4 * (size_t)(m + 1))) return SCT_E_HIP;
-        if (!zc_segs && l.segs.ensure((size_t)bytes + 64)) return SCT_E_HIP;
-        if ((!zc_index || !by_offs) && l.index_in.ensure(isz * (size_t)(m + 1) + 16)) return SCT_E_HIP;
+        if (l.offs32.ensure(4 * (size_t)(m + 1))) return g_code;
+        if (!zc_segs && l.segs.ensure((size_t)bytes + 64)) return g_code;
+        if ((!zc_index || !by_offs) && l.index_in.ensure(isz * (size_t)(m + 1) + 16)) return g_code;
         hipStream_t st = l.stream;
         if (int rc = reset_counters(l)) return rc;
         const void *idx_dev = zc_index ? (const void *)(zc_index + isz * (size_t)cp.r0) : l.index_in.p;
@@ -1265,14 +1289,16 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
                 if (l.n_hits && (n_chunks > 1 || slow || (uint64_t)l.n_hits > cp.narrow_cap)) {
                     if (l.hits16_ptr && !slow) {
                         // the fill kernel found the result buffer too small and wrote nothing: fill the 32-bit array on the device first
-                        if (l.hits.ensure(4 * (size_t)(l.n_hits + 1))) return SCT_E_HIP;
+                        if (l.hits.ensure(4 * (size_t)(l.n_hits + 1))) return g_code;
                         k_fill<<<blocks_for(m, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
                                                                    l.wave_base.as<uint64_t>(), l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(), m,
                                                                    l.hits.as<uint32_t>(), l.hits.cap / 4, l.ctr(), nullptr);
                         l.hits_ptr = l.hits.as<uint32_t>();
                     }
-                    k_narrow_hits<<<blocks_for(l.n_hits, 2048), 256, 0, st>>>(l.hits_ptr, l.ctr(), ~0ull,
-                                                                              (uint16_t *)device_view(c->h_hits, true) + hit_base);
+                    // (ensure_host_hits above may have moved the buffer: ask for its device view again)
+                    uint16_t *out16 = (uint16_t *)host_hits_device_view(c);
+                    if (!out16) return fail(SCT_E_STATE, "the page-locked result buffer is not mapped into the device");
+                    k_narrow_hits<<<blocks_for(l.n_hits, 2048), 256, 0, st>>>(l.hits_ptr, l.ctr(), ~0ull, out16 + hit_base);
                 }
             } else if (l.n_hits && !l.direct_hits) {
                 HIPCHK(hipMemcpyAsync(c->h_hits + hit_base, l.hits_ptr, 4 * (size_t)l.n_hits, hipMemcpyDeviceToHost, st));
@@ -1327,7 +1353,7 @@ extern "C" int sct_match(sct_ctx *c, const char *segs, const int64_t *offs, int6
     int rc = sct_match_stream(c, segs, offs[n], offs, SCT_IDX_OFFS64, n, max_err, threads, min_e, hit_offs, SCT_CNT_OFFS64, SCT_HITS_U32, &h, &total);
     if (rc) return rc;
     uint32_t *out = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(total ? total : 1));
-    if (!out) return fail(SCT_E_ARG, "out of host memory for %lld hits", (long long)total);
+    if (!out) return fail(SCT_E_NOMEM, "out of host memory for %lld hits", (long long)total);
     if (total) memcpy(out, h, sizeof(uint32_t) * (size_t)total);
     *hits = out;
     *n_hits = total;
@@ -1414,7 +1440,7 @@ extern "C" int sct_wl_set(sct_ctx *c, const char *keys, const int32_t *key_lens,
         }
     }
     hipStream_t st = c->lane0().stream;
-    if (c->wl_table.ensure(tab.size() * sizeof(SctWlSlot))) return SCT_E_HIP;
+    if (c->wl_table.ensure(tab.size() * sizeof(SctWlSlot))) return g_code;
     HIPCHK(hipMemcpyAsync(c->wl_table.p, tab.data(), tab.size() * sizeof(SctWlSlot), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     c->wl_mask = mask;
@@ -1428,11 +1454,11 @@ extern "C" int sct_wl_count(sct_ctx *c, const char *segs, const int64_t *offs, c
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
     if (c->wl_n < 0) return fail(SCT_E_STATE, "sct_wl_count before sct_wl_set");
     if (!counts || !first_seen || (n > 0 && !skip)) return fail(SCT_E_ARG, "sct_wl_count: NULL argument");
-    int rc = sct_upload_segments(c, segs, offs, n);
+    int rc = upload_segments(c, segs, offs, n, true);
     if (rc) return rc;
     Lane &l = c->lane0();
     const size_t nk = (size_t)(c->wl_n > 0 ? c->wl_n : 1);
-    if (c->wl_counts.ensure(4 * nk) || c->wl_first.ensure(4 * nk) || c->wl_skip.ensure((size_t)(n ? n : 1))) return SCT_E_HIP;
+    if (c->wl_counts.ensure(4 * nk) || c->wl_first.ensure(4 * nk) || c->wl_skip.ensure((size_t)(n ? n : 1))) return g_code;
     hipStream_t st = l.stream;
     c->last_ms.clear();
     l.timed.clear();
@@ -1474,7 +1500,7 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
     if (m > 32) return fail(SCT_E_UNSUPPORTED, "adapter length %d exceeds the supported maximum 32", m);
     for (int i = 0; i < m; i++)
         if ((uint8_t)adapter[i] >= 128) return fail(SCT_E_ARG, "adapter contains a byte >= 128");
-    int rc = sct_upload_segments(c, reads, offs, n);
+    int rc = upload_segments(c, reads, offs, n, true);
     if (rc) return rc;
     Lane &l = c->lane0();
     // match masks: adapter, its reverse complement (rev_compl, scTagger.py:148-156, :365), and that one reversed
@@ -1490,9 +1516,9 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
     if (c->ad_peq.ensure(peq.size() * 4) || c->ad_strand.ensure(n1) || c->ad_dist.ensure(4 * n1) || l.cnt.ensure(4 * n1) ||
         c->ad_first.ensure(8 * n1) || c->ad_last.ensure(8 * n1) || l.hit_offs.ensure(8 * (n1 + 1)) ||
         l.counters.ensure(sizeof(uint32_t) * CTR_WORDS))
-        return SCT_E_HIP;
+        return g_code;
     const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    if (l.sums.ensure(8 * (size_t)(nb ? nb : 1))) return SCT_E_HIP;
+    if (l.sums.ensure(8 * (size_t)(nb ? nb : 1))) return g_code;
     hipStream_t st = l.stream;
     c->last_ms.clear();
     l.timed.clear();
@@ -1524,7 +1550,7 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
         if (e == hipSuccess) e = es;
     }
     if (e == hipSuccess && n > 0 && total) {
-        if (c->ad_locs.ensure(4 * (size_t)total)) return SCT_E_HIP;
+        if (c->ad_locs.ensure(4 * (size_t)total)) return g_code;
         Timer t(c, l, "k_adapter_fill");
         k_adapter_fill<<<blocks_for(n, 256), 256, 0, st>>>(l.segs.as<uint8_t>(), l.offs64.as<int64_t>(), n, c->ad_peq.as<uint32_t>(), m,
                                                           c->ad_strand.as<int8_t>(), c->ad_dist.as<int32_t>(), c->ad_first.as<int64_t>(),
@@ -1534,7 +1560,7 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
         h = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total ? total : 1));
         if (!h) {
             (void)hipStreamSynchronize(st);
-            return fail(SCT_E_ARG, "out of host memory");
+            return fail(SCT_E_NOMEM, "out of host memory");
         }
     }
     if (n == 0) loc_offs[0] = 0;

@@ -220,8 +220,66 @@ def seam_vectors(mod, lr, sr):
         json.dump(out, f)
 
 
+def high_byte_vectors(mod):
+    """G13: bytes >= 128 at the in-process seam (module globals set as read_long_reads / read_sr_barcodes leave them,
+    scTagger.py:616-627, :631-640): what run_get_matches_prefix returns, or which exception it raises."""
+    from multiprocessing import RawArray
+    rng = np.random.default_rng(13)
+    bcs = ["".join("ACGT"[x] for x in rng.integers(0, 4, 16)) for _ in range(40)]
+    good = [b"TCT" + bcs[3].encode() + b"ACG", b"GG" + bcs[7][:9].encode() + bcs[7][10:].encode() + b"TTTTTT", b"", b"ACGTACGTAC"]
+
+    def with_byte(row, at, val):
+        r = bytearray(row)
+        r[at:at + len(val)] = val
+        return bytes(r)
+    rows = {
+        "short_row_10": [b"ACGT\x80CGTAC"[:10]],                       # shorter than bl - e at e = 1, 2: never inserted
+        "row_13": [with_byte(b"ACGTACGTACGTA", 6, b"\x80")],            # 13 = bl - e - 1 at e = 2; bl - e - 2 at e = 1
+        "row_14": [with_byte(b"ACGTACGTACGTAC", 6, b"\x80")],           # 14 = bl - e at e = 2: inserted; too short at e = 1
+        "row_22_mid": [with_byte(good[0], 9, b"\xff")],
+        "row_22_utf8_pair": [with_byte(good[0], 9, b"\xc3\xa9")],      # decodes to one char, ord 233: IndexError instead
+        "row_22_first": [with_byte(good[0], 0, b"\x80")],               # only the window at 0 covers byte 0
+        "row_22_last": [with_byte(good[0], 21, b"\x80")],
+        "row_22_second": [with_byte(good[0], 1, b"\x80")],
+        "row_80_late": [with_byte(good[0] + b"ACGT" * 14 + b"AC", 70, b"\x80")],
+        "row_80_first": [with_byte(good[0] + b"ACGT" * 14 + b"AC", 0, b"\x80")],
+    }
+    out = {"barcodes": bcs, "good_rows": [g.decode() for g in good], "cases": {}}
+    for name, bad in rows.items():
+        segs = good[:2] + bad + good[2:]
+        flat = b"".join(segs)
+        mod.barcodes = list(bcs)
+        mod.barcodes_rc = [mod.rev_compl(b) for b in bcs]
+        mod.lr_segs = RawArray("c", len(flat))
+        mod.lr_segs[:] = flat
+        mod.lr_segs_idxs = RawArray("i", len(segs) + 1)
+        a = 0
+        for i, sg in enumerate(segs):
+            mod.lr_segs_idxs[i] = a
+            a += len(sg)
+        mod.lr_segs_idxs[len(segs)] = a
+        mod.lr_names = ["r%d" % i for i in range(len(segs))]
+        case = {"rows_hex": [sg.hex() for sg in segs], "runs": {}}
+        for e in (1, 2):
+            for t in (1, 4, 16):
+                try:
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        r = mod.run_get_matches_prefix(e, t)
+                    case["runs"]["%d:%d" % (e, t)] = sorted(
+                        [int(rid), int(d), sorted([int(b), bool(st)] for b, st in X)] for rid, (d, X) in r.items())
+                except Exception as ex:     # the pool re-raises the worker's exception in the parent
+                    case["runs"]["%d:%d" % (e, t)] = "raises " + type(ex).__name__
+        out["cases"][name] = case
+        print("  g13 %s: %s" % (name, {k: (v if isinstance(v, str) else "%d rows" % len(v)) for k, v in case["runs"].items()}), file=sys.stderr)
+    with open(os.path.join(HERE, "g13.high_bytes.json"), "w") as f:
+        json.dump(out, f)
+
+
 def main():
     mod = load_reference()
+    if "g13" in sys.argv[1:]:   # bytes >= 128: where the reference raises and where it never looks
+        high_byte_vectors(mod)
+        return
     if "g12" in sys.argv[1:]:   # a sub-sample of BASELINE configs[1] (1 M x 5 k, e<=2) at the reference's default -t 16
         lr, sr = synth_pair("g12", 3000, 5000, 16, seed=2, gz_bc=True)
         expected(mod, "g12", lr, sr, 2, 16, 16)

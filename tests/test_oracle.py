@@ -71,3 +71,30 @@ def test_oracle_rejects_high_bytes():
     segs = np.frombuffer(b"ACGT\xc3\xa9ACGTACGTACGTACGT", dtype=np.uint8)
     with pytest.raises(ValueError):
         trie_oracle.match(bc, segs, np.array([0, segs.size], dtype=np.int64), 1)
+
+
+def test_oracle_high_bytes_follow_the_reference():
+    """g13: bytes >= 128 — the reference raises exactly when it inserts a window that contains one (scTagger.py:677-682)
+    and never looks at the others (short rows; with -t > 1 windows whose first k bytes are not all ACGT)."""
+    import json
+    with open(os.path.join(util.GOLDEN, "g13.high_bytes.json")) as f:
+        g = json.load(f)
+    bc = util.bc_matrix(g["barcodes"], 16)
+    seen = set()
+    for name, case in g["cases"].items():
+        rows = [bytes.fromhex(h) for h in case["rows_hex"]]
+        segs = np.frombuffer(b"".join(rows), dtype=np.uint8)
+        offs = np.zeros(len(rows) + 1, dtype=np.int64)
+        np.cumsum([len(r) for r in rows], out=offs[1:])
+        for key, want in case["runs"].items():
+            e, t = (int(x) for x in key.split(":"))
+            if isinstance(want, str):
+                with pytest.raises(ValueError):
+                    trie_oracle.match(bc, segs, offs, e, threads=t)
+                seen.add("raises")
+            else:
+                me, ho, hits = trie_oracle.match(bc, segs, offs, e, threads=t)
+                got = [[rid, int(me[rid]), [[int(p) >> 1, bool(p & 1)] for p in hits[ho[rid]:ho[rid + 1]]]] for rid in range(len(rows)) if me[rid] != 0xFF]
+                assert got == want, (name, key)
+                seen.add("rows")
+    assert seen == {"raises", "rows"}
