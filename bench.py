@@ -83,11 +83,11 @@ def pmc_quote(workload_desc, fname="k_filter_counters.json"):
     return q if shape(q.get("workload", "")) == shape(workload_desc) else None
 
 
-def make_batch(n, bc, seed, chunk=1_000_000, seg_len=22):
+def make_batch(n, bc, seed, chunk=1_000_000, seg_len=22, frac_empty=0.05):
     """Seeded synthetic segments, generated in chunks to bound host memory."""
     segs, offs, base = [], [np.zeros(1, np.int64)], 0
     for i, c0 in enumerate(range(0, n, chunk)):
-        s, o = synth.make_segments(min(chunk, n - c0), bc, seed=seed * 1000 + i, seg_len=seg_len)
+        s, o = synth.make_segments(min(chunk, n - c0), bc, seed=seed * 1000 + i, seg_len=seg_len, frac_empty=frac_empty)
         segs.append(s)
         offs.append(o[1:] + base)
         base += int(o[-1])
@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--max-err", type=int, default=None, help="override the workload's max_err (exploration)")
     ap.add_argument("--slots", type=int, default=-1, help="bucket slots of the seed tables: -1 = library default, 0 = off, 1 = on (exploration)")
     ap.add_argument("--seg-len", type=int, default=22, help="segment length of the synthetic rows (22 = the reference's nominal length)")
+    ap.add_argument("--frac-empty", type=float, default=0.05, help="share of empty rows (SURVEY 8(d): 5 %%; exploration)")
     ap.add_argument("--index-format", default="len8", choices=sorted(IDX), help="row index handed to the seam (len8 = one byte per row)")
     ap.add_argument("--count-format", default="u8", choices=sorted(CNT), help="hit counts taken from the seam (u8 = one byte per row)")
     ap.add_argument("--hits-format", default="u16", choices=sorted(HITS), help="hit lists taken from the seam (u16 while the barcode set has at most 32768 entries)")
@@ -383,7 +384,7 @@ def main():
     bc_seed = SEEDS.get(wl, 3)
     bc = synth.make_barcodes(n_bc, bl=bl, seed=bc_seed)
     seed = SEEDS.get(wl, 3) if world == 1 else 40 + rank   # cfg4's shards are seeds 40..47
-    segs, offs = make_batch(n_seg, bc, seed, seg_len=args.seg_len)
+    segs, offs = make_batch(n_seg, bc, seed, seg_len=args.seg_len, frac_empty=args.frac_empty)
 
     m = _native.Matcher(device)
     for kv in args.option:

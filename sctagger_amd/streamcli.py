@@ -84,17 +84,22 @@ def _inflate_pieces(path, piece_bytes):
         data = f.read()
     at = _gzip_header_end(data, 0)
     if at is None:                                # not a plain gzip member at offset 0: let zlib judge
-        d = zlib.decompressobj(31)
+        # bounded output per call (a small input can expand a thousandfold) and, like gzip.open in the reference (:605-606),
+        # EOFError for a stream that stops before its end-of-stream marker
+        d, started = zlib.decompressobj(31), False
         for a in range(0, len(data), 1 << 20):
             raw = data[a:a + (1 << 20)]
             while raw:
-                out = d.decompress(raw)
-                raw = b""
+                out = d.decompress(raw, piece_bytes)
+                started = True
+                raw = d.unconsumed_tail
                 if d.eof:
-                    raw = d.unused_data
-                    d = zlib.decompressobj(31)
+                    raw = d.unused_data.lstrip(b"\0") if not raw else raw
+                    d, started = zlib.decompressobj(31), False
                 if out:
                     yield out
+        if started and not d.eof:
+            raise EOFError("Compressed file ended before the end-of-stream marker was reached")
         return
     lib = _iolib()
     base = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value

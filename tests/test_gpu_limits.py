@@ -38,7 +38,7 @@ def stream_pinned(m, segs, offs, e, t):
     ps, pl = pinned_copy(m, segs), pinned_copy(m, np.diff(offs).astype(np.uint8))
     me, cnt, hits = m.match_stream(ps, pl, e, t, index_format=_native.IDX_LEN8, count_format=_native.CNT_U8,
                                    min_e=m.host_array(max(offs.size - 1, 1), np.uint8), counts=m.host_array(max(offs.size - 1, 1), np.uint8))
-    return me.copy(), counts_to_offsets(cnt), hits.astype(np.uint32)
+    return me.copy(), counts_to_offsets(cnt, _native.CNT_U8), hits.astype(np.uint32)
 
 
 @pytest.mark.parametrize("exhaustive", [0, 1], ids=["filter", "exhaustive"])
@@ -105,7 +105,7 @@ def test_more_than_2_24_rows_in_one_stream_call_at_the_default_chunking(m):
     bme, bcnt, bhits = m.match_stream(pinned_copy(m, bsegs), pinned_copy(m, np.diff(boffs).astype(np.uint8)), 2, 1, index_format=_native.IDX_LEN8,
                                       count_format=_native.CNT_U8, hits_format=_native.HITS_U16)
     want = trie_oracle.match(bc, bsegs[:boffs[20000]], boffs[:20001], 2, threads=1, workers=8)
-    assert np.array_equal(bme[:20000], want[0]) and np.array_equal(counts_to_offsets(bcnt[:20000]), want[1])
+    assert np.array_equal(bme[:20000], want[0]) and np.array_equal(counts_to_offsets(bcnt[:20000], _native.CNT_U8), want[1])
     assert np.array_equal(bhits[:want[2].size].astype(np.uint32), want[2])
     assert np.array_equal(me, np.tile(bme, reps)) and np.array_equal(cnt, np.tile(bcnt, reps)) and np.array_equal(hits, np.tile(bhits, reps))
     # the resident route over the same 20 M rows
