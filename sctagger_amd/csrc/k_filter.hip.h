@@ -174,7 +174,7 @@ struct FamTables {
 template <typename W, int HM, int QC, bool WIDE = false>
 struct FilterWaveLds {
     static constexpr int QCAP = QC;
-    typedef typename std::conditional<WIDE, uint32_t, uint16_t>::type PtabT;
+    typedef typename std::conditional<WIDE || sizeof(W) == 8, uint32_t, uint16_t>::type PtabT;
     static constexpr int PTAB = WIDE ? (sizeof(W) == 4 ? 160 : 448) : (sizeof(W) == 4 ? 128 : 320);
     static constexpr int HMAX = HM;
     alignas(32) W em[64][4];  // em[lane][c]: bit i+1 set iff character i of the lane's segment has code c (bits 1..len)
@@ -184,7 +184,8 @@ struct FilterWaveLds {
     } pl[64];            // the segments' bit-planes (lookup lanes read the planes of the segment they work for)
     uint8_t slen[64];    // and lengths
     uint8_t alist[64];   // lanes whose segment still generates candidates, compacted
-    PtabT ptab[PTAB];    // this family's placements for the longest segment: t | t2 << 8 (| u << 16)
+    PtabT ptab[PTAB];    // this family's placements for the longest segment: t | t2 << PF | need << 2 PF, PF = 5 / 6 bits (32- / 64-bit
+                         // masks; FilterWave::build_ptab); wide families: t | t2 << 8 | u << 16
     uint32_t best[64];   // smallest distance verified so far for the lane's segment
     uint32_t hcnt[64];
     alignas(16) uint32_t hlist[HM][64];  // hlist, qk and qm double as the stage of the ASCII decode (k_decode.hip.h)
@@ -556,6 +557,27 @@ struct FilterWave {
         }
     }
 
+    // The family's placements for a text of `maxlen` characters (the wave's longest), pruned (sct_placement_need, sct_core.h):
+    // one lane per start t, shift after shift, so the table is ordered by (d, t) as the unpruned walk was.  An entry carries the
+    // shortest text the placement is worth a lookup for; a lane working for a shorter segment skips it.
+    static constexpr int PF = sizeof(W) == 4 ? 5 : 6;
+    static constexpr uint32_t PFM = (1u << PF) - 1u;
+    template <typename Fam>
+    __device__ __forceinline__ int build_ptab(const Fam &fam, int maxlen) {
+        int P = 0;
+#pragma unroll
+        for (int d = -fam.SLACK; d <= fam.SLACK; d++) {
+            const int t2 = lane + fam.GAP + d;
+            const int need = sct_placement_need(fam, E, lane, t2);
+            const bool ok = need <= maxlen;
+            const uint64_t m = __ballot(ok);
+            if (ok) L.ptab[P + (int)lane_rank(m)] = (typename FilterWaveLds<W, HM, QCAP, WIDE>::PtabT)((uint32_t)lane | ((uint32_t)t2 << PF) | ((uint32_t)need << (2 * PF)));
+            P += (int)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        return P;
+    }
+
     // One family.  The lookups are spread over the lanes as (active segment, placement) PAIRS: with A segments of
     // the wave still generating candidates and P placements, the A * P pairs are numbered placement-major and every
     // pass takes the next 64 of them, so the wave-uniform cost of a pass is shared by 64 lookups even when most
@@ -568,17 +590,7 @@ struct FilterWave {
         if (am == 0) return;
         const int A = (int)__popcll(am);
         if (active) L.alist[lane_rank(am)] = (uint8_t)lane;
-        // placement table
-        int P = 0;
-#pragma unroll
-        for (int d = -fam.SLACK; d <= fam.SLACK; d++) {
-            const int c = maxlen - fam.GAP - d - fam.LB + 1;
-            if (c > 0) {
-                for (int t = lane; t < c; t += 64) L.ptab[P + t] = (uint16_t)(t | ((t + fam.GAP + d) << 8));
-                P += c;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+        const int P = build_ptab(fam, maxlen);
         if (P == 0) return;
         // SL:  pair q = 64 * pass + lane is placement q / A of the (q mod A)-th active segment; advancing q by 64 moves
         //      the lane dp placements on and da segments further (with a carry): every pass takes 64 pairs
@@ -610,8 +622,8 @@ struct FilterWave {
             if constexpr (SL) {
                 // branch-free: a lane without a lookup of its own reads the spare all-zero slot behind the family's keys
                 const uint32_t tt = L.ptab[p < P ? p : P - 1];
-                const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
-                const bool ok = worker && p < P && sct_valid_of(fam, t2, slen);
+                const int t = (int)(tt & PFM), t2 = (int)((tt >> PF) & PFM);
+                const bool ok = worker && p < P && (int)(tt >> (2 * PF)) <= slen;
                 const uint32_t key = sct_key_of<W>(fam, slo, shi, t, t2);
                 const uint2 sv = slot[ok ? key : (uint32_t)fam.NKEYS];
                 s = sv.x;
@@ -624,8 +636,8 @@ struct FilterWave {
 #endif
             } else if (worker && p < P) {
                 const uint32_t tt = L.ptab[p];
-                const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
-                if (sct_valid_of(fam, t2, slen)) {
+                const int t = (int)(tt & PFM), t2 = (int)((tt >> PF) & PFM);
+                if ((int)(tt >> (2 * PF)) <= slen) {
                     // one 8-byte load: the bucket's slot, or its start and end (neighbouring words, 4-byte aligned;
                     // absolute entry indices).  Nothing depends on the load until the bucket is queued, one pass later.
                     const uint32_t key = sct_key_of<W>(fam, slo, shi, t, t2);
@@ -725,16 +737,7 @@ struct FilterWave {
         if (am == 0) return;
         const int A = (int)__popcll(am);
         if (active) L.alist[lane_rank(am)] = (uint8_t)lane;
-        int P = 0;
-#pragma unroll
-        for (int d = -fam.SLACK; d <= fam.SLACK; d++) {
-            const int c = maxlen - fam.GAP - d - fam.LB + 1;
-            if (c > 0) {
-                for (int t = lane; t < c; t += 64) L.ptab[P + t] = (uint16_t)(t | ((t + fam.GAP + d) << 8));
-                P += c;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+        const int P = build_ptab(fam, maxlen);
         if (P == 0) return;
         const uint32_t inv = 65536u / (uint32_t)A + 1u;
         int p = (int)(((uint32_t)lane * inv) >> 16);
@@ -755,8 +758,8 @@ struct FilterWave {
             uint32_t meta = 0;
             if (worker && p < P) {
                 const uint32_t tt = L.ptab[p];
-                const int t = (int)(tt & 0xFFu), t2 = (int)(tt >> 8);
-                if (sct_valid_of(fam, t2, slen)) {
+                const int t = (int)(tt & PFM), t2 = (int)((tt >> PF) & PFM);
+                if ((int)(tt >> (2 * PF)) <= slen) {
                     const uint32_t key = sct_key_of<W>(fam, slo, shi, t, t2);
 #pragma unroll
                     for (int q = 0; q < CAPW / 4; q++) {

@@ -234,10 +234,28 @@ SCT_HD uint32_t sct_key_of(const Fam &fam, W lo, W hi, int t, int t2) {
 }
 template <typename Fam>
 SCT_HD bool sct_valid_of(const Fam &fam, int t2, int len) { return t2 + fam.LB <= len; }
+// Which placements are worth a lookup.  Piece A at t and piece B at t2 = t + GAP + d pin the barcode in the text: the PA
+// characters before piece A must end at t, so at least (PA - t)+ of them are deleted; the stretch between the pieces absorbs
+// |d| edits; of the n2 = BL - PB - LB characters behind piece B at least (n2 - (len - t2 - LB))+ are deleted.  A placement
+// whose three lower bounds add up to more than E cannot verify within E edits (the anchored automaton computes the cost of an
+// alignment with exactly these anchors) and is skipped: for 22-character texts that is 32 of the 146 placements of the six
+// quarter families at E = 2, 6 of the 15 of H1.  sct_placement_need = the shortest text for which the placement can still verify.
+static constexpr int SCT_NEED_NEVER = 1 << 20;
+static constexpr int SCT_E_UNPRUNED = 99;   // "every placement whose pieces lie in the text" (tests of the automaton itself)
+template <typename Fam>
+SCT_HD int sct_placement_need(const Fam &fam, int E, int t, int t2) {
+    const int d = t2 - t - fam.GAP, ad = d < 0 ? -d : d;
+    const int left = fam.PA > t ? fam.PA - t : 0;
+    const int rb = E - ad - left;                 // edits left for the characters behind piece B
+    if (rb < 0) return SCT_NEED_NEVER;
+    const int n2 = fam.BL - fam.PB - fam.LB;
+    return t2 + fam.LB + (n2 > rb ? n2 - rb : 0);
+}
 template <typename Fam, typename Fn>
-SCT_HD void sct_for_each_placement_of(const Fam &fam, int len, Fn &&fn) {
+SCT_HD void sct_for_each_placement_of(const Fam &fam, int len, Fn &&fn, int E = SCT_E_UNPRUNED) {
     for (int d = -fam.SLACK; d <= fam.SLACK; d++)
-        for (int t = 0; t + fam.GAP + d + fam.LB <= len; t++) fn(t, t + fam.GAP + d);
+        for (int t = 0; t + fam.GAP + d + fam.LB <= len; t++)
+            if (sct_placement_need(fam, E, t, t + fam.GAP + d) <= len) fn(t, t + fam.GAP + d);
 }
 
 // key of the text (planes lo/hi, W = uint32_t up to 31 characters, uint64_t up to 63) for pieces at t and t2:
@@ -398,9 +416,8 @@ template <int F>
 SCT_HD bool sct_placement_valid(int t2, int len) { return t2 + SctFamily<F>::LB <= len; }
 
 template <int F, typename Fn>
-SCT_HD void sct_for_each_placement(int len, Fn &&fn) {
-    for (int d = -SctFamily<F>::SLACK; d <= SctFamily<F>::SLACK; d++)
-        for (int t = 0; t + SctFamily<F>::GAP + d + SctFamily<F>::LB <= len; t++) fn(t, t + SctFamily<F>::GAP + d);
+SCT_HD void sct_for_each_placement(int len, Fn &&fn, int E = SCT_E_UNPRUNED) {
+    sct_for_each_placement_of(SctFamily<F>{}, len, fn, E);
 }
 
 // Every (family, key) lookup for one text (planes lo/hi), family by family.
@@ -413,22 +430,22 @@ struct SctSeedExpand {
 // thirds scheme (max_err <= 1)
 template <int E, typename W, typename Fn>
 SCT_HD void sct_for_each_seed_thirds(W lo, W hi, int len, Fn &&fn) {
-    { SctSeedExpand<SCT_F_T01, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_T01>(len, x); }
+    { SctSeedExpand<SCT_F_T01, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_T01>(len, x, E); }
     if (E >= 1) {
-        { SctSeedExpand<SCT_F_T12, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_T12>(len, x); }
-        { SctSeedExpand<SCT_F_T02, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_T02>(len, x); }
+        { SctSeedExpand<SCT_F_T12, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_T12>(len, x, E); }
+        { SctSeedExpand<SCT_F_T02, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_T02>(len, x, E); }
     }
 }
 // quarters scheme (max_err <= 2)
 template <int E, typename W, typename Fn>
 SCT_HD void sct_for_each_seed(W lo, W hi, int len, Fn &&fn) {
-    { SctSeedExpand<SCT_F_H1, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H1>(len, x); }
-    if (E >= 1) { SctSeedExpand<SCT_F_H2, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H2>(len, x); }
+    { SctSeedExpand<SCT_F_H1, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H1>(len, x, E); }
+    if (E >= 1) { SctSeedExpand<SCT_F_H2, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_H2>(len, x, E); }
     if (E >= 2) {
-        { SctSeedExpand<SCT_F_MID, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_MID>(len, x); }
-        { SctSeedExpand<SCT_F_02, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_02>(len, x); }
-        { SctSeedExpand<SCT_F_13, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_13>(len, x); }
-        { SctSeedExpand<SCT_F_03, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_03>(len, x); }
+        { SctSeedExpand<SCT_F_MID, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_MID>(len, x, E); }
+        { SctSeedExpand<SCT_F_02, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_02>(len, x, E); }
+        { SctSeedExpand<SCT_F_13, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_13>(len, x, E); }
+        { SctSeedExpand<SCT_F_03, W, Fn> x{lo, hi, fn}; sct_for_each_placement<SCT_F_03>(len, x, E); }
     }
 }
 

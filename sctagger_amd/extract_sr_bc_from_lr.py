@@ -63,16 +63,16 @@ def select(counts, first_seen, max_barcode_cnt, step_size, thresh):
 
 def extract_sr_bc_from_lr(args, device=0):
     """args: input, barcode_whitelist, outfile, thresh, step_size, max_barcode_cnt (reference :67-79)."""
-    _log("Reading whiltelist barcodes from: %s" % args.barcode_whitelist)
+    _log("whitelist: %s" % args.barcode_whitelist)
     barcodes = read_whitelist(args.barcode_whitelist)
-    _log("Matching exact barcodes on long-reads: %s" % args.input)
+    _log("counting exact whitelist occurrences in the segments of %s" % args.input)
     na, segs, offs = read_rows(args.input)
     with _native.Matcher(device) as m:
         m.wl_set(barcodes)
         counts, first_seen = m.wl_count(segs, offs, na)
-    _log("Found {:,} unique barcodes on long-reads".format(int((counts > 0).sum())))
+    _log("{:,} whitelist entries occur in at least one segment".format(int((counts > 0).sum())))
     idx, c = select(counts, first_seen, args.max_barcode_cnt, args.step_size, args.thresh)
-    _log("Writing the top %d barcodes" % idx.size)
+    _log("keeping %d barcodes" % idx.size)
     text = "".join("%s\t%d\n" % (barcodes[b], n) for b, n in zip(idx.tolist(), c.tolist()))
     if args.outfile:
         with gzip.open(args.outfile, "wt") as f:      # the reference gzips whatever the name is (:839)

@@ -201,15 +201,27 @@ def _match_trie_streaming(args, devices, level):
     bc = _barcode_matrix(args.barcode_length)
     table = fastio.pattern_text_table(barcodes, barcodes_rc)
     want_plot = getattr(args, "plotfile", None) is not None
+    # The reference reads and checks the whole -lr file before it opens the output (:763-771): a bad input never leaves an output
+    # file behind.  Here blocks are written while later ones are still being read, so the rows go to a temporary file beside the
+    # target, which takes its name only when every block has been read, checked (gzip CRC and length included) and written.
+    tmp = "%s.tmp.%d" % (args.outfile, os.getpid())
     if args.outfile.endswith("gz"):
-        sink = fastio.GzipChunkWriter(args.outfile, level, threads=min(32, max(4, (os.cpu_count() or 8) // 2)))
+        sink = fastio.GzipChunkWriter(tmp, level, threads=min(32, max(4, (os.cpu_count() or 8) // 2)))
     else:
-        sink = open(args.outfile, "wb")
+        sink = open(tmp, "wb")
     try:
-        rows, min_es = streamcli.run_pipeline(args.long_read_segments, bc, args.barcode_length, args.max_error, args.threads, table, sink,
-                                              devices=tuple(devices), want_min_e=want_plot)
-    finally:
-        sink.close()
+        try:
+            rows, min_es = streamcli.run_pipeline(args.long_read_segments, bc, args.barcode_length, args.max_error, args.threads, table, sink,
+                                                  devices=tuple(devices), want_min_e=want_plot)
+        finally:
+            sink.close()
+        os.replace(tmp, args.outfile)
+    except BaseException:
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+        raise
     _log("There are {:,} LRs".format(rows))
     if want_plot:
         from . import plots

@@ -95,7 +95,7 @@ static int anchored_family(const std::vector<int> &p, const std::vector<int> &t)
     am.code = 0;
     for (int j = 0; j < 16; j++) am.code |= (uint32_t)p[j] << (2 * j);
     am.best = E + 1;
-    sct_for_each_placement<F>(L, am);
+    sct_for_each_placement<F>(L, am, E);   // pruned as the kernels prune: completeness is checked WITH the pruning
     return am.best;
 }
 template <int E, typename W = uint32_t>
@@ -200,7 +200,7 @@ static int anchored_rt(const std::vector<int> &p, const std::vector<int> &t) {
         sct_for_each_placement_of(fam, L, [&](int a, int b) {
             if (sct_key_of<uint32_t>(fam, (uint32_t)tlo, (uint32_t)thi, a, b) != pkey) return;
             best = std::min(best, wm_anchored_of<E, uint32_t>(fam, em, va, code, a, b));
-        });
+        }, E);
     }
     return best;
 }
@@ -335,7 +335,7 @@ static bool emulate_filter(const SctSeedTables &T, const std::vector<std::vector
                 for (uint32_t gk = off[key]; gk < off[key + 1]; gk++)
                     add(wm_anchored_of<E, uint32_t>(fam, em, va, T.code[gk], a, b), T.ent[gk]);
             }
-        });
+        }, E);
     }
     int want = E + 1;
     std::set<uint32_t> want_hits;

@@ -273,3 +273,34 @@ def test_streaming_command_small_blocks_devices_and_fallback(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", str(bad), "-sr", os.path.join(g, "g1.sr.tsv"),
                         "-o", str(tmp_path / "bad.out.tsv")], capture_output=True, env=env)
     assert r.returncode != 0 and b"IndexError" in r.stderr
+
+
+def test_bad_input_leaves_no_output_file(tmp_path):
+    """The reference reads and checks the whole -lr file before it opens the output (scTagger.py:763-771): an input that is bad
+    somewhere — a gzip stream whose CRC does not match, a short line in a late block — must not leave an output file behind,
+    although the pipelined command has written the earlier blocks by then."""
+    g = util.GOLDEN
+    env = dict(os.environ, SCT_STREAM_BLOCK_BYTES="4096")       # many blocks: the bad spot is reached after rows were written
+    with open(os.path.join(g, "g2.lr.tsv"), "rb") as f:
+        good = f.read()
+    gz = bytearray(gzip.compress(good, 6))
+    gz[-8] ^= 0x55                                              # the CRC-32 of the trailer
+    (tmp_path / "badcrc.tsv.gz").write_bytes(bytes(gz))
+    lines = good.split(b"\n")
+    lines[len(lines) * 3 // 4] = b"rX\t1\t2"                    # three columns, three quarters into the file
+    (tmp_path / "short.tsv").write_bytes(b"\n".join(lines))
+    (tmp_path / "short.tsv.gz").write_bytes(gzip.compress(b"\n".join(lines), 6))
+    (tmp_path / "trunc.tsv.gz").write_bytes(gzip.compress(good, 6)[:-200])
+    for src, err in (("badcrc.tsv.gz", b"CRC"), ("short.tsv", b"IndexError"), ("short.tsv.gz", b"IndexError"), ("trunc.tsv.gz", b"Error")):
+        for out in ("o.tsv", "o.tsv.gz"):
+            o = tmp_path / out
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", str(tmp_path / src), "-sr",
+                                os.path.join(g, "g2.sr.tsv"), "-mr", "2", "-t", "1", "-o", str(o)], capture_output=True, env=env)
+            assert r.returncode != 0 and err in r.stderr, (src, out, r.stderr[-500:])
+            assert not o.exists() and not [p for p in os.listdir(tmp_path) if ".tmp." in p], (src, out, os.listdir(tmp_path))
+    # and the good file still comes out right through the same many-block route
+    o = tmp_path / "ok.tsv.gz"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", os.path.join(g, "g2.lr.tsv"), "-sr",
+                           os.path.join(g, "g2.sr.tsv"), "-mr", "2", "-t", "1", "-o", str(o)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+    with open(os.path.join(g, "g2.e2.t1.expected.tsv"), "rb") as f:
+        assert gzip.open(o, "rb").read() == f.read()

@@ -16,6 +16,7 @@ import sys
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
+    quote_name = sys.argv[3] if len(sys.argv) > 3 else "k_filter_counters.json"   # cfg5: k_filter_counters_cfg5.json
     os.makedirs("profiles", exist_ok=True)
     stats = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
     if stats:
@@ -59,6 +60,7 @@ def main():
         d, c = out[dom[0]], out[dom[0]]["counters_avg_per_launch"]
         quote = {"source": "rocprofv3 --pmc passes of tools/profile.sh, tag %s (profiles/%s_pmc_summary.json)" % (tag, tag),
                  "kernel": dom[0], "workload": b["config"]["workload"], "segments_per_launch": b["config"]["segments_per_gpu"],
+                 "valu_busy_share": (4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8)) if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE") else None,
                  "hbm_read_bytes": d.get("hbm_read_bytes_raw"), "hbm_read_bytes_x2_gfx950": d.get("hbm_read_bytes_x2_gfx950"),
                  "note": "FETCH_SIZE as read: the kernel's loads are 4-, 8- and 16-byte-per-lane mixed (seed slots, offsets, the ASCII "
                          "stage); the guide's x2 rule is calibrated for pure 16-byte-per-lane streams and is given beside it",
@@ -69,7 +71,7 @@ def main():
                  "kernel_ms_at_profile": b.get("kernels_ms", {}).get("k_filter"),
                  "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
                  "lds_insts_per_launch": c.get("SQ_INSTS_LDS"), "vmem_rd_insts_per_launch": c.get("SQ_INSTS_VMEM_RD")}
-        with open("profiles/k_filter_counters.json", "w") as f:
+        with open(os.path.join("profiles", quote_name), "w") as f:
             json.dump(quote, f, indent=1)
     print(json.dumps({k: v for k, v in out.items() if "filter" in k}, indent=1))
 
