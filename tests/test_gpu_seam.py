@@ -291,7 +291,7 @@ def test_bad_input_leaves_no_output_file(tmp_path):
     (tmp_path / "short.tsv").write_bytes(b"\n".join(lines))
     (tmp_path / "short.tsv.gz").write_bytes(gzip.compress(b"\n".join(lines), 6))
     (tmp_path / "trunc.tsv.gz").write_bytes(gzip.compress(good, 6)[:-200])
-    for src, err in (("badcrc.tsv.gz", b"CRC"), ("short.tsv", b"IndexError"), ("short.tsv.gz", b"IndexError"), ("trunc.tsv.gz", b"Error")):
+    for src, err in (("badcrc.tsv.gz", b"CRC"), ("short.tsv", b"IndexError"), ("short.tsv.gz", b"IndexError"), ("trunc.tsv.gz", b"BadGzipFile")):
         for out in ("o.tsv", "o.tsv.gz"):
             o = tmp_path / out
             r = subprocess.run([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", str(tmp_path / src), "-sr",
