@@ -111,3 +111,30 @@ __device__ __forceinline__ bool sct_decode_rows_staged(const uint8_t *__restrict
     __builtin_amdgcn_wave_barrier();  // the stage is the filter's queue and hit lists from here on
     return true;
 }
+
+// The BLOCK's rows through LDS (main launch, four waves per block): the 256 rows of a block are one contiguous stretch
+// [lo, hi) of the byte buffer, and all 256 threads load it together, every 16-byte piece once.  Per-wave staging (above) makes
+// two neighbouring waves both ask for the line their stretches share; for HBM that is nothing, but page-locked HOST memory is
+// not cached on the device and every such line crosses the PCIe link twice: a plain streaming kernel reads the link at
+// 56 GB/s, per-wave stretches of 1.3 - 1.4 KB at arbitrary offsets at 50 (tools/link_shape_probe.hip,
+// profiles/r03_link_shape_probe.json), stretches of 5.6 KB at 56.  The caller synchronises the block before any lane reads
+// `stage` and again before anything else is written to that LDS.
+__device__ __forceinline__ void sct_block_stage_load(const uint8_t *__restrict__ segs, int64_t lo, int64_t hi, uint32_t *stage) {
+    const uint64_t a = (uint64_t)(uintptr_t)segs + (uint64_t)lo;
+    const uint64_t base = a & ~15ull;
+    const int n16 = (int)(((uint64_t)(uintptr_t)segs + (uint64_t)hi - base + 15) >> 4);
+    const __attribute__((address_space(1))) sct_u4 *src = (const __attribute__((address_space(1))) sct_u4 *)(uintptr_t)base;
+    for (int i = (int)threadIdx.x; i < n16; i += (int)blockDim.x) {
+        const sct_u4 v = __builtin_nontemporal_load(src + i);
+        *reinterpret_cast<sct_u4 *>(stage + 4 * i) = v;
+    }
+}
+// ... and a lane's row out of that stage (start = the row's byte offset in the buffer, lo = the block stretch's)
+template <typename W>
+__device__ __forceinline__ void sct_decode_row_from_block_stage(const uint8_t *__restrict__ segs, int64_t lo, int64_t start, int len, const uint32_t *stage,
+                                                                W &plo, W &phi, bool &nonacgt) {
+    const uint64_t base = ((uint64_t)(uintptr_t)segs + (uint64_t)lo) & ~15ull;
+    const uint32_t so = len > 0 ? (uint32_t)((uint64_t)(uintptr_t)segs + (uint64_t)start - base) : 0u;
+    const uint32_t *wp = stage + (so >> 2);
+    sct_decode_words<W>([&](int k) { return wp[k]; }, (int)(so & 3u), len, plo, phi, nonacgt);
+}

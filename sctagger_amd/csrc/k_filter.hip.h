@@ -1016,9 +1016,12 @@ struct FilterArgs {
 // One wave's RPW rows, starting at row (or list position) `first`.
 // SCHEME: 0 = the six quarter families, 1 = thirds (max_err <= 1), 2 = wide (max_err = 2); sct_core.h
 static constexpr int SCHEME_QUARTERS = 0, SCHEME_THIRDS = 1, SCHEME_WIDE = 2;
-template <int E, typename W, int SCHEME, int KS, int HM, int RPW, bool RT, bool SL, typename OffT>
+// COOP (main launch of the 32-bit instantiation, four waves per block): the block stages its 256 rows' bytes together
+// (sct_block_stage_load) in `block_lds`, the LDS of all four waves, which nothing else uses yet; `block_flags` = four bytes of LDS.
+// Every wave of the block must make the call, whether or not it has rows (the function synchronises the block).
+template <int E, typename W, int SCHEME, int KS, int HM, int RPW, bool RT, bool SL, typename OffT, bool COOP = false>
 __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE> &L, int64_t first,
-                                            int64_t n) {
+                                            int64_t n, uint32_t *block_lds = nullptr, int block_lds_bytes = 0, uint8_t *block_flags = nullptr) {
     const int bl = RT ? a.bl : 16;
     const int lane = threadIdx.x & 63;
     const int64_t gid = first + lane;
@@ -1035,11 +1038,38 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     const int maxlen = wave_max_i(len);
     // W = uint32_t handles the waves whose longest such row has at most 31 characters (waves without any included:
     // their rows still have to be routed), W = uint64_t the others; a wave leaves at once if it is not its kind
-    if ((maxlen <= 31) != (sizeof(W) == 4)) return;
-    if (__ballot(inrange) == 0) return;
+    const bool mykind = (maxlen <= 31) == (sizeof(W) == 4);
+    const bool anyrow = __ballot(inrange) != 0;
     W lo, hi;
     bool nonacgt;
-    {
+    bool decoded = false;
+    if constexpr (COOP) {
+        static_assert(RPW == 64, "the cooperative stage belongs to the main launch");
+        const int widx = (int)(threadIdx.x >> 6);
+        if (lane == 0) block_flags[widx] = !anyrow ? 2 : (mykind ? 1 : 0);
+        __syncthreads();
+        const uint32_t f4 = *reinterpret_cast<const uint32_t *>(block_flags);
+        // every wave of the block is of this kind (or has no rows): one load of the block's stretch instead of four overlapping ones
+        if ((f4 & 0xFFu) != 0u && (f4 & 0xFF00u) != 0u && (f4 & 0xFF0000u) != 0u && (f4 & 0xFF000000u) != 0u) {
+            const int64_t bf = first - 64 * widx;
+            const int64_t be = bf + 256 < n ? bf + 256 : n;
+            int64_t A = (int64_t)a.offs[bf], B = (int64_t)a.offs[be];
+            A = A < 0 ? 0 : (A > a.seg_bytes ? a.seg_bytes : A);
+            B = B < A ? A : (B > a.seg_bytes ? a.seg_bytes : B);
+            if (B > A && B - A + 32 <= (int64_t)block_lds_bytes) {   // block-uniform
+                sct_block_stage_load(a.segs, A, B, block_lds);
+                __syncthreads();
+                // (a row outside the block's stretch means an inconsistent index: the call fails on CTR_BAD_ROW; it must not read past the stage)
+                const int dl = (start >= A && start + len <= B) ? len : 0;
+                sct_decode_row_from_block_stage<W>(a.segs, A, start, dl, block_lds, lo, hi, nonacgt);
+                __syncthreads();   // the stage is every wave's working LDS from here on
+                decoded = true;
+            }
+        }
+    }
+    if (!mykind) return;
+    if (!anyrow) return;
+    if (!decoded) {
         using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE>;
         static_assert(__builtin_offsetof(Lds, qk) == __builtin_offsetof(Lds, hlist) + 4 * 64 * HM &&
                           __builtin_offsetof(Lds, qm) == __builtin_offsetof(Lds, qk) + 4 * Lds::QCAP && __builtin_offsetof(Lds, hlist) % 16 == 0,
@@ -1359,13 +1389,17 @@ template <int E, typename W, int SCHEME, int KS, int HM, int RPW, bool RT, bool 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RPW < 64 && !SL && sizeof(W) == 4) ? 4 : 1)))
 k_filter(const FilterArgs<OffT> a) {
     constexpr int WPB = FilterWavesPerBlock<W, RPW>::value;
-    __shared__ FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE> lds[WPB];
+    using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE>;
+    __shared__ Lds lds[WPB];
     const int64_t n = a.n_dev ? (int64_t)*a.n_dev : a.n;
     const int64_t first = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * RPW;
     if constexpr (WPB == 4) {
         // the main launch's 32-bit instantiation — where the time goes — is launched over all rows and stays loop-free:
-        // wrapped in the loop below the compiler hoists enough address arithmetic out of it to cost two waves per SIMD
-        if (first < n) filter_rows<E, W, SCHEME, KS, HM, RPW, RT, SL, OffT>(a, lds[threadIdx.x >> 6], first, n);
+        // wrapped in the loop below the compiler hoists enough address arithmetic out of it to cost two waves per SIMD.
+        // Its four waves stage the block's rows together (COOP): every wave makes the call, rows or not.
+        __shared__ uint32_t block_flags;
+        filter_rows<E, W, SCHEME, KS, HM, RPW, RT, SL, OffT, true>(a, lds[threadIdx.x >> 6], first, n, reinterpret_cast<uint32_t *>(&lds[0]),
+                                                                   (int)sizeof(lds), reinterpret_cast<uint8_t *>(&block_flags));
     } else {
         const int64_t step = (int64_t)gridDim.x * WPB * RPW;
         for (int64_t f = first; f < n; f += step) {

@@ -50,10 +50,15 @@ static constexpr int CHAINS = 8, UNROLL = 8;
                  : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) \
                  : "v"(a))
 
-enum Op { AND_OR, LSHLREV, PK_LSHLREV16, PK_ADD_U16, XOR, ADD_U32, BFE, LSHL_OR, OR3, MUL_LO, FMA_F32, PK_FMA_F32, AND, XAD, PERM, N_OPS };
+enum Op { AND_OR, LSHLREV, PK_LSHLREV16, PK_ADD_U16, XOR, ADD_U32, BFE, LSHL_OR, OR3, MUL_LO, FMA_F32, PK_FMA_F32, AND, XAD, PERM,
+          // round 3: the rest of what the filter kernel is made of (static histogram of its disassembly, tools/valu_mix.py)
+          LSHRREV, OR, SUB_U32, MOV, CNDMASK, CMP_GT_U32, BITOP3, LSHL_ADD_U32, ADD3, MAD_I24, MIN_U32, MBCNT_LO, PK_LSHRREV16, LSHRREV_SDWA, N_OPS };
 static const char *OP_NAMES[N_OPS] = {"v_and_or_b32", "v_lshlrev_b32", "v_pk_lshlrev_b16", "v_pk_add_u16", "v_xor_b32", "v_add_u32",
                                       "v_bfe_u32", "v_lshl_or_b32", "v_or3_b32", "v_mul_lo_u32", "v_fma_f32", "v_pk_fma_f32",
-                                      "v_and_b32", "v_xad_u32", "v_perm_b32"};
+                                      "v_and_b32", "v_xad_u32", "v_perm_b32",
+                                      "v_lshrrev_b32", "v_or_b32", "v_sub_u32", "v_mov_b32", "v_cndmask_b32", "v_cmp_gt_u32", "v_bitop3_b32",
+                                      "v_lshl_add_u32", "v_add3_u32", "v_mad_i32_i24", "v_min_u32", "v_mbcnt_lo_u32_b32", "v_pk_lshrrev_b16",
+                                      "v_lshrrev_b32_sdwa"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_issue(int loops, uint32_t seed, unsigned long long *__restrict__ cycles, uint32_t *__restrict__ sink) {
@@ -83,6 +88,31 @@ __global__ void __launch_bounds__(256) k_issue(int loops, uint32_t seed, unsigne
             else if constexpr (OP == AND) OP2("v_and_b32");
             else if constexpr (OP == XAD) OP3("v_xad_u32");
             else if constexpr (OP == PERM) OP3("v_perm_b32");
+            else if constexpr (OP == LSHRREV) OP2("v_lshrrev_b32");
+            else if constexpr (OP == OR) OP2("v_or_b32");
+            else if constexpr (OP == SUB_U32) OP2("v_sub_u32");
+            else if constexpr (OP == MIN_U32) OP2("v_min_u32");
+            else if constexpr (OP == MBCNT_LO) OP2("v_mbcnt_lo_u32_b32");
+            else if constexpr (OP == PK_LSHRREV16) OP2("v_pk_lshrrev_b16");
+            else if constexpr (OP == LSHL_ADD_U32) OP3("v_lshl_add_u32");
+            else if constexpr (OP == ADD3) OP3("v_add3_u32");
+            else if constexpr (OP == MAD_I24) OP3("v_mad_i32_i24");
+            else if constexpr (OP == MOV) {
+#define ROUNDM "v_mov_b32 %0, %8\n\t v_mov_b32 %1, %8\n\t v_mov_b32 %2, %8\n\t v_mov_b32 %3, %8\n\t v_mov_b32 %4, %8\n\t v_mov_b32 %5, %8\n\t v_mov_b32 %6, %8\n\t v_mov_b32 %7, %8\n\t"
+                asm volatile(X8(ROUNDM) : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(a));
+            } else if constexpr (OP == CNDMASK) {
+#define ROUNDC "v_cndmask_b32 %0, %0, %8, vcc\n\t v_cndmask_b32 %1, %1, %8, vcc\n\t v_cndmask_b32 %2, %2, %8, vcc\n\t v_cndmask_b32 %3, %3, %8, vcc\n\t v_cndmask_b32 %4, %4, %8, vcc\n\t v_cndmask_b32 %5, %5, %8, vcc\n\t v_cndmask_b32 %6, %6, %8, vcc\n\t v_cndmask_b32 %7, %7, %8, vcc\n\t"
+                asm volatile(X8(ROUNDC) : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(a) : "vcc");
+            } else if constexpr (OP == CMP_GT_U32) {
+#define ROUNDP "v_cmp_gt_u32 vcc, %8, %0\n\t v_cmp_gt_u32 vcc, %8, %1\n\t v_cmp_gt_u32 vcc, %8, %2\n\t v_cmp_gt_u32 vcc, %8, %3\n\t v_cmp_gt_u32 vcc, %8, %4\n\t v_cmp_gt_u32 vcc, %8, %5\n\t v_cmp_gt_u32 vcc, %8, %6\n\t v_cmp_gt_u32 vcc, %8, %7\n\t"
+                asm volatile(X8(ROUNDP) : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(a) : "vcc");
+            } else if constexpr (OP == BITOP3) {
+#define ROUNDB "v_bitop3_b32 %0, %0, %8, %9 bitop3:0x96\n\t v_bitop3_b32 %1, %1, %8, %9 bitop3:0x96\n\t v_bitop3_b32 %2, %2, %8, %9 bitop3:0x96\n\t v_bitop3_b32 %3, %3, %8, %9 bitop3:0x96\n\t v_bitop3_b32 %4, %4, %8, %9 bitop3:0x96\n\t v_bitop3_b32 %5, %5, %8, %9 bitop3:0x96\n\t v_bitop3_b32 %6, %6, %8, %9 bitop3:0x96\n\t v_bitop3_b32 %7, %7, %8, %9 bitop3:0x96\n\t"
+                asm volatile(X8(ROUNDB) : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(a), "v"(b));
+            } else if constexpr (OP == LSHRREV_SDWA) {
+#define ROUNDS "v_lshrrev_b32_sdwa %0, %8, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t v_lshrrev_b32_sdwa %1, %8, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t v_lshrrev_b32_sdwa %2, %8, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t v_lshrrev_b32_sdwa %3, %8, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t v_lshrrev_b32_sdwa %4, %8, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t v_lshrrev_b32_sdwa %5, %8, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t v_lshrrev_b32_sdwa %6, %8, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t v_lshrrev_b32_sdwa %7, %8, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                asm volatile(X8(ROUNDS) : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(a));
+            }
             else if constexpr (OP == PK_FMA_F32) {
                 asm volatile(X8(ROUND3("v_pk_fma_f32"))
                              : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7])
@@ -102,7 +132,10 @@ typedef void (*KernelFn)(int, uint32_t, unsigned long long *, uint32_t *);
 template <int OP>
 static KernelFn kernel_of() { return k_issue<OP>; }
 static KernelFn KERNELS[N_OPS] = {kernel_of<0>(), kernel_of<1>(), kernel_of<2>(), kernel_of<3>(), kernel_of<4>(), kernel_of<5>(), kernel_of<6>(),
-                                  kernel_of<7>(), kernel_of<8>(), kernel_of<9>(), kernel_of<10>(), kernel_of<11>(), kernel_of<12>(), kernel_of<13>(), kernel_of<14>()};
+                                  kernel_of<7>(), kernel_of<8>(), kernel_of<9>(), kernel_of<10>(), kernel_of<11>(), kernel_of<12>(), kernel_of<13>(), kernel_of<14>(),
+                                  kernel_of<15>(), kernel_of<16>(), kernel_of<17>(), kernel_of<18>(), kernel_of<19>(), kernel_of<20>(), kernel_of<21>(),
+                                  kernel_of<22>(), kernel_of<23>(), kernel_of<24>(), kernel_of<25>(), kernel_of<26>(), kernel_of<27>(), kernel_of<28>()};
+static_assert(N_OPS == 29, "KERNELS lists every op");
 
 int main(int argc, char **argv) {
     const int loops = argc > 1 ? atoi(argv[1]) : 20000;
