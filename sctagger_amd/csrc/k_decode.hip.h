@@ -120,9 +120,12 @@ __device__ __forceinline__ bool sct_decode_rows_staged(const uint8_t *__restrict
 // profiles/r03_link_shape_probe.json), stretches of 5.6 KB at 56.  The caller synchronises the block before any lane reads
 // `stage` and again before anything else is written to that LDS.
 __device__ __forceinline__ void sct_block_stage_load(const uint8_t *__restrict__ segs, int64_t lo, int64_t hi, uint32_t *stage) {
+    // whole 128-byte lines from the line that holds the first byte: a pass of the loop below (256 threads x 16 bytes = 32 lines)
+    // then ends on a line boundary, and no line is asked for by two instructions.  (A line never leaves its page: reading the
+    // bytes of the first and last line that lie outside [lo, hi) is safe, and they belong to the neighbouring blocks' rows anyway.)
     const uint64_t a = (uint64_t)(uintptr_t)segs + (uint64_t)lo;
-    const uint64_t base = a & ~15ull;
-    const int n16 = (int)(((uint64_t)(uintptr_t)segs + (uint64_t)hi - base + 15) >> 4);
+    const uint64_t base = a & ~127ull;
+    const int n16 = (int)(((((uint64_t)(uintptr_t)segs + (uint64_t)hi - base + 127) >> 7)) << 3);
     const __attribute__((address_space(1))) sct_u4 *src = (const __attribute__((address_space(1))) sct_u4 *)(uintptr_t)base;
     for (int i = (int)threadIdx.x; i < n16; i += (int)blockDim.x) {
         const sct_u4 v = __builtin_nontemporal_load(src + i);
@@ -133,7 +136,7 @@ __device__ __forceinline__ void sct_block_stage_load(const uint8_t *__restrict__
 template <typename W>
 __device__ __forceinline__ void sct_decode_row_from_block_stage(const uint8_t *__restrict__ segs, int64_t lo, int64_t start, int len, const uint32_t *stage,
                                                                 W &plo, W &phi, bool &nonacgt) {
-    const uint64_t base = ((uint64_t)(uintptr_t)segs + (uint64_t)lo) & ~15ull;
+    const uint64_t base = ((uint64_t)(uintptr_t)segs + (uint64_t)lo) & ~127ull;
     const uint32_t so = len > 0 ? (uint32_t)((uint64_t)(uintptr_t)segs + (uint64_t)start - base) : 0u;
     const uint32_t *wp = stage + (so >> 2);
     sct_decode_words<W>([&](int k) { return wp[k]; }, (int)(so & 3u), len, plo, phi, nonacgt);

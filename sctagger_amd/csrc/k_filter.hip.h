@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
             int64_t A = (int64_t)a.offs[bf], B = (int64_t)a.offs[be];
             A = A < 0 ? 0 : (A > a.seg_bytes ? a.seg_bytes : A);
             B = B < A ? A : (B > a.seg_bytes ? a.seg_bytes : B);
-            if (B > A && B - A + 32 <= (int64_t)block_lds_bytes) {   // block-uniform
+            if (B > A && B - A + 256 <= (int64_t)block_lds_bytes) {   // block-uniform (whole lines: up to 127 bytes more at either end)
                 sct_block_stage_load(a.segs, A, B, block_lds);
                 __syncthreads();
                 // (a row outside the block's stretch means an inconsistent index: the call fails on CTR_BAD_ROW; it must not read past the stage)

@@ -559,6 +559,17 @@ SCT_HD uint32_t sct_pk_shl1(uint32_t x) { return (x << 1) & 0xFFFEFFFEu; }
 SCT_HD uint32_t sct_pk_shr(uint32_t x, uint32_t sh) { return ((x & 0xFFFFu) >> (sh & 0xFFFFu)) | (((x >> 16) >> (sh >> 16)) << 16); }
 #endif
 SCT_HD uint32_t sct_pk(uint32_t lo, uint32_t hi) { return (lo & 0xFFFFu) | (hi << 16); }
+// (a & b) | c and a | b | c.  On gfx950 the compiler selects v_and_or_b32 / v_or3_b32 for these, which issue at half rate
+// (4.2 cycles per wave64 instruction per SIMD); v_bitop3_b32 computes any three-input boolean function at FULL rate (2.3 cycles;
+// tools/valu_peak.hip, profiles/r03_valu_issue_rates.md).  Truth table: bit (a << 2 | b << 1 | c) of the immediate, i.e. the
+// function applied to a = 0xF0, b = 0xCC, c = 0xAA.
+#if defined(__HIP_DEVICE_COMPILE__)
+SCT_HD uint32_t sct_and_or(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, (0xF0 & 0xCC) | 0xAA); }
+SCT_HD uint32_t sct_or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xF0 | 0xCC | 0xAA); }
+#else
+SCT_HD uint32_t sct_and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
+SCT_HD uint32_t sct_or3(uint32_t a, uint32_t b, uint32_t c) { return a | b | c; }
+#endif
 
 template <int E>
 struct WmPair {
@@ -568,10 +579,10 @@ struct WmPair {
         const uint32_t n0 = s0 & Em;
         if (E >= 1) {
             const uint32_t s1 = sct_pk_shl1(R1);
-            const uint32_t n1 = (s1 & Em) | s0 | R0 | sct_pk_shl1(n0);
+            const uint32_t n1 = sct_or3(sct_and_or(s1, Em, s0), R0, sct_pk_shl1(n0));
             if (E >= 2) {
                 const uint32_t s2 = sct_pk_shl1(R2);
-                R2 = (s2 & Em) | s1 | R1 | sct_pk_shl1(n1);
+                R2 = sct_or3(sct_and_or(s2, Em, s1), R1, sct_pk_shl1(n1));
             }
             R1 = n1;
         }
@@ -582,8 +593,8 @@ struct WmPair {
     SCT_HDM void anchor(uint32_t at) {
         const uint32_t one = 0x00010001u;
         R0 = sct_pk_shr(R0, at) & one;
-        if (E >= 1) R1 = (sct_pk_shr(R1, at) & one) | (R0 << 1);
-        if (E >= 2) R2 = (sct_pk_shr(R2, at) & one) | (R1 << 1);
+        if (E >= 1) R1 = sct_and_or(sct_pk_shr(R1, at), one, R0 << 1);
+        if (E >= 2) R2 = sct_and_or(sct_pk_shr(R2, at), one, R1 << 1);
     }
     SCT_HDM uint32_t result(uint32_t m) const {  // d of X | d of Y << 16
         const uint32_t a0 = R0 & m, a1 = E >= 1 ? (R1 & m) : 0u, a2 = E >= 2 ? (R2 & m) : 0u;

@@ -5,12 +5,14 @@ everything around it seconds, most of it in one place: inflating the input (a gz
 So the command is organised around that one serial stage and hides the rest behind it:
 
     reader thread     gunzip / read the file in blocks of ~32 MB that end at a line end
-    worker thread(s)  one per device: parse the block's columns 0 and 3 straight into page-locked buffers (C helper),
-                      sct_match_stream on them in place (uint8 lengths in, uint8 counts + hit lists out),
-                      render the block's output rows (C helper)
+    CPU workers       several, whatever the number of devices (cpu_workers_for): parse the block's columns 0 and 3 (C helper),
+                      sct_match_stream on the arrays in place on the worker's device (uint8 lengths in, uint8 counts + hit lists
+                      out; the device's context is shared under a lock: a call takes half a millisecond), render the block's
+                      output rows (C helper)
+    device threads    one per device: create the context and load the barcodes while the first blocks are read and parsed
     main thread       hands the rendered rows, in block order, to a pool that gzips them as consecutive gzip members
 
-Blocks are dealt round-robin to the devices (`--devices`), so several GPUs need no sharding step.  The bytes written are
+The workers are bound round-robin to the devices (`--devices`), so several GPUs need no sharding step.  The bytes written are
 exactly the reference's (after decompression).  Input the C parser cannot represent exactly — bytes >= 128, '\\r' —
 raises NeedPlainReader and the caller falls back to the reference's own text-mode procedure on the whole file.
 """
@@ -191,43 +193,80 @@ def iter_blocks(path, block_bytes=BLOCK_BYTES):
         yield buf, True
 
 
-class _Worker(threading.Thread):
-    """One device: parse -> match -> render, block after block."""
+class _Device(threading.Thread):
+    """One context on one device, created on a thread of its own while the first blocks are being read and parsed (creating it
+    costs 0.2 s), then shared by the CPU workers bound to it: a context serves one host thread at a time (`lock`)."""
 
-    def __init__(self, device, bc, bl, max_err, threads, table, want_min_e):
+    def __init__(self, device, bc, bl):
         super().__init__(daemon=True)
-        self.device, self.bc, self.bl, self.max_err, self.threads = device, bc, bl, max_err, threads
+        self.device, self.bc, self.bl = device, bc, bl
+        self.ready = threading.Event()
+        self.lock = threading.Lock()
+        self.m = None
+        self.error = None
+
+    def run(self):
+        try:
+            self.m = _native.Matcher(self.device)
+            self.m.set_barcodes(self.bc, self.bl)
+        except BaseException as e:
+            self.error = e
+        finally:
+            self.ready.set()
+
+    def matcher(self):
+        self.ready.wait()
+        if self.error is not None:
+            raise self.error
+        return self.m
+
+    def close(self):
+        self.ready.wait()
+        if self.m is not None:
+            with self.lock:
+                self.m.close()
+            self.m = None
+
+
+class _Worker(threading.Thread):
+    """One CPU worker: parse -> match (on its device, under the device's lock) -> render, block after block.  The reference's
+    reader (scTagger.py:602-628) and writer loop (:777-789) are serial Python; here as many workers as the host has cores to
+    spare parse and render side by side, whatever the number of devices."""
+
+    def __init__(self, dev, inq, max_err, threads, table, want_min_e):
+        super().__init__(daemon=True)
+        self.dev, self.inq, self.max_err, self.threads = dev, inq, max_err, threads
         self.table, self.want_min_e = table, want_min_e
-        self.inq = queue.Queue(maxsize=2)
         self.outq = None          # set by run_pipeline
         self.error = None
         self.rows = 0
         self.cap_rows = self.cap_bytes = 0
 
-    def _ensure(self, m, nbytes):
+    def _ensure(self, nbytes):
         if nbytes <= self.cap_bytes:
             return
-        m.sync()
-        m.release_host_arrays()
+        # ordinary (pageable) arrays, so that parsing does not have to wait for the device context; the library page-locks them
+        # for the duration of each call (option "register") and its kernels read and write them in place
         self.cap_bytes = max(nbytes, BLOCK_BYTES + (1 << 20))
         self.cap_rows = ROWS_PER_PASS
-        self.segs = m.host_array(self.cap_bytes, np.uint8)
-        self.offs = m.host_array(self.cap_rows + 1, np.int32)
-        self.lens = m.host_array(self.cap_rows, np.uint8)
-        self.min_e = m.host_array(self.cap_rows, np.uint8)
-        self.cnt = m.host_array(self.cap_rows, np.uint32)     # viewed as uint8 for the one-byte counts
+        self.segs = np.empty(self.cap_bytes, np.uint8)
+        self.offs = np.empty(self.cap_rows + 1, np.int32)
+        self.lens = np.empty(self.cap_rows, np.uint8)
+        self.min_e = np.empty(self.cap_rows, np.uint8)
+        self.cnt = np.empty(self.cap_rows, np.uint32)     # viewed as uint8 for the one-byte counts
         self.ns = np.empty(self.cap_rows, dtype=np.int64)
         self.ne = np.empty(self.cap_rows, dtype=np.int64)
         self.info = np.zeros(8, dtype=np.int64)
 
-    def _block(self, m, lib, buf, final):
+    def _block(self, lib, buf, final):
         """-> (list of rendered byte strings, list of min_e copies, rows)"""
-        self._ensure(m, len(buf))
+        self._ensure(len(buf))
         base = ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p).value
         at, n_rows, out, keep = 0, 0, [], []
         cnt8 = self.cnt.view(np.uint8)
+        n_bc = self.dev.bc.shape[0]
         # 16-bit hits while the pattern ids fit (2 per barcode): half the bytes back over the link
-        hfmt, hbytes = (_native.HITS_U16, 2) if 2 * self.bc.shape[0] <= 65536 else (_native.HITS_U32, 4)
+        hfmt, hbytes = (_native.HITS_U16, 2) if 2 * n_bc <= 65536 else (_native.HITS_U32, 4)
         while at < len(buf):
             lib.sctio_parse_block(base + at, len(buf) - at, 1 if final else 0, self.cap_rows, self.cap_bytes, self.ns.ctypes.data,
                                   self.ne.ctypes.data, self.segs.ctypes.data, self.offs.ctypes.data, self.lens.ctypes.data,
@@ -244,16 +283,18 @@ class _Worker(threading.Thread):
                 index, ifmt = self.lens[:n], _native.IDX_LEN8
             else:
                 index, ifmt = self.offs[:n + 1], _native.IDX_OFFS32
-            try:
-                me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
-                                               count_format=_native.CNT_U8, min_e=self.min_e, counts=cnt8, copy_hits=False, hits_format=hfmt)
-                cbytes = 1
-            except _native.SctError as e:
-                if e.code != _native.E_RANGE:
-                    raise
-                me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
-                                               count_format=_native.CNT_U32, min_e=self.min_e, counts=self.cnt, copy_hits=False, hits_format=hfmt)
-                cbytes = 4
+            m = self.dev.matcher()
+            with self.dev.lock:       # the hit lists come back in the context's own buffer: copied before the next worker's call
+                try:
+                    me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
+                                                   count_format=_native.CNT_U8, min_e=self.min_e, counts=cnt8, copy_hits=True, hits_format=hfmt)
+                    cbytes = 1
+                except _native.SctError as e:
+                    if e.code != _native.E_RANGE:
+                        raise
+                    me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
+                                                   count_format=_native.CNT_U32, min_e=self.min_e, counts=self.cnt, copy_hits=True, hits_format=hfmt)
+                    cbytes = 4
             hp = hits.ctypes.data if hits.size else None
             args = [base + at, self.ns.ctypes.data, self.ne.ctypes.data, self.segs.ctypes.data, self.offs.ctypes.data, me.ctypes.data,
                     cnt.ctypes.data, cbytes, hp, hbytes, self.table.ctypes.data, self.table.shape[1] if self.table.ndim == 2 else 0, n]
@@ -271,27 +312,41 @@ class _Worker(threading.Thread):
     def run(self):
         try:
             lib = _iolib()
-            with _native.Matcher(self.device) as m:
-                m.set_barcodes(self.bc, self.bl)
-                while True:
-                    item = self.inq.get()
-                    if item is None:
-                        break
-                    idx, buf, final = item
-                    out, keep, n = self._block(m, lib, buf, final)
-                    self.rows += n
-                    self.outq.put((idx, out, keep))
-                m.sync()
-                m.release_host_arrays()
+            while True:
+                item = self.inq.get()
+                if item is None:
+                    break
+                idx, buf, final = item
+                out, keep, n = self._block(lib, buf, final)
+                self.rows += n
+                self.outq.put((idx, out, keep))
         except BaseException as e:          # handed to the main thread
             self.error = e
             self.outq.put((-1, None, None))
 
 
-def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), want_min_e=False, block_bytes=BLOCK_BYTES):
+def cpu_workers_for(n_devices):
+    """CPU workers of the command: SCT_CLI_WORKERS, or by the host's cores — at least one per device, at most 8 (parse + render
+    of 10^7 rows is 0.6 s of one core; the gzip pool of the writer wants the other cores)."""
+    env = os.environ.get("SCT_CLI_WORKERS")
+    if env:
+        return max(n_devices, int(env))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    return max(n_devices, min(8, max(1, cores // 4)))
+
+
+def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), want_min_e=False, block_bytes=BLOCK_BYTES, cpu_workers=None):
     """Stream `lr_path` through the devices into `sink` (an object with write(bytes-like)); -> (rows read, list of min_e
     arrays in row order if want_min_e).  Raises NeedPlainReader / IndexError like the whole-file readers."""
-    workers = [_Worker(d, bc, bl, max_err, threads, table, want_min_e) for d in devices]
+    devs = [_Device(d, bc, bl) for d in devices]
+    for d in devs:
+        d.start()
+    n_workers = cpu_workers or cpu_workers_for(len(devs))
+    inq = queue.Queue(maxsize=2 * n_workers)
+    workers = [_Worker(devs[i % len(devs)], inq, max_err, threads, table, want_min_e) for i in range(n_workers)]
     outq = queue.Queue()
     for w in workers:
         w.outq = outq
@@ -304,7 +359,12 @@ def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), w
             for i, (buf, final) in enumerate(iter_blocks(lr_path, block_bytes)):
                 if stop.is_set():
                     break
-                workers[i % len(workers)].inq.put((i, buf, final))
+                while not stop.is_set():
+                    try:
+                        inq.put((i, buf, final), timeout=0.05)
+                        break
+                    except queue.Full:
+                        pass
                 state["blocks"] = i + 1
         except BaseException as e:
             state["error"] = e
@@ -338,29 +398,22 @@ def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), w
                     sink.write(mv[a:a + PIECE_BYTES])
             min_es.extend(keep)
             nxt += 1
-    # wind down: on failure the reader may be blocked on a full queue of a worker that is gone — empty the queues until it
-    # has left, then tell the workers that are still there to stop
+    # wind down: the reader gives up by itself once `stop` is set; blocks still queued are dropped, every worker gets its sentinel
     stop.set()
-    while reader.is_alive():
-        if failure is not None:
-            for w in workers:
-                try:
-                    w.inq.get_nowait()
-                except queue.Empty:
-                    pass
-        reader.join(timeout=0.02)
-    for w in workers:
-        while w.is_alive():
-            try:
-                w.inq.put(None, timeout=0.02)
-                break
-            except queue.Full:
-                try:
-                    w.inq.get_nowait()
-                except queue.Empty:
-                    pass
+    reader.join()
+    while True:
+        try:
+            inq.get_nowait()
+        except queue.Empty:
+            break
+    for _ in workers:
+        inq.put(None)
     for w in workers:
         w.join()
+    for d in devs:
+        d.close()
     if failure is not None:
         raise failure
+    if any(w.error is not None for w in workers):      # an error that arrived after the loop had what it needed
+        raise next(w.error for w in workers if w.error is not None)
     return sum(w.rows for w in workers), min_es

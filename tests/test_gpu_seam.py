@@ -252,11 +252,13 @@ def test_streaming_command_small_blocks_devices_and_fallback(tmp_path):
         lrgz = tmp_path / (name + ".lr.tsv.gz")
         with open(os.path.join(g, name + ".lr.tsv"), "rb") as f, gzip.open(lrgz, "wb") as z:
             z.write(f.read())
-        for extra in (["--devices", "0", "0", "0"], [], ["--no-stream"]):
+        # CPU workers are independent of the devices: seven of them on one context, five spread over three, one, the default
+        for extra, workers in ((["--devices", "0", "0", "0"], "5"), ([], "7"), ([], "1"), ([], None), (["--no-stream"], None)):
             o = tmp_path / (name + ".out.tsv.gz")
+            wenv = dict(env, SCT_CLI_WORKERS=workers) if workers else env
             subprocess.check_call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", str(lrgz), "-sr", sr, "-mr", str(e),
-                                   "-t", str(t), "-o", str(o)] + extra, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
-            assert gzip.open(o, "rb").read() == want, (name, extra)
+                                   "-t", str(t), "-o", str(o)] + extra, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=wenv)
+            assert gzip.open(o, "rb").read() == want, (name, extra, workers)
     # CRLF input: Python's text mode turns \r\n into \n; the block parser declines and the whole-file reader takes over
     with open(os.path.join(g, "g1.lr.tsv"), "rb") as f:
         crlf = f.read().replace(b"\n", b"\r\n")
