@@ -55,6 +55,7 @@ PCIE_PEAK_GBS = 63.0   # MI355X_MICROARCH.md: PCIe Gen5 x16 (spec); 57 GB/s meas
 # SIMD whatever the occupancy (5.9e11 wave-instructions/s for the chip); plain and / xor / add issue every ~2.2 cycles.
 VALU_PEAK_WINST_S = 5.9e11
 VALU_PEAK_FULL_RATE_WINST_S = 1.1e12
+RANDOM_LINE_PEAK = 5.5e10   # tools/gather_probe.hip -> profiles/r03_gather_probe.jsonl
 L2_PEAK_REQ_S = 8 * 16 * 2.4e9   # L2: 16 channels per XCD, one 128-byte request per channel and clock (MI355X_MICROARCH.md: 34.5 TB/s)
 IDX = {"len8": _native.IDX_LEN8, "len16": _native.IDX_LEN16, "offs32": _native.IDX_OFFS32, "offs64": _native.IDX_OFFS64}
 CNT = {"u8": _native.CNT_U8, "u32": _native.CNT_U32, "offs64": _native.CNT_OFFS64}
@@ -81,6 +82,15 @@ def pmc_quote(workload_desc, fname="k_filter_counters.json"):
     def shape(d):   # everything but the row count: counters of a launch over fewer rows are scaled per row by the caller
         return d.split(":")[0], d.split(" LR segments x ")[-1]
     return q if shape(q.get("workload", "")) == shape(workload_desc) else None
+
+
+def valu_mix(kernel_name):
+    """The committed instruction-mix estimate of the dominant kernel (tools/valu_mix.py), if it is about this kernel."""
+    path = os.path.join(ROOT, "profiles", "r03_valu_mix.json")
+    if not kernel_name or not os.path.exists(path):
+        return None
+    m = json.load(open(path))
+    return m if m.get("kernel") == kernel_name and m.get("mean_cycles_per_instruction") else None
 
 
 def make_batch(n, bc, seed, chunk=1_000_000, seg_len=22, frac_empty=0.05):
@@ -251,7 +261,15 @@ def hbm_roofline(loops, avg, desc, quote_file, exhaustive=False):
         roof["traffic_quoted"] = {"source": q["source"], "hbm_read_bytes": q.get("hbm_read_bytes"), "hbm_write_bytes": q.get("hbm_write_bytes"),
                                   "segments_per_profiled_launch": q.get("segments_per_launch"), "note": q.get("note")}
         if q.get("hbm_read_bytes"):
-            roof["traffic_quoted"]["missed_64B_lines_per_segment"] = round(q["hbm_read_bytes"] / 64.0 / q["segments_per_launch"], 2)
+            lines_seg = q["hbm_read_bytes"] / 64.0 / q["segments_per_launch"]
+            roof["traffic_quoted"]["missed_64B_lines_per_segment"] = round(lines_seg, 2)
+            # what the memory system delivers to random reads of one line each from a table far beyond the L2, whatever the table's
+            # size (32 MB - 2 GB, Infinity Cache or not) and whatever the bytes used per line: tools/gather_probe.hip
+            lps = lines_seg * loops.n_seg / (avg[dominant] * 1e-3)
+            roof["random_lines_quoted"] = {"lines_per_s": lps, "peak_lines_per_s": RANDOM_LINE_PEAK, "frac": round(lps / RANDOM_LINE_PEAK, 3),
+                                           "note": "peak measured: 5.5e10 random 16- or 32-byte reads per second from tables of 128 MB - 2 GB "
+                                                   "(profiles/r03_gather_probe.jsonl); meaningful where the misses are table lookups (cfg5), "
+                                                   "not streams (cfg3)"}
             tb = (rd + wr) / (avg[dominant] * 1e-3) / 1e9
             roof["traffic_GBps"] = round(tb, 1)
             roof["traffic_frac_of_peak"] = round(tb / HBM_PEAK_GBS, 4)
@@ -264,16 +282,17 @@ def hbm_roofline(loops, avg, desc, quote_file, exhaustive=False):
                                  "note": "peak = 16 channels x 8 XCDs x 1 request/clk at 2.4 GHz (34.5 TB/s / 128 B lines)"}
         if q.get("valu_insts_per_launch"):
             w = q["valu_insts_per_launch"] * scale / (avg[dominant] * 1e-3)
-            share_full = q.get("valu_full_rate_share")
             v = {"insts_per_segment": round(q["valu_insts_per_launch"] / q["segments_per_launch"], 1),
                  "achieved_wave_insts_per_s": w, "peak_if_all_half_rate_ops": VALU_PEAK_WINST_S,
                  "peak_if_all_full_rate_ops": VALU_PEAK_FULL_RATE_WINST_S}
-            if share_full is not None:
-                # ceiling of THIS instruction mix: the harmonic mean of the two measured issue rates, weighted by the dynamic share
-                # of each class (profiles/r03_valu_mix.json)
-                peak = 1.0 / ((1.0 - share_full) / VALU_PEAK_WINST_S + share_full / VALU_PEAK_FULL_RATE_WINST_S)
-                v.update({"full_rate_share": share_full, "peak_wave_insts_per_s": peak, "frac": round(min(w / peak, 1.0), 3),
-                          "frac_uncapped": round(w / peak, 3), "mix_source": q.get("valu_mix_source")})
+            mix = valu_mix(q.get("kernel"))
+            if mix:
+                # ceiling of THIS kernel's instruction mix: 1024 SIMDs x 2.4 GHz / (mean cycles per wave-instruction of the mix,
+                # every opcode priced at its measured issue cost: profiles/r03_valu_mix.json)
+                peak = 1024 * 2.4e9 / mix["mean_cycles_per_instruction"]
+                v.update({"full_rate_share": mix["valu_full_rate_share"], "mean_cycles_per_instruction": mix["mean_cycles_per_instruction"],
+                          "peak_wave_insts_per_s": peak, "frac": round(min(w / peak, 1.0), 3), "frac_uncapped": round(w / peak, 3),
+                          "mix_source": "profiles/r03_valu_mix.json (tools/valu_mix.py: disassembly weighted by loop depth; issue costs tools/valu_peak.hip)"})
             else:
                 v.update({"peak_wave_insts_per_s": VALU_PEAK_WINST_S, "frac": round(min(w / VALU_PEAK_WINST_S, 1.0), 3),
                           "frac_uncapped": round(w / VALU_PEAK_WINST_S, 3)})

@@ -71,8 +71,10 @@ static uint32_t d_payload(int sym) {
 
 /*
  * Canonical Huffman code -> look-up table.  lens[0..n) code lengths (0 = unused, <= 15).  kind: 0 = literal/length, 1 = distance,
- * 2 = code-length code (payload = symbol << 16).  Returns 0, or -1 if the lengths over-subscribe the code space or the
- * table does not fit.  Incomplete codes are accepted (RFC 1951 allows a single distance code); unassigned slots decode to K_BAD.
+ * 2 = code-length code (payload = symbol << 16).  Returns 0, or -1 if the lengths over-subscribe the code space, the table does
+ * not fit, or the code is incomplete — zlib's rule (inftrees.c), so that the command refuses exactly the streams gzip.open in the
+ * reference refuses: an incomplete literal/length or distance code is accepted only if it consists of ONE code of ONE bit (or of
+ * no code at all: a block without matches), a code-length code never.  Unassigned slots decode to K_BAD.
  */
 static int build_table(uint32_t *table, int table_size, int tbits, const uint8_t *lens, int n, int kind) {
     int count[16] = {0};
@@ -80,12 +82,15 @@ static int build_table(uint32_t *table, int table_size, int tbits, const uint8_t
     count[0] = 0;
     uint32_t code = 0, next[16];
     int64_t space = 1;
+    int max_len = 0;
     for (int l = 1; l <= 15; l++) {
         space = space * 2 - count[l];
         if (space < 0) return -1;
+        if (count[l]) max_len = l;
         code = (code + (l > 1 ? (uint32_t)count[l - 1] : 0u)) << 1;
         next[l] = code;
     }
+    if (space > 0 && max_len != 0 && (kind == 2 || max_len != 1)) return -1;   /* incomplete set */
     const int psize = 1 << tbits;
     for (int i = 0; i < psize; i++) table[i] = K_BAD | 1u;
     /* pass 1: sub-table widths per primary prefix */

@@ -166,6 +166,7 @@ static size_t mutate(uint8_t *c, size_t n, const uint8_t *other, size_t other_n)
 }
 
 /* -> 0 finished, 1 error, 2 input ended too early, 3 output limit */
+static char zlib_msg[128];
 static int run_zlib(const uint8_t *c, size_t n, uint8_t *out, size_t *out_n, size_t *used) {
     z_stream z;
     memset(&z, 0, sizeof(z));
@@ -177,6 +178,7 @@ static int run_zlib(const uint8_t *c, size_t n, uint8_t *out, size_t *out_n, siz
     const int rc = inflate(&z, Z_FINISH);
     *out_n = z.total_out;
     *used = z.total_in;
+    snprintf(zlib_msg, sizeof(zlib_msg), "%s", z.msg ? z.msg : "-");
     inflateEnd(&z);
     if (rc == Z_STREAM_END) return 0;
     if (rc == Z_DATA_ERROR || rc == Z_NEED_DICT) return 1;
@@ -251,7 +253,7 @@ int main(int argc, char **argv) {
             agree_bad++;
             if (vz != vo) class_differs++; /* "corrupt" vs "ends too early": which one is seen first depends on look-ahead */
         } else if (vo == 0) {
-            if (ours_ok_zlib_bad < 5) fprintf(stderr, "decoder accepts what zlib rejects (zlib verdict %d) at iteration %ld, %zu bytes in\n", vz, it, cn);
+            if (ours_ok_zlib_bad < 20) fprintf(stderr, "decoder accepts what zlib rejects (zlib verdict %d: %s) at iteration %ld, %zu bytes in\n", vz, zlib_msg, it, cn);
             ours_ok_zlib_bad++;
         } else {
             if (ours_bad_zlib_ok < 5) fprintf(stderr, "decoder rejects (%d) what zlib accepts at iteration %ld, %zu bytes in\n", vo, it, cn);
