@@ -987,8 +987,7 @@ struct FilterArgs {
     const uint8_t *segs;          // the rows' ASCII bytes (padded by 64 bytes past the end)
     const OffT *offs;             // CSR offsets of the rows: int64 (resident upload) or uint32 relative to the chunk (stream)
     int64_t seg_bytes;
-    int64_t row0;                 // main launch: first row of this launch (a batch's main launch may come as two row ranges); else 0
-    int64_t n;                    // end of the rows (main launch: rows row0 .. n - 1) / listed rows (retry launch) ...
+    int64_t n;                    // rows (main launch) / listed rows (retry launch) ...
     const uint32_t *n_dev;        // ... or, if not NULL, where that number lives on the device (the retry launch is queued
                                   // before the host knows how many rows the main launch handed over)
     const int32_t *rows;          // NULL = all rows; else the listed rows (retry launch)
@@ -1393,7 +1392,7 @@ k_filter(const FilterArgs<OffT> a) {
     using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE>;
     __shared__ Lds lds[WPB];
     const int64_t n = a.n_dev ? (int64_t)*a.n_dev : a.n;
-    const int64_t first = a.row0 + ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * RPW;
+    const int64_t first = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * RPW;
     if constexpr (WPB == 4) {
         // the main launch's 32-bit instantiation — where the time goes — is launched over all rows and stays loop-free:
         // wrapped in the loop below the compiler hoists enough address arithmetic out of it to cost two waves per SIMD.

@@ -206,14 +206,10 @@ __global__ void __launch_bounds__(256) k_index_offs(const T *__restrict__ in, in
     out[i] = (uint32_t)(a < 0 ? 0 : (a > bytes ? bytes : a));
 }
 
-// The scan may come in two parts (head rows first, so that their filter launch can start while the index of the rest is still
-// crossing the link): `base` = where the part's first row starts (the head's total, on the device; NULL = 0), `last` = this part
-// ends the chunk (writes out[n] and checks that the lengths add up to `bytes`), `row_base` = the part's first row (for CTR_BAD_ROW).
 template <typename T>
 __global__ void __launch_bounds__(256) k_index_lens(const T *__restrict__ lens, int64_t n, const uint64_t *__restrict__ sums,
                                                      const uint64_t *__restrict__ total, int64_t bytes, uint32_t *__restrict__ out,
-                                                     unsigned long long *__restrict__ bad_row, const uint64_t *__restrict__ base_dev = nullptr,
-                                                     bool last = true, int64_t row_base = 0) {
+                                                     unsigned long long *__restrict__ bad_row) {
     __shared__ uint64_t lds[8];
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint64_t v[SCAN_ITEMS];
@@ -222,17 +218,15 @@ __global__ void __launch_bounds__(256) k_index_lens(const T *__restrict__ lens, 
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) s += v[i];
     uint64_t tot;
-    const uint64_t b0 = base_dev ? *base_dev : 0ull;
-    uint64_t run = b0 + sums[blockIdx.x] + block_exclusive_scan(s, &tot, lds);
+    uint64_t run = sums[blockIdx.x] + block_exclusive_scan(s, &tot, lds);
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
         if (base + i < n) out[base + i] = (uint32_t)(run < (uint64_t)bytes ? run : (uint64_t)bytes);
         run += v[i];
     }
-    if (last && blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint64_t end = b0 + *total;
-        out[n] = (uint32_t)(end < (uint64_t)bytes ? end : (uint64_t)bytes);
-        if (end != (uint64_t)bytes) atomicMin(bad_row, (unsigned long long)(row_base + (n > 0 ? n - 1 : 0)));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[n] = (uint32_t)(*total < (uint64_t)bytes ? *total : (uint64_t)bytes);
+        if (*total != (uint64_t)bytes) atomicMin(bad_row, (unsigned long long)(n > 0 ? n - 1 : 0));
     }
 }
 

@@ -157,11 +157,6 @@ struct Lane {
     uint16_t *hits16_ptr = nullptr;  // 16-bit hits of a one-chunk stream call: the fill kernel writes them itself (hits_cap = their room)
     bool direct_min_e = false, direct_cnt = false, direct_hits = false;
     BatchParams bp;
-    // a zero-copy chunk whose row index is a list of lengths: the main filter launch comes as two row ranges, [0, head_rows) as soon
-    // as the head's offsets exist and the rest when `tail_index_done` (recorded on another lane's stream) has passed; 0 = one launch
-    int64_t head_rows = 0;
-    hipEvent_t tail_index_done = nullptr;
-    hipEvent_t aux[3] = {nullptr, nullptr, nullptr};
     int64_t n_hits = 0;
     int64_t stats[5] = {0, 0, 0, 0, 0};
     bool have_result = false;
@@ -185,10 +180,6 @@ struct Lane {
         for (DevBuf *b : bufs) b->release();
         for (hipEvent_t e : pool) (void)hipEventDestroy(e);
         pool.clear();
-        for (hipEvent_t &e : aux) {
-            if (e) (void)hipEventDestroy(e);
-            e = nullptr;
-        }
         if (done) (void)hipEventDestroy(done);
         if (h_ctr) (void)hipHostFree(h_ctr);
         if (stream) (void)hipStreamDestroy(stream);
@@ -582,8 +573,6 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
     l.hits_cap = l.hits.cap / 4;
     l.hits16_ptr = nullptr;
     l.direct_min_e = l.direct_cnt = l.direct_hits = false;
-    l.head_rows = 0;             // (sct_match_stream sets them after this call when it splits the index)
-    l.tail_index_done = nullptr;
     return SCT_OK;
 }
 
@@ -632,7 +621,6 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     {
         Timer t(c, l, "k_filter");
         fa.n = n;
-        fa.row0 = 0;
         fa.n_dev = nullptr;
         fa.rows = nullptr;
         fa.slots = l.slots.as<uint32_t>();
@@ -640,18 +628,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.list_defer = l.list_retry.as<int32_t>();
         fa.defer_count = ctr + CTR_RETRY;
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR);
-        if (l.head_rows > 0 && l.head_rows < n && l.tail_index_done) {
-            // the head's rows while the index of the rest is still being read over the link (sct_match_stream), then the rest
-            fa.n = l.head_rows;
-            launch_filter(bp.max_err, v, fa, blocks_for(l.head_rows, 256), capped((l.head_rows + 63) / 64), st);
-            (void)hipStreamWaitEvent(st, l.tail_index_done, 0);
-            fa.row0 = l.head_rows;
-            fa.n = n;
-            launch_filter(bp.max_err, v, fa, blocks_for(n - l.head_rows, 256), capped((n - l.head_rows + 63) / 64), st);
-            fa.row0 = 0;
-        } else {
-            launch_filter(bp.max_err, v, fa, blocks_for(n, 256), capped((n + 63) / 64), st);
-        }
+        launch_filter(bp.max_err, v, fa, blocks_for(n, 256), capped((n + 63) / 64), st);
     }
     {
         // rows with more ties / verified matches than the main launch keeps: once more with larger lists.  How many
@@ -660,7 +637,6 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         Timer t(c, l, "k_filter_retry");
         v.retry = true;
         fa.n = 0;
-        fa.row0 = 0;
         fa.n_dev = ctr + CTR_RETRY;
         fa.rows = l.list_retry.as<int32_t>();
         fa.slots = l.slots_retry.as<uint32_t>();
@@ -1251,61 +1227,22 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
             else {
                 const int64_t nb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
                 uint64_t *total = reinterpret_cast<uint64_t *>(l.ctr() + CTR_TOTAL);  // free until the hit counts are summed
-                // One zero-copy chunk of many rows: the lengths alone take 0.2 ms per 10 M rows to cross the link, during which
-                // nothing else would happen.  The first sixteenth of the rows is indexed by itself (a few microseconds), its filter
-                // launch starts, and the index of the rest is read on ANOTHER stream beside it (queue_filter_launches waits for it).
-                l.head_rows = 0;
-                l.tail_index_done = nullptr;
-                const int64_t head = (zc_index && n_chunks == 1 && m >= ((int64_t)1 << 21)) ? (m / 16) / SCAN_BLOCK * SCAN_BLOCK : 0;
-                Lane *lb = nullptr;
-                if (head > 0) {
-                    while (c->lanes.size() < 2) {
-                        Lane *nl = nullptr;
-                        if (int rc = lane_create(&nl)) return rc;
-                        c->lanes.push_back(nl);
-                    }
-                    lb = c->lanes[1];
-                    for (hipEvent_t &e : l.aux)
-                        if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                    const int64_t nbA = head / SCAN_BLOCK, nbB = (m - head + SCAN_BLOCK - 1) / SCAN_BLOCK;
-                    if (l.sums.ensure(8 * (size_t)(nbA + nbB + 4))) return g_code;
-                }
-                auto index_lens = [&](auto tag) -> int {
-                    using T = decltype(tag);
-                    const T *src = (const T *)idx_dev;
-                    T *keep = zc_index ? l.index_in.as<T>() : nullptr;
-                    if (head == 0) {
-                        k_sum_blocks<T><<<(unsigned)nb, 256, 0, st>>>(src, m, l.sums.as<uint64_t>(), keep);
-                        k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
-                        k_index_lens<T><<<(unsigned)nb, 256, 0, st>>>(keep ? keep : src, m, l.sums.as<uint64_t>(), total, bytes, l.offs32.as<uint32_t>(), bad);
-                        return SCT_OK;
-                    }
-                    const int64_t nbA = head / SCAN_BLOCK, nbB = (m - head + SCAN_BLOCK - 1) / SCAN_BLOCK;
-                    uint64_t *sums = l.sums.as<uint64_t>();
-                    uint64_t *total_b = sums + nbA + nbB + 1;
-                    hipStream_t sb = lb->stream;
-                    HIPCHK(hipEventRecord(l.aux[0], st));          // (the counter record has been reset on st)
-                    HIPCHK(hipStreamWaitEvent(sb, l.aux[0], 0));
-                    // the rest's block sums do not need the head ...
-                    k_sum_blocks<T><<<(unsigned)nbB, 256, 0, sb>>>(src + head, m - head, sums + nbA, keep + head);
-                    k_scan_sums<<<1, 256, 0, sb>>>(sums + nbA, nbB, total_b);
-                    // ... the head: sums, scan, offsets
-                    k_sum_blocks<T><<<(unsigned)nbA, 256, 0, st>>>(src, head, sums, keep);
-                    k_scan_sums<<<1, 256, 0, st>>>(sums, nbA, total);
-                    k_index_lens<T><<<(unsigned)nbA, 256, 0, st>>>(keep, head, sums, total, bytes, l.offs32.as<uint32_t>(), bad, nullptr, false, 0);
-                    HIPCHK(hipEventRecord(l.aux[1], st));
-                    // ... the rest's offsets start where the head's end
-                    HIPCHK(hipStreamWaitEvent(sb, l.aux[1], 0));
-                    k_index_lens<T><<<(unsigned)nbB, 256, 0, sb>>>(keep + head, m - head, sums + nbA, total_b, bytes, l.offs32.as<uint32_t>() + head, bad, total, true, head);
-                    HIPCHK(hipEventRecord(l.aux[2], sb));
-                    l.head_rows = head;
-                    l.tail_index_done = l.aux[2];
-                    return SCT_OK;
-                };
+                // a zero-copy index crosses the link once: the first pass leaves a copy on the device for the second.
+                // (Tried in round 3: the index in two parts, the head's filter launch beside the rest's lengths on a second stream.
+                // Nothing gained, 4.89 -> 5.04 ms per 10 M rows: the lengths are link traffic like the segments — 10 of the
+                // 219 MB a 10 M-row call reads — and the link is busy from the call's first microsecond to the start of the tail.)
                 if (index_format == SCT_IDX_LEN8) {
-                    if (int rc = index_lens(uint8_t{})) return rc;
+                    uint8_t *keep = zc_index ? l.index_in.as<uint8_t>() : nullptr;
+                    k_sum_blocks<uint8_t><<<(unsigned)nb, 256, 0, st>>>((const uint8_t *)idx_dev, m, l.sums.as<uint64_t>(), keep);
+                    k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
+                    k_index_lens<uint8_t><<<(unsigned)nb, 256, 0, st>>>(keep ? keep : (const uint8_t *)idx_dev, m, l.sums.as<uint64_t>(), total, bytes,
+                                                                       l.offs32.as<uint32_t>(), bad);
                 } else {
-                    if (int rc = index_lens(uint16_t{})) return rc;
+                    uint16_t *keep = zc_index ? l.index_in.as<uint16_t>() : nullptr;
+                    k_sum_blocks<uint16_t><<<(unsigned)nb, 256, 0, st>>>((const uint16_t *)idx_dev, m, l.sums.as<uint64_t>(), keep);
+                    k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
+                    k_index_lens<uint16_t><<<(unsigned)nb, 256, 0, st>>>(keep ? keep : (const uint16_t *)idx_dev, m, l.sums.as<uint64_t>(), total, bytes,
+                                                                        l.offs32.as<uint32_t>(), bad);
                 }
             }
         }
