@@ -39,7 +39,7 @@ def write_lr_file(path, segs, offs):
     return len(data)
 
 
-def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_rows=20000, quiet=False, extra=()):
+def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_rows=20000, quiet=False, extra=(), plain=False):
     """-> dict with the CLI's wall time over n rows x 25 k barcodes (gz TSV in, gz TSV out) and the sample check."""
     import bench
     os.makedirs(work, exist_ok=True)
@@ -51,6 +51,13 @@ def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_
     t0 = time.time()
     lr = os.path.join(work, "lr.tsv.gz")
     raw = write_lr_file(lr, segs, offs)
+    if plain:      # the same rows as a plain-text -lr file (no inflate on the way in)
+        data = gzip.open(lr, "rb").read()
+        os.remove(lr)
+        lr = os.path.join(work, "lr.tsv")
+        with open(lr, "wb") as f:
+            f.write(data)
+        del data
     sr = os.path.join(work, "sr.tsv")
     synth.write_barcodes_tsv(sr, bc)
     if not quiet:
@@ -88,4 +95,5 @@ def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/sct_e2e"
-    print(json.dumps(run(n, work, extra=sys.argv[3:])), flush=True)
+    extra = [a for a in sys.argv[3:] if a != "--plain"]
+    print(json.dumps(run(n, work, extra=extra, plain="--plain" in sys.argv[3:])), flush=True)
