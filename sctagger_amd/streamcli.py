@@ -21,6 +21,7 @@ import os
 import queue
 import sys
 import threading
+import time
 import zlib
 
 import numpy as np
@@ -241,6 +242,7 @@ class _Worker(threading.Thread):
         self.error = None
         self.rows = 0
         self.cap_rows = self.cap_bytes = 0
+        self.t = {"parse": 0.0, "wait_device": 0.0, "wait_lock": 0.0, "match": 0.0, "render": 0.0, "idle": 0.0}
 
     def _ensure(self, nbytes):
         if nbytes <= self.cap_bytes:
@@ -267,7 +269,9 @@ class _Worker(threading.Thread):
         n_bc = self.dev.bc.shape[0]
         # 16-bit hits while the pattern ids fit (2 per barcode): half the bytes back over the link
         hfmt, hbytes = (_native.HITS_U16, 2) if 2 * n_bc <= 65536 else (_native.HITS_U32, 4)
+        clk = time.perf_counter
         while at < len(buf):
+            t0 = clk()
             lib.sctio_parse_block(base + at, len(buf) - at, 1 if final else 0, self.cap_rows, self.cap_bytes, self.ns.ctypes.data,
                                   self.ne.ctypes.data, self.segs.ctypes.data, self.offs.ctypes.data, self.lens.ctypes.data,
                                   self.info.ctypes.data)
@@ -283,8 +287,12 @@ class _Worker(threading.Thread):
                 index, ifmt = self.lens[:n], _native.IDX_LEN8
             else:
                 index, ifmt = self.offs[:n + 1], _native.IDX_OFFS32
+            t1 = clk()
             m = self.dev.matcher()
-            with self.dev.lock:       # the hit lists come back in the context's own buffer: copied before the next worker's call
+            t2 = clk()
+            self.dev.lock.acquire()   # the hit lists come back in the context's own buffer: copied before the next worker's call
+            t3 = clk()
+            try:
                 try:
                     me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
                                                    count_format=_native.CNT_U8, min_e=self.min_e, counts=cnt8, copy_hits=True, hits_format=hfmt)
@@ -295,6 +303,9 @@ class _Worker(threading.Thread):
                     me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
                                                    count_format=_native.CNT_U32, min_e=self.min_e, counts=self.cnt, copy_hits=True, hits_format=hfmt)
                     cbytes = 4
+            finally:
+                self.dev.lock.release()
+            t4 = clk()
             hp = hits.ctypes.data if hits.size else None
             args = [base + at, self.ns.ctypes.data, self.ne.ctypes.data, self.segs.ctypes.data, self.offs.ctypes.data, me.ctypes.data,
                     cnt.ctypes.data, cbytes, hp, hbytes, self.table.ctypes.data, self.table.shape[1] if self.table.ndim == 2 else 0, n]
@@ -305,6 +316,9 @@ class _Worker(threading.Thread):
             out.append(o)
             if self.want_min_e:
                 keep.append(me.copy())
+            t5 = clk()
+            for k, v in (("parse", t1 - t0), ("wait_device", t2 - t1), ("wait_lock", t3 - t2), ("match", t4 - t3), ("render", t5 - t4)):
+                self.t[k] += v
             n_rows += n
             at += used
         return out, keep, n_rows
@@ -313,7 +327,9 @@ class _Worker(threading.Thread):
         try:
             lib = _iolib()
             while True:
+                t0 = time.perf_counter()
                 item = self.inq.get()
+                self.t["idle"] += time.perf_counter() - t0
                 if item is None:
                     break
                 idx, buf, final = item
@@ -341,6 +357,7 @@ def cpu_workers_for(n_devices):
 def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), want_min_e=False, block_bytes=BLOCK_BYTES, cpu_workers=None):
     """Stream `lr_path` through the devices into `sink` (an object with write(bytes-like)); -> (rows read, list of min_e
     arrays in row order if want_min_e).  Raises NeedPlainReader / IndexError like the whole-file readers."""
+    t_start = time.perf_counter()
     devs = [_Device(d, bc, bl) for d in devices]
     for d in devs:
         d.start()
@@ -369,6 +386,7 @@ def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), w
         except BaseException as e:
             state["error"] = e
         finally:
+            state["reader_done"] = time.perf_counter() - t_start
             outq.put((-2, None, None))      # the reader is done
 
     reader = threading.Thread(target=feed, daemon=True)
@@ -412,6 +430,10 @@ def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), w
         w.join()
     for d in devs:
         d.close()
+    if os.environ.get("SCT_CLI_TIMING"):
+        tot = {k: round(sum(w.t[k] for w in workers), 3) for k in workers[0].t}
+        sys.stderr.write("streamcli timing: %d workers, %d blocks, reader done at %.3f s, pipeline %.3f s; summed over workers: %s\n" % (
+            n_workers, state["blocks"], state.get("reader_done", -1.0), time.perf_counter() - t_start, tot))
     if failure is not None:
         raise failure
     if any(w.error is not None for w in workers):      # an error that arrived after the loop had what it needed
