@@ -73,9 +73,34 @@ def parse_args(argv=None):
     return args
 
 
+def since_process_start():
+    """Seconds since this process was started (Linux), for SCT_CLI_TIMING."""
+    try:
+        import os
+        with open("/proc/self/stat") as f:
+            start_ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return up - start_ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:
+        return -1.0
+
+
 def main(argv=None):
+    import os
+    timing = bool(os.environ.get("SCT_CLI_TIMING"))
+    if timing:
+        sys.stderr.write("cli timing: main() entered %.3f s after process start\n" % since_process_start())
     args = parse_args(argv)
     print(args, file=sys.stderr)
+    try:
+        _dispatch(args)
+    finally:
+        if timing:
+            sys.stderr.write("cli timing: sub-command returned %.3f s after process start\n" % since_process_start())
+
+
+def _dispatch(args):
     if args.subcommand == "extract_lr_bc":
         from . import extract_lr_bc as _l
         _l.extract_lr_bc(args)

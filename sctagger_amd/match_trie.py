@@ -209,13 +209,19 @@ def _match_trie_streaming(args, devices, level):
         sink = fastio.GzipChunkWriter(tmp, level, threads=min(32, max(4, (os.cpu_count() or 8) // 2)))
     else:
         sink = open(tmp, "wb")
+    import time
+    t0 = time.perf_counter()
     try:
         try:
             rows, min_es = streamcli.run_pipeline(args.long_read_segments, bc, args.barcode_length, args.max_error, args.threads, table, sink,
                                                   devices=tuple(devices), want_min_e=want_plot)
         finally:
+            t1 = time.perf_counter()
             sink.close()
         os.replace(tmp, args.outfile)
+        if os.environ.get("SCT_CLI_TIMING"):
+            sys.stderr.write("match_trie timing: pipeline %.3f s, closing the output (last gzip members, write, rename) %.3f s\n" % (
+                t1 - t0, time.perf_counter() - t1))
     except BaseException:
         try:
             os.remove(tmp)
