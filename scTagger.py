@@ -4,3 +4,10 @@ from sctagger_amd.cli import main
 
 if __name__ == "__main__":
     main()
+    # The work is done and every output file is closed: leave at once.  Unwinding the interpreter (worker threads, the gzip pool)
+    # and the HIP runtime (freeing a few GB of device buffers) costs 0.12 s of a command that takes 0.7 s for 10^7 rows.
+    import os
+    import sys
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)

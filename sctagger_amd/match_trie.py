@@ -195,7 +195,7 @@ def write_matches(outfile, min_e, hit_offs, hits, chunk=200_000):
         outfile.write("".join(lines))
 
 
-def _match_trie_streaming(args, devices, level):
+def _match_trie_streaming(args, devices, level, devs=None):
     from . import streamcli
     _log("Reading long reads barcodes")
     bc = _barcode_matrix(args.barcode_length)
@@ -214,7 +214,7 @@ def _match_trie_streaming(args, devices, level):
     try:
         try:
             rows, min_es = streamcli.run_pipeline(args.long_read_segments, bc, args.barcode_length, args.max_error, args.threads, table, sink,
-                                                  devices=tuple(devices), want_min_e=want_plot)
+                                                  devices=tuple(devices), want_min_e=want_plot, devs=devs)
         finally:
             t1 = time.perf_counter()
             sink.close()
@@ -237,16 +237,26 @@ def _match_trie_streaming(args, devices, level):
 def match_trie(args):
     """reference :758-790. args: long_read_segments, short_read_barcodes, max_error, barcode_length,
     threads, outfile; mem is accepted and unused as in the reference; plotfile draws the distance histogram."""
-    read_sr_barcodes(args.short_read_barcodes)
-    barcode_lens = {len(b) for b in barcodes}
-    assert barcode_lens == {args.barcode_length}, barcode_lens
     devices = getattr(args, "devices", None) or (0,)
     level = getattr(args, "gzip_level", 4)
-    if args.outfile and not getattr(args, "no_stream", False):
-        # the pipelined command (streamcli.py): read || parse + match + render || compress, block by block
+    streaming = bool(args.outfile) and not getattr(args, "no_stream", False)
+    devs = None
+    if streaming:
+        # creating a device context takes 0.2 s: start now, on threads of their own, while the barcodes are read
         from . import streamcli
+        devs = streamcli.start_devices(tuple(devices))
+    try:
+        read_sr_barcodes(args.short_read_barcodes)
+        barcode_lens = {len(b) for b in barcodes}
+        assert barcode_lens == {args.barcode_length}, barcode_lens
+    except BaseException:
+        for d in devs or ():
+            d.close()
+        raise
+    if streaming:
+        # the pipelined command (streamcli.py): read || parse + match + render || compress, block by block
         try:
-            _match_trie_streaming(args, devices, level)
+            _match_trie_streaming(args, devices, level, devs)
             return
         except streamcli.NeedPlainReader:
             pass    # bytes the block parser cannot represent exactly: the reference's own procedure on the whole file, below

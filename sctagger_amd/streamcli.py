@@ -28,7 +28,11 @@ import numpy as np
 
 from . import _native, fastio
 
-BLOCK_BYTES = int(os.environ.get("SCT_STREAM_BLOCK_BYTES", 32 << 20))   # the environment variable is for tests (many small blocks)
+# Blocks of 4 MB (105 k rows of the usual shape).  Measured on the GPU box, 10 M rows (tools/cli_workers_sweep.sh): the reader
+# finishes a gzip input in 0.67 s with 32 MB blocks and in 0.52 s with 4 or 8 MB ones — a piece that has just been inflated is still
+# in the cache when it is copied out, CRC-summed and cut at its last line end —, a plain-text input in 0.36 / 0.19 s; and the last
+# block's parse + match + render + compress, which nothing overlaps, shrinks with the block.  (The environment variable is for tests.)
+BLOCK_BYTES = int(os.environ.get("SCT_STREAM_BLOCK_BYTES", 4 << 20))
 ROWS_PER_PASS = 1 << 21
 PIECE_BYTES = 4 << 20
 
@@ -198,18 +202,27 @@ class _Device(threading.Thread):
     """One context on one device, created on a thread of its own while the first blocks are being read and parsed (creating it
     costs 0.2 s), then shared by the CPU workers bound to it: a context serves one host thread at a time (`lock`)."""
 
-    def __init__(self, device, bc, bl):
+    def __init__(self, device, bc=None, bl=None):
         super().__init__(daemon=True)
         self.device, self.bc, self.bl = device, bc, bl
+        self.have_bc = threading.Event()       # the barcodes may be handed over later (set_barcodes): the context is created meanwhile
+        if bc is not None:
+            self.have_bc.set()
         self.ready = threading.Event()
         self.lock = threading.Lock()
         self.m = None
         self.error = None
 
+    def set_barcodes(self, bc, bl):
+        self.bc, self.bl = bc, bl
+        self.have_bc.set()
+
     def run(self):
         try:
             self.m = _native.Matcher(self.device)
-            self.m.set_barcodes(self.bc, self.bl)
+            self.have_bc.wait()
+            if self.bc is not None:
+                self.m.set_barcodes(self.bc, self.bl)
         except BaseException as e:
             self.error = e
         finally:
@@ -222,6 +235,7 @@ class _Device(threading.Thread):
         return self.m
 
     def close(self):
+        self.have_bc.set()
         self.ready.wait()
         if self.m is not None:
             with self.lock:
@@ -354,13 +368,25 @@ def cpu_workers_for(n_devices):
     return max(n_devices, min(8, max(1, cores // 4)))
 
 
-def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), want_min_e=False, block_bytes=BLOCK_BYTES, cpu_workers=None):
-    """Stream `lr_path` through the devices into `sink` (an object with write(bytes-like)); -> (rows read, list of min_e
-    arrays in row order if want_min_e).  Raises NeedPlainReader / IndexError like the whole-file readers."""
-    t_start = time.perf_counter()
-    devs = [_Device(d, bc, bl) for d in devices]
+def start_devices(devices):
+    """Start creating one context per entry of `devices` (0.2 s each, on threads of their own) before the barcodes have even been
+    read; run_pipeline(..., devs=...) hands the barcodes over."""
+    devs = [_Device(d) for d in devices]
     for d in devs:
         d.start()
+    return devs
+
+
+def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), want_min_e=False, block_bytes=BLOCK_BYTES, cpu_workers=None,
+                 devs=None):
+    """Stream `lr_path` through the devices into `sink` (an object with write(bytes-like)); -> (rows read, list of min_e
+    arrays in row order if want_min_e).  Raises NeedPlainReader / IndexError like the whole-file readers.  `devs`: contexts already
+    being created by start_devices (they are closed here)."""
+    t_start = time.perf_counter()
+    if devs is None:
+        devs = start_devices(devices)
+    for d in devs:
+        d.set_barcodes(bc, bl)
     n_workers = cpu_workers or cpu_workers_for(len(devs))
     inq = queue.Queue(maxsize=2 * n_workers)
     workers = [_Worker(devs[i % len(devs)], inq, max_err, threads, table, want_min_e) for i in range(n_workers)]

@@ -11,7 +11,7 @@ lrgz = os.path.join(work, "lr.tsv.gz"); cli_e2e.write_lr_file(lrgz, segs, offs)
 import gzip
 data = gzip.open(lrgz, "rb").read(); open(os.path.join(work, "lr.tsv"), "wb").write(data); del data
 sr = os.path.join(work, "sr.tsv"); synth.write_barcodes_tsv(sr, bc)
-for inp, w, blk in (("lr.tsv", "8", 32), ("lr.tsv", "8", 8), ("lr.tsv", "8", 4), ("lr.tsv", "4", 8), ("lr.tsv.gz", "4", 32), ("lr.tsv.gz", "4", 8), ("lr.tsv.gz", "4", 4)):
+for inp, w, blk in (("lr.tsv", "8", 4), ("lr.tsv", "4", 4), ("lr.tsv", "4", 2), ("lr.tsv.gz", "4", 4), ("lr.tsv.gz", "8", 4), ("lr.tsv.gz", "4", 2)):
     if True:
         env = dict(os.environ, SCT_CLI_WORKERS=w, SCT_CLI_TIMING="1", SCT_STREAM_BLOCK_BYTES=str(blk << 20))
         best = 9; err = b""
