@@ -82,10 +82,46 @@ def _gzip_header_end(data, at):
     return p if p <= len(data) else None
 
 
-def _inflate_pieces(path, piece_bytes):
-    """The decompressed contents of a gzip file, in pieces, through the decoder of csrc/sct_inflate.c (about twice zlib's
-    speed: the command waits for nothing else).  CRC-32 and length of every member are checked, the CRC on a thread of its
-    own; a file the decoder does not take from its first byte on is read through zlib instead."""
+WINDOW = 32768      # what the decoder of csrc/sct_inflate.c wants in front of its output (the previous 32 KiB, for the matches)
+
+
+def _cut(region, block_bytes):
+    """Cut a filled region (uint8 array: the previous piece's unfinished line + a new piece) into blocks of about block_bytes that
+    end at a line end.  -> (list of views, the unfinished rest as bytes)."""
+    out, at, n = [], 0, region.size
+    mv = memoryview(region)
+    while n - at > 0:
+        end = min(n, at + block_bytes)
+        # the last line end at or before `end` ... or, if the block would be empty, the first one after it
+        k = _rfind_nl(mv, at, end)
+        if k < 0:
+            k = _find_nl(mv, end, n)
+            if k < 0:
+                break
+        out.append(region[at:k + 1])
+        at = k + 1
+    return out, bytes(mv[at:n])
+
+
+def _rfind_nl(mv, a, b):
+    k = bytes(mv[max(a, b - 4096):b]).rfind(b"\n")
+    if k >= 0:
+        return max(a, b - 4096) + k
+    k = bytes(mv[a:b]).rfind(b"\n")     # a line of more than 4 KB
+    return a + k if k >= 0 else -1
+
+
+def _find_nl(mv, a, b):
+    k = bytes(mv[a:b]).find(b"\n")
+    return a + k if k >= 0 else -1
+
+
+def _inflate_regions(path, piece_bytes):
+    """The decompressed contents of a gzip file as (buffer, start, end, carry_room) pieces decoded STRAIGHT into fresh numpy buffers
+    by the decoder of csrc/sct_inflate.c (about twice zlib's speed: the command waits for nothing else): yields (buf, pre, n) — the
+    piece is buf[pre : pre + n] and buf[:pre] is scratch (>= `want_pre()` bytes) in which the caller may put the unfinished line
+    of the piece before.  CRC-32 and length of every member are checked, the CRC on a thread of its own; a file the decoder does
+    not take from its first byte on is read through zlib instead."""
     import gzip
     with open(path, "rb") as f:
         data = f.read()
@@ -104,16 +140,18 @@ def _inflate_pieces(path, piece_bytes):
                     raw = d.unused_data.lstrip(b"\0") if not raw else raw
                     d, started = zlib.decompressobj(31), False
                 if out:
-                    yield out
+                    pre = yield None
+                    buf = np.empty(pre + len(out), dtype=np.uint8)
+                    buf[pre:] = np.frombuffer(out, dtype=np.uint8)
+                    yield buf, pre, len(out)
         if started and not d.eof:
             raise EOFError("Compressed file ended before the end-of-stream marker was reached")
         return
     lib = _iolib()
     base = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value
     st = lib.sctio_inflate_new()
-    out = np.empty(32768 + piece_bytes, dtype=np.uint8)
     status, used = ctypes.c_int32(0), ctypes.c_int64(0)
-    crc_q = queue.Queue(maxsize=8)
+    crc_q = queue.Queue(maxsize=16)
     crc_state = {"bad": False}
 
     def crc_worker():
@@ -137,11 +175,13 @@ def _inflate_pieces(path, piece_bytes):
         while True:
             lib.sctio_inflate_set_input(st, base + at, len(data) - at)
             while True:
-                n = lib.sctio_inflate_run(st, out.ctypes.data, piece_bytes, ctypes.byref(status), ctypes.byref(used))
+                pre = yield None                  # how much room the consumer wants in front of the piece (its unfinished line)
+                pre = max(int(pre), WINDOW)
+                buf = np.empty(pre + piece_bytes, dtype=np.uint8)
+                n = lib.sctio_inflate_run(st, buf.ctypes.data + pre - WINDOW, piece_bytes, ctypes.byref(status), ctypes.byref(used))
                 if n:
-                    piece = out[32768:32768 + n].tobytes()
-                    crc_q.put(piece)
-                    yield piece
+                    crc_q.put(memoryview(buf)[pre:pre + n])
+                yield buf, pre, int(n)
                 if status.value != 0:
                     break
             if status.value < 0:
@@ -166,36 +206,46 @@ def _inflate_pieces(path, piece_bytes):
         raise gzip.BadGzipFile("CRC check failed")
 
 
-def iter_blocks(path, block_bytes=BLOCK_BYTES):
-    """Yield (bytes, final) pieces of the file's (decompressed) contents, each ending at a line end except possibly the
-    last.  gzip iff the name ends with '.gz' (the reference's rule, :605); multi-member gzip files are read through."""
-    def pieces():
-        if path.endswith(".gz"):
-            yield from _inflate_pieces(path, max(block_bytes, 1 << 16))
-        else:
-            with open(path, "rb") as f:
-                while True:
-                    raw = f.read(block_bytes)
-                    if not raw:
-                        return
-                    yield raw
+def _file_regions(path, piece_bytes):
+    """The same protocol for a plain file: readinto a fresh buffer behind the room the consumer asks for."""
+    with open(path, "rb", buffering=0) as f:
+        while True:
+            pre = yield None
+            pre = int(pre)
+            buf = np.empty(pre + piece_bytes, dtype=np.uint8)
+            n = f.readinto(memoryview(buf)[pre:])
+            yield buf, pre, int(n or 0)
+            if not n:
+                return
 
-    pend, size = [], 0
-    for out in pieces():
-        pend.append(out)
-        size += len(out)
-        if size >= block_bytes:
-            buf = b"".join(pend) if len(pend) > 1 else pend[0]
-            k = buf.rfind(b"\n")
-            if k < 0:
-                pend, size = [buf], len(buf)
-            else:
-                pend = [buf[k + 1:]] if k + 1 < len(buf) else []
-                size = len(buf) - (k + 1)
-                yield buf[:k + 1], False
-    buf = b"".join(pend)
-    if buf:
-        yield buf, True
+
+def iter_blocks(path, block_bytes=BLOCK_BYTES):
+    """Yield (uint8 array, final) pieces of the file's (decompressed) contents, each ending at a line end except possibly the
+    last.  gzip iff the name ends with '.gz' (the reference's rule, :605); multi-member gzip files are read through.  The
+    bytes are decoded / read once, into the buffer the blocks are views of: only an unfinished last line is copied (into the
+    scratch in front of the next piece)."""
+    piece = max(block_bytes, 1 << 16)             # (the decoder wants at least 64 KiB of room; small blocks are cut out of a piece)
+    gen = (_inflate_regions if path.endswith(".gz") else _file_regions)(path, piece)
+    carry = b""
+    try:
+        while True:
+            try:
+                next(gen)                         # runs to its `pre = yield None`
+            except StopIteration:
+                break
+            buf, pre, n = gen.send(len(carry))
+            if n == 0:
+                continue
+            c = len(carry)
+            if c:
+                buf[pre - c:pre] = np.frombuffer(carry, dtype=np.uint8)
+            blocks, carry = _cut(buf[pre - c:pre + n], block_bytes)
+            for b in blocks:
+                yield b, False
+    finally:
+        gen.close()
+    if carry:
+        yield np.frombuffer(carry, dtype=np.uint8), True
 
 
 class _Device(threading.Thread):
@@ -277,7 +327,7 @@ class _Worker(threading.Thread):
     def _block(self, lib, buf, final):
         """-> (list of rendered byte strings, list of min_e copies, rows)"""
         self._ensure(len(buf))
-        base = ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p).value
+        base = buf.ctypes.data          # (a uint8 array: a view of the buffer the reader decoded into)
         at, n_rows, out, keep = 0, 0, [], []
         cnt8 = self.cnt.view(np.uint8)
         n_bc = self.dev.bc.shape[0]

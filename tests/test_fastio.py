@@ -132,8 +132,8 @@ def test_iter_blocks_cuts_at_line_ends(tmp_path):
     for path in (plain, gz1, gzm):
         for bb in (1 << 10, 50_000, 1 << 30):
             blocks = list(streamcli.iter_blocks(str(path), bb))
-            assert b"".join(b for b, _ in blocks) == data
-            assert all(b.endswith(b"\n") for b, _ in blocks[:-1]) and [f for _, f in blocks][:-1] == [False] * (len(blocks) - 1)
+            assert b"".join(bytes(b) for b, _ in blocks) == data
+            assert all(bytes(b[-1:]) == b"\n" for b, _ in blocks[:-1]) and [f for _, f in blocks][:-1] == [False] * (len(blocks) - 1)
     empty = tmp_path / "e.tsv.gz"
     with gzip.open(empty, "wb"):
         pass

@@ -91,7 +91,7 @@ def test_gzip_container(tmp_path):
     text = ("\n".join("r%d\t0\t5\t%s" % (i, "".join(rng.choice("ACGTN") for _ in range(rng.randint(0, 40)))) for i in range(20000)) + "\n").encode()
 
     def read(path, block=1 << 16):
-        return b"".join(b for b, _ in streamcli.iter_blocks(str(path), block))
+        return b"".join(bytes(b) for b, _ in streamcli.iter_blocks(str(path), block))
 
     p = tmp_path / "named.tsv.gz"                  # FNAME + mtime in the header (gzip.open writes them)
     with gzip.open(p, "wb", compresslevel=6) as f:
