@@ -206,7 +206,9 @@ def _match_trie_streaming(args, devices, level, devs=None):
     # target, which takes its name only when every block has been read, checked (gzip CRC and length included) and written.
     tmp = "%s.tmp.%d" % (args.outfile, os.getpid())
     if args.outfile.endswith("gz"):
-        sink = fastio.GzipChunkWriter(tmp, level, threads=min(32, max(4, (os.cpu_count() or 8) // 2)))
+        # (10^7 rows are 420 MB of output: 8 CPU-seconds of deflate at level 4 — the pool, not the device, is what a plain-text
+        # input waits for)
+        sink = fastio.GzipChunkWriter(tmp, level, threads=min(64, max(4, (os.cpu_count() or 8) // 2)))
     else:
         sink = open(tmp, "wb")
     import time

@@ -90,14 +90,14 @@ def _cut(region, block_bytes):
     end at a line end.  -> (list of views, the unfinished rest as bytes)."""
     out, at, n = [], 0, region.size
     mv = memoryview(region)
-    while n - at > 0:
-        end = min(n, at + block_bytes)
-        # the last line end at or before `end` ... or, if the block would be empty, the first one after it
+    # as many blocks as the region holds whole multiples of block_bytes (a piece plus the few bytes of an unfinished line is ONE
+    # block, not a block and a crumb), each cut at the last line end before its share of the region
+    k_blocks = max(1, int(round(n / float(block_bytes))))
+    for i in range(1, k_blocks + 1):
+        end = n if i == k_blocks else min(n, max(at + 1, (n * i) // k_blocks))
         k = _rfind_nl(mv, at, end)
         if k < 0:
-            k = _find_nl(mv, end, n)
-            if k < 0:
-                break
+            continue              # no line end in this share: the next share's block takes these bytes too
         out.append(region[at:k + 1])
         at = k + 1
     return out, bytes(mv[at:n])
