@@ -31,7 +31,7 @@ void launch(const SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, un
             k_filter<E, uint64_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, true, false, OffT><<<g64, 64, 0, st>>>(fa);
         } else if (v.thirds) {
             if constexpr (E <= 1) {
-                k_filter<E, uint32_t, SCHEME_THIRDS, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
+                if (!v.only64) k_filter<E, uint32_t, SCHEME_THIRDS, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
                 k_filter<E, uint64_t, SCHEME_THIRDS, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.wide) {

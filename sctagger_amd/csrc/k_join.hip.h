@@ -1,0 +1,335 @@
+// k_join.hip.h — the thirds scheme at max_err = 1 as a PARTITIONED JOIN (very large barcode sets: BASELINE configs[4], 3.6 M barcodes).
+// Part of libsctagger_hip.so (translation unit join_e1.hip).  gfx950 only.
+//
+// Why.  With 7.2 M patterns the seed tables (fixed buckets, sct_tables.h) are 160 MB; the filter kernel (k_filter.hip.h) makes ~26
+// lookups per row, each a random 16- or 32-byte read, and the memory system serves 5.5 x 10^10 random lines per second beyond the L2
+// whatever the table's size (tools/gather_probe.hip, profiles/r03_gather_probe.jsonl): 5.0 ms per 10 M rows, 27 missed lines per row,
+// nothing the kernel itself can improve.  From a table slice of 2 MB the same reads come at 2.6 x 10^11/s (L2).  So the lookups are
+// turned into a join: every lookup becomes an 8-byte TUPLE (row, low key bits, the few text characters the verification needs),
+// tuples are written partition by partition — a partition = the keys whose buckets lie in one 2 MB slice of a family's table —, and
+// probed partition by partition, every workgroup on the chip inside the same slice.  A row's candidates meet again in a small
+// per-row list (global atomics, one per verified hit) that the last kernel folds exactly as the filter kernel folds its LDS lists.
+//
+//   k_join_part0   rows -> bit-planes (kept for tier 1), routing as in the filter kernel, T01 tuples        (reads the rows once)
+//   k_join_probe   T01 partitions: bucket (L2) -> compare (sct_join_distance, sct_core.h) -> per-row hit list
+//   k_join_part1   rows without a distance-0 hit -> T12 and T02 tuples                                         (tiering, as the filter)
+//   k_join_probe   T12 / T02 partitions
+//   k_join_finish  per-row list -> pattern ids, minimum, distinct, sorted; stored exactly as the filter's main launch stores them
+// Rows of 32 .. 63 characters (whole waves of them: the filter kernel's own rule), rows the retry launch must redo and everything
+// else stay with k_filter: the join replaces its 32-bit main launch only.  Verification needs no automaton at one edit: the two
+// seed pieces are exact, the remaining 5 or 6 pattern characters are compared with the text beside the anchors by mismatch masks
+// (host-checked against the anchored automaton for every placement, tests/host_core_check.cpp).
+#pragma once
+
+static constexpr int JOIN_P0 = 16;           // T01: 2^20 keys x 32 B = 32 MB -> 16 slices of 2 MB (key >> 16)
+static constexpr int JOIN_P1 = 64;           // T12 and T02: 2^22 keys x 16 B = 64 MB each -> 32 slices each (key >> 17)
+static constexpr int JOIN_CAP0 = 512;        // tuples a producer block (256 rows) may leave in one partition: T01 (mean 128 at 22 characters)
+static constexpr int JOIN_CAP1 = 256;        // ... T12 / T02 (mean 77)
+static constexpr int JOIN_GROUP = 16;        // producer blocks per probe block
+static constexpr int64_t JOIN_SUB_ROWS = (int64_t)1 << 22;   // rows per pass (a multiple of 256): the tuple regions hold one pass
+static constexpr int JOIN_HITS = 8;          // entries of a row's list (more: the row goes to the retry launch)
+static constexpr int JOIN_STAGE_BYTES = 256 * 31 + 384;
+
+template <typename OffT>
+struct JoinArgs {
+    FilterArgs<OffT> fa;          // rows, tables, result arrays, routing lists, counters: as the filter's main launch gets them
+    int64_t row0, row1;           // the rows of this pass (the tuple buffers hold JOIN_SUB_ROWS rows' worth)
+    uint2 *planes;                // per row: the bit-planes (0 for rows the join does not handle)
+    uint8_t *jlen;                // per row: its length if the join handles it, else 0
+    uint8_t *wave_kind;           // per 64 rows: 1 = the join handles this wave (k_join_finish stores it), 0 = k_filter's 64-bit launch does
+    uint32_t *jcnt;               // per row: hits handed out (bits 0..15) | distance-0 hits (bits 16..30)
+    uint32_t *jslots;             // per row: JOIN_HITS entries, distance << 30 | locator
+    unsigned long long *tup0, *tup1;
+    uint32_t *cnt0, *cnt1;        // tuples per (producer block, partition)
+};
+
+// tuple: bits 0..29 row | bits 30..46 low key bits | bits 47..63 context (sct_join_ctx_*)
+__device__ __forceinline__ unsigned long long join_tuple(int64_t row, uint32_t keylow, uint32_t ctx) {
+    return (unsigned long long)(uint32_t)row | ((unsigned long long)keylow << 30) | ((unsigned long long)ctx << 47);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pass 0: decode + route (the prologue of filter_rows, E = 1, 32-bit masks) + T01 tuples
+// ------------------------------------------------------------------------------------------------------------
+template <typename OffT>
+__global__ void __launch_bounds__(256) k_join_part0(const JoinArgs<OffT> ja) {
+    const FilterArgs<OffT> &a = ja.fa;
+    constexpr int E = 1, bl = 16;
+    __shared__ uint32_t stage[JOIN_STAGE_BYTES / 4];
+    __shared__ uint32_t pcnt[JOIN_P0];
+    __shared__ uint32_t block_flags;
+    const int lane = threadIdx.x & 63, widx = threadIdx.x >> 6;
+    const int64_t n = ja.row1;
+    const int64_t first = ja.row0 + ((int64_t)blockIdx.x * 4 + widx) * 64;
+    const int64_t gid = first + lane;
+    const bool inrange = gid < n;
+    const int64_t r = gid;
+    int64_t start = 0, len64 = 0;
+    if (inrange) sct_row_span(a.offs, r, a.seg_bytes, start, len64);
+    const int len_all = (int)(len64 < 0x7FFFFFFF ? len64 : 0x7FFFFFFF);
+    const bool fits = inrange && len_all >= bl - E && len_all <= PLANE_MAX;
+    int len = fits ? len_all : 0;
+    const int maxlen = wave_max_i(len);
+    const bool mykind = maxlen <= 31;
+    const bool anyrow = __ballot(inrange) != 0;
+    if (threadIdx.x < JOIN_P0) pcnt[threadIdx.x] = 0;
+    if (lane == 0) reinterpret_cast<uint8_t *>(&block_flags)[widx] = !anyrow ? 2 : (mykind ? 1 : 0);
+    __syncthreads();
+    uint32_t lo = 0, hi = 0;
+    bool nonacgt = false, decoded = false;
+    {
+        const uint32_t f4 = block_flags;
+        if ((f4 & 0xFFu) != 0u && (f4 & 0xFF00u) != 0u && (f4 & 0xFF0000u) != 0u && (f4 & 0xFF000000u) != 0u) {
+            const int64_t bf = first - 64 * widx;
+            const int64_t be = bf + 256 < n ? bf + 256 : n;
+            int64_t A = (int64_t)a.offs[bf], B = (int64_t)a.offs[be];
+            A = A < 0 ? 0 : (A > a.seg_bytes ? a.seg_bytes : A);
+            B = B < A ? A : (B > a.seg_bytes ? a.seg_bytes : B);
+            if (B > A && B - A + 256 <= (int64_t)JOIN_STAGE_BYTES) {   // block-uniform
+                sct_block_stage_load(a.segs, A, B, stage);
+                __syncthreads();
+                const int dl = (start >= A && start + len <= B) ? len : 0;
+                sct_decode_row_from_block_stage<uint32_t>(a.segs, A, start, dl, stage, lo, hi, nonacgt);
+                decoded = true;
+            }
+        }
+    }
+    const bool mine = mykind && anyrow;      // this wave's rows are the join's
+    if (mine && !decoded) sct_decode_row<uint32_t>(a.segs, start, len, lo, hi, nonacgt);
+    if (lane == 0 && first < n) ja.wave_kind[first >> 6] = mine ? 1 : 0;
+    bool active = false;
+    if (mine) {
+        if (__ballot(nonacgt) != 0) {
+            if (nonacgt) {
+                for (int i = 0; i < len; i++)
+                    if (a.segs[start + i] >= 128 && sct_byte_is_read(a.segs + start, len, i, bl, E, a.prefix_len)) {
+                        atomicMin(reinterpret_cast<unsigned long long *>(a.ctr + CTR_BAD_BYTE), (unsigned long long)(start + i));
+                        break;
+                    }
+            }
+        }
+        active = fits;
+        const bool line = first + 64 <= a.n && (((uintptr_t)(a.min_e + first)) & 15) == 0 && (a.cnt8 == nullptr || (((uintptr_t)(a.cnt8 + first)) & 15) == 0);
+        if (inrange) {
+            // routing: as the filter's main launch does it (k_join_finish's store covers the wave's min_e / cnt8 lines)
+            if (!line && a.cnt8 && (!fits || (nonacgt && a.prefix_len > 0))) a.cnt8[r] = 0;
+            if (!fits) {
+                if (len_all > PLANE_MAX) {
+                    a.list_long[atomicAdd(&a.ctr[CTR_LONG], 1u)] = (int32_t)r;
+                    a.cnt[r] = CNT_DEFER;
+                } else {
+                    if (!line) a.min_e[r] = SCT_NO_HIT;
+                    a.cnt[r] = 0;
+                }
+            } else if (nonacgt && a.prefix_len > 0) {
+                a.list_dp[atomicAdd(&a.ctr[CTR_DP], 1u)] = (int32_t)r;
+                a.cnt[r] = CNT_DEFER;
+                active = false;
+            }
+        }
+    }
+    if (inrange) {   // (also for the waves k_filter's 64-bit launch owns: pass 1 and the finish must find zeros there)
+        ja.planes[r] = active ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+        ja.jlen[r] = active ? (uint8_t)len : (uint8_t)0;
+        ja.jcnt[r] = 0u;
+    }
+    if (!active) len = 0;
+    // T01 tuples: exact 10-mer at t, the 6 characters behind it within one edit (placements pruned as sct_placement_need prunes them:
+    // the last five of those characters must exist: t + 15 <= len)
+    const int pmax = wave_max_i(mine ? len : 0) - 15;
+    const int64_t prod = (int64_t)blockIdx.x;      // producer block index within this pass
+    for (int t = 0; t <= pmax; t++) {
+        if (len > 0 && t + 15 <= len) {
+            const SctFamily<SCT_F_T01> fam{};
+            const uint32_t key = sct_key_of<uint32_t>(fam, lo, hi, t, t + fam.GAP);
+            const uint32_t q = key >> 16;
+            const uint32_t pos = atomicAdd(&pcnt[q], 1u);
+            if (pos < (uint32_t)JOIN_CAP0)
+                ja.tup0[((size_t)prod * JOIN_P0 + q) * JOIN_CAP0 + pos] = join_tuple(r, key & 0xFFFFu, sct_join_ctx_t01(lo, hi, len, t));
+            else
+                a.ctr[CTR_JOIN_OVERFLOW] = 1u;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < JOIN_P0) ja.cnt0[(size_t)prod * JOIN_P0 + threadIdx.x] = pcnt[threadIdx.x] < (uint32_t)JOIN_CAP0 ? pcnt[threadIdx.x] : (uint32_t)JOIN_CAP0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pass 1: rows without a distance-0 hit -> T12 and T02 tuples (partitions 0..31: T12, 32..63: T02)
+// ------------------------------------------------------------------------------------------------------------
+template <typename OffT>
+__global__ void __launch_bounds__(256) k_join_part1(const JoinArgs<OffT> ja) {
+    const FilterArgs<OffT> &a = ja.fa;
+    constexpr int E = 1;
+    __shared__ uint32_t pcnt[JOIN_P1];
+    const int64_t r = ja.row0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < JOIN_P1) pcnt[threadIdx.x] = 0;
+    __syncthreads();
+    int len = 0;
+    uint32_t lo = 0, hi = 0;
+    if (r < ja.row1) {
+        len = (int)ja.jlen[r];
+        if (len > 0 && (ja.jcnt[r] >> 16) != 0u) len = 0;     // a barcode at distance 0 is known: only the minimum is reported
+        if (len > 0) {
+            const uint2 p = ja.planes[r];
+            lo = p.x;
+            hi = p.y;
+        }
+    }
+    const int64_t prod = (int64_t)blockIdx.x;
+    const int maxlen = wave_max_i(len);
+    auto put = [&](uint32_t q, uint32_t keylow, uint32_t ctx) {
+        const uint32_t pos = atomicAdd(&pcnt[q], 1u);
+        if (pos < (uint32_t)JOIN_CAP1) ja.tup1[((size_t)prod * JOIN_P1 + q) * JOIN_CAP1 + pos] = join_tuple(r, keylow, ctx);
+        else a.ctr[CTR_JOIN_OVERFLOW] = 1u;
+    };
+    {   // T12: exact 11-mer (pattern characters 5..15) at t, the 5 characters in front of it within one edit
+        const SctFamily<SCT_F_T12> fam{};
+        for (int t = 0; t + fam.LA + fam.LB <= maxlen; t++) {
+            const int t2 = t + fam.GAP;
+            if (len > 0 && sct_placement_need(fam, E, t, t2) <= len) {
+                const uint32_t key = sct_key_of<uint32_t>(fam, lo, hi, t, t2);
+                put(key >> 17, key & 0x1FFFFu, sct_join_ctx_t12(lo, hi, t));
+            }
+        }
+    }
+    {   // T02: exact 5-mer at t and exact 6-mer at t2 = t + 10 + d, the 5 + d characters between them within one edit
+        const SctFamily<SCT_F_T02> fam{};
+#pragma unroll
+        for (int d = -1; d <= 1; d++) {
+            for (int t = 0; t + fam.GAP + d + fam.LB <= maxlen; t++) {
+                const int t2 = t + fam.GAP + d;
+                if (len > 0 && sct_placement_need(fam, E, t, t2) <= len) {
+                    const uint32_t key = sct_key_of<uint32_t>(fam, lo, hi, t, t2);
+                    put(32u + (key >> 17), key & 0x1FFFFu, sct_join_ctx_t02(lo, hi, t, t2));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < JOIN_P1) ja.cnt1[(size_t)prod * JOIN_P1 + threadIdx.x] = pcnt[threadIdx.x] < (uint32_t)JOIN_CAP1 ? pcnt[threadIdx.x] : (uint32_t)JOIN_CAP1;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// probe: one workgroup = one partition x JOIN_GROUP producer blocks; a wave takes a producer block at a time, a lane a tuple
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void join_hit(uint32_t *__restrict__ jcnt, uint32_t *__restrict__ jslots, uint32_t row, uint32_t d, uint32_t loc) {
+    const uint32_t v = atomicAdd(&jcnt[row], 1u + (d == 0u ? 0x10000u : 0u));
+    const uint32_t k = v & 0xFFFFu;
+    if (k < (uint32_t)JOIN_HITS) jslots[(size_t)row * JOIN_HITS + k] = (d << 30) | loc;
+}
+
+// FAM: SCT_F_T01 (partitions of tup0 / cnt0, P = JOIN_P0, q0 = 0), SCT_F_T12 (tup1, P = JOIN_P1, q0 = 0), SCT_F_T02 (tup1, q0 = 32)
+template <int FAM, typename OffT>
+__global__ void __launch_bounds__(256) k_join_probe(const JoinArgs<OffT> ja, int n_prod, int groups) {
+    const FilterArgs<OffT> &a = ja.fa;
+    constexpr bool T01 = FAM == SCT_F_T01;
+    constexpr int P = T01 ? JOIN_P0 : JOIN_P1, CAP = T01 ? JOIN_CAP0 : JOIN_CAP1, Q0 = FAM == SCT_F_T02 ? 32 : 0;
+    constexpr int KSHIFT = T01 ? 16 : 17, CAPE = T01 ? 16 : 8, NREST = T01 ? 6 : 5;
+    const SctFamily<FAM> fam{};
+    const unsigned long long *tup = T01 ? ja.tup0 : ja.tup1;
+    const uint32_t *cnt = T01 ? ja.cnt0 : ja.cnt1;
+    const int lane = threadIdx.x & 63, widx = threadIdx.x >> 6;
+    const int ql = (int)(blockIdx.x / (unsigned)groups), g = (int)(blockIdx.x % (unsigned)groups);
+    const int q = Q0 + ql;
+    const uint32_t *off = a.tab_off + a.ft.off_base[FAM];
+    const uint4 *fb = reinterpret_cast<const uint4 *>(a.tab_fb + a.ft.fb_base[FAM - SCT_F_T01]);
+    for (int b = g * JOIN_GROUP + widx; b < (g + 1) * JOIN_GROUP && b < n_prod; b += 4) {
+        const uint32_t c = cnt[(size_t)b * P + q];
+        const unsigned long long *src = tup + ((size_t)b * P + q) * CAP;
+        for (uint32_t i0 = 0; i0 < c; i0 += 64) {   // wave-uniform
+            const bool have = i0 + (uint32_t)lane < c;
+            const unsigned long long tp = have ? __builtin_nontemporal_load(src + i0 + lane) : 0ull;
+            const uint32_t row = (uint32_t)tp & 0x3FFFFFFFu;
+            const uint32_t key = ((uint32_t)ql << KSHIFT) | ((uint32_t)(tp >> 30) & ((1u << KSHIFT) - 1u));
+            const uint32_t ctx = (uint32_t)(tp >> 47);
+            uint32_t w[CAPE / 2];
+            if (have) {
+#pragma unroll
+                for (int k = 0; k < CAPE / 8; k++) {
+                    const uint4 v = fb[(size_t)key * (CAPE / 8) + k];
+                    w[4 * k + 0] = v.x;
+                    w[4 * k + 1] = v.y;
+                    w[4 * k + 2] = v.z;
+                    w[4 * k + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CAPE / 2; k++) w[k] = 0u;
+            }
+            const bool over = have && (w[0] & SCT_FB_OVERFLOW) != 0u;
+            // context -> (characters that exist, fixed end)
+            const int m = FAM == SCT_F_T02 ? NREST + (int)(ctx >> 14) - 1 : (int)(ctx >> 14);
+#pragma unroll
+            for (int j = 0; j < CAPE; j++) {
+                const uint32_t e = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                const bool valid = have && !over && (e & SCT_FB_VALID) != 0u;
+                if (__ballot(valid) == 0) break;     // a bucket is filled from its first place on
+                if (valid) {
+                    const uint32_t rest = FAM == SCT_F_T12 ? sct_join_rest_t12(e & 0x03FFu) : (e & 0x0FFFu);
+                    const uint32_t d = sct_join_distance(rest, ctx, NREST, m, FAM == SCT_F_T02);
+                    if (d <= 1u) join_hit(ja.jcnt, ja.jslots, row, d, LOC_INLINE | ((a.ft.off_base[FAM] + key) << 5) | (uint32_t)j);
+                }
+            }
+            if (__ballot(over) != 0 && over) {
+                // more entries than a fixed bucket holds (0.03 % of the keys at 3.6 M barcodes): through the offsets, entry by entry
+                const uint32_t s = off[key], en = off[key + 1];
+                for (uint32_t gk = s; gk < en; gk++) {
+                    const uint32_t r0 = sct_rest_of(fam, a.tab_code[gk]);
+                    const uint32_t rest = FAM == SCT_F_T12 ? sct_join_rest_t12(r0 & 0x03FFu) : (r0 & 0x0FFFu);
+                    const uint32_t d = sct_join_distance(rest, ctx, NREST, m, FAM == SCT_F_T02);
+                    if (d <= 1u) join_hit(ja.jcnt, ja.jslots, row, d, gk);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// finish: a row's list -> minimum + distinct pattern ids, stored as the filter's main launch stores its rows
+// ------------------------------------------------------------------------------------------------------------
+template <typename OffT>
+__global__ void __launch_bounds__(256) k_join_finish(const JoinArgs<OffT> ja) {
+    const FilterArgs<OffT> &a = ja.fa;
+    constexpr int E = 1;
+    const int lane = threadIdx.x & 63;
+    const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (first >= a.n) return;
+    if (ja.wave_kind[first >> 6] != 1) return;        // k_filter's 64-bit launch owns this wave
+    const int64_t r = first + lane;
+    const bool inrange = r < a.n;
+    const bool active = inrange && ja.jlen[r] > 0;
+    const uint32_t v = active ? ja.jcnt[r] : 0u;
+    const uint32_t handed = v & 0xFFFFu;
+    const uint32_t c = handed < (uint32_t)JOIN_HITS ? handed : (uint32_t)JOIN_HITS;
+    uint32_t ent[JOIN_HITS];
+    {
+        const uint4 *p = reinterpret_cast<const uint4 *>(ja.jslots + (size_t)(inrange ? r : 0) * JOIN_HITS);
+        const uint4 x = active ? p[0] : make_uint4(0, 0, 0, 0), y = active ? p[1] : make_uint4(0, 0, 0, 0);
+        ent[0] = x.x; ent[1] = x.y; ent[2] = x.z; ent[3] = x.w;
+        ent[4] = y.x; ent[5] = y.y; ent[6] = y.z; ent[7] = y.w;
+    }
+    // the minimum first: only entries at the minimum cost a table read
+    uint32_t best = E + 1;
+#pragma unroll
+    for (int i = 0; i < JOIN_HITS; i++)
+        if ((uint32_t)i < c) best = min(best, ent[i] >> 30);
+    LaneResult<E, K_SLOTS> res;
+    res.init();
+#pragma unroll
+    for (int i = 0; i < JOIN_HITS; i++) {
+        if ((uint32_t)i < c && (ent[i] >> 30) == best) {
+            const uint32_t loc = ent[i] & LOC_MASK;
+            uint32_t idx = loc;
+            if (loc & LOC_INLINE) {
+                const uint32_t l = loc & (LOC_INLINE - 1u);
+                idx = a.tab_off[l >> 5] + (l & 31u);
+            }
+            res.add((int)best, a.ft.pid16 ? (uint32_t)a.tab_ent16[idx] : a.tab_ent[idx]);
+        }
+    }
+    const bool line = first + 64 <= a.n && (((uintptr_t)(a.min_e + first)) & 15) == 0 && (a.cnt8 == nullptr || (((uintptr_t)(a.cnt8 + first)) & 15) == 0);
+    // more hits than the list holds: entries at the minimum may be missing -> the retry launch does the row from scratch
+    res.store(active, r, handed > (uint32_t)JOIN_HITS, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.wave_base, first, a.list_defer, a.defer_count,
+              a.slot_cursor);
+}

@@ -637,6 +637,91 @@ SCT_HD uint32_t wm_anchored_pair(const Fam &fam, EmX &&emx, EmY &&emy, WV vax, W
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Thirds families at max_err = 1 without the automaton (the partitioned join, k_join.hip.h).  A candidate found under family F at
+// placement (t, t2) has its two pieces exactly in the text; what is left to compare is ONE short piece of the pattern — its
+// "rest" (sct_rest_of: T01 the 6 characters behind the 10-mer, T12 the 5 in front of the 11-mer, T02 the 5 between the two
+// pieces) — with the text beside the anchors, within one edit:
+//   T01  rest vs the text behind the seed, free end          context = the next <= 7 characters
+//   T12  rest vs the text in front of the seed, free start   context = the <= 6 characters before t, REVERSED (so it is a free END)
+//   T02  rest vs the text between the pieces, both ends fixed context = the 5 + d characters between them, d = t2 - t - 10
+// Characters are 2-bit codes at bits 2j, 2j+1 (tab_code / sct_rest_of order); the T12 context and rest are bit-reversed as a
+// whole (v_bfrev: character order AND the two bits of a character swap — on both sides, so equality of characters is kept).
+// Within one edit "distance" is: equal -> 0; one substitution, one deleted pattern character or one inserted text character -> 1;
+// anything else -> 2 (= E + 1).  With X0 = mismatches rest[j] : ctx[j], X1 = rest[j+1] : ctx[j], X2 = rest[j] : ctx[j+1] (bit 2j
+// each) and a = the first mismatch of X0: a deletion exists iff X1 is clear from min(a, n-1) on, an insertion iff X2 is clear from
+// min(a, n) on.  Context characters that do not exist (text ends / starts) count as mismatches.
+// The same value as wm_anchored<1, F> for every placement whose key matches (tests/host_core_check.cpp).
+// ---------------------------------------------------------------------------------------------------
+SCT_HD uint32_t sct_spread8(uint32_t v) {   // bit i -> bit 2i, 8 bits
+    v = (v | (v << 4)) & 0x0F0Fu;
+    v = (v | (v << 2)) & 0x3333u;
+    return (v | (v << 1)) & 0x5555u;
+}
+SCT_HD uint32_t sct_rev32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+// The context word of a tuple: bits 0..13 the context characters, bits 14..16 how many of them exist (T01, T12) or d + 1 (T02).
+// lo / hi = the text's bit-planes (at most 31 characters), len its length.
+SCT_HD uint32_t sct_join_ctx_t01(uint32_t lo, uint32_t hi, int len, int t) {
+    const int at = t + 10, avail = len - at < 7 ? (len - at < 0 ? 0 : len - at) : 7;
+    return sct_spread8((lo >> at) & 0x7Fu) | (sct_spread8((hi >> at) & 0x7Fu) << 1) | ((uint32_t)avail << 14);
+}
+SCT_HD uint32_t sct_join_ctx_t12(uint32_t lo, uint32_t hi, int t) {
+    // character k of the context = text[t - 1 - k], its two bits swapped (hi plane at bit 2k)
+    const int avail = t < 6 ? t : 6;
+    const uint32_t rl = t > 0 ? sct_rev32(lo << (32 - t)) : 0u, rh = t > 0 ? sct_rev32(hi << (32 - t)) : 0u;
+    return (sct_spread8(rl & 0x3Fu) << 1) | sct_spread8(rh & 0x3Fu) | ((uint32_t)avail << 14);
+}
+SCT_HD uint32_t sct_join_ctx_t02(uint32_t lo, uint32_t hi, int t, int t2) {
+    const int at = t + 5, d = t2 - t - 10;
+    return sct_spread8((lo >> at) & 0x3Fu) | (sct_spread8((hi >> at) & 0x3Fu) << 1) | ((uint32_t)(d + 1) << 14);
+}
+// rest of a T12 entry as the compare wants it: reversed like its context (5 characters, 10 bits)
+SCT_HD uint32_t sct_join_rest_t12(uint32_t rest10) { return sct_rev32(rest10) >> 22; }
+
+// distance (0, 1, or 2 = more) of an n-character rest against a context; m = context characters that exist;
+// fixed_end: the alignment must consume exactly the m characters (T02), else it may end anywhere (T01, reversed T12)
+SCT_HD uint32_t sct_join_distance(uint32_t rest, uint32_t ctx, int n, int m, bool fixed_end) {
+    const uint32_t C = ctx & 0x3FFFu;
+    const uint32_t exist = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);             // context characters 0 .. m-1
+    const uint32_t maskn = (1u << (2 * n)) - 1u, maskn1 = (1u << (2 * (n - 1))) - 1u;
+    const uint32_t ev = 0x55555555u;
+    uint32_t x = rest ^ C;
+    const uint32_t X0 = (((x | (x >> 1)) & ev) | (~exist & ev)) & maskn;                  // rest[j] : ctx[j]
+    x = (rest >> 2) ^ C;
+    const uint32_t X1 = (((x | (x >> 1)) & ev) | (~exist & ev)) & maskn1;                 // rest[j+1] : ctx[j], j < n - 1
+    x = rest ^ (C >> 2);
+    const uint32_t X2 = (((x | (x >> 1)) & ev) | (~(exist >> 2) & ev)) & maskn;          // rest[j] : ctx[j+1]
+    // a = first mismatch of X0 (in bits: 2 a), n if none
+    const uint32_t low = X0 & (0u - X0);                                                 // lowest set bit, 0 if none
+    const uint32_t below = low ? low - 1u : 0xFFFFFFFFu;                                  // bits below the first mismatch
+    const bool eq = X0 == 0u;
+    const bool sub1 = !eq && (X0 & (X0 - 1u)) == 0u;
+    // deletion of a pattern character: X1 clear from min(a, n - 1) on  <=>  no X1 bit at or above position min(a, n-1)
+    const bool del_ok = (X1 & ~below) == 0u;
+    // insertion of a text character: X2 clear from a on
+    const bool ins_ok = (X2 & ~below) == 0u;
+    if (fixed_end) {
+        if (m == n) return eq ? 0u : (sub1 ? 1u : 2u);
+        if (m == n + 1) return ins_ok ? 1u : 2u;
+        return (m == n - 1 && del_ok) ? 1u : 2u;
+    }
+    if (m >= n && eq) return 0u;
+    if (m >= n && sub1) return 1u;
+    if (m >= n - 1 && del_ok) return 1u;
+    if (m >= n + 1 && ins_ok) return 1u;
+    return 2u;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Bucket slots of the quarter families (k_filter.hip.h): one 8-byte word per seed key, read as two 32-bit words
 // (a = bits 0..31, b = bits 32..63), that answers most lookups by itself.
 //   bit 15 clear  inline bucket: bits 0..1 = n <= 3 entries, bits 2..14 = where its entries start inside their group of 64 keys

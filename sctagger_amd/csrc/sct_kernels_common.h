@@ -34,6 +34,7 @@ enum {
     CTR_BAD_ROW = 8,    // (64-bit, words 8-9)  smallest row whose index entry is invalid, ~0 = none
     CTR_BAD_BYTE = 10,  // (64-bit, words 10-11) smallest offset of a segment byte >= 128, ~0 = none
     CTR_CNT_OVERFLOW = 12,  // a row's hit count did not fit the requested count format
+    CTR_JOIN_OVERFLOW = 13, // partitioned join (k_join.hip.h): a producer block had more tuples for one partition than its region holds
     CTR_TOTAL = 14,     // (64-bit, words 14-15) total number of hits of the batch
     CTR_WORDS = 16
 };

@@ -79,6 +79,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_decode.hip.h"
 #include "k_filter.hip.h"
 #include "filter_launch.h"
+#include "k_join.hip.h"
 #include "k_scan.hip.h"
 #include "k_offsets.hip.h"
 #include "k_whitelist.hip.h"
@@ -128,6 +129,7 @@ struct TimedSpan {
 struct BatchParams {
     int max_err = 0, threads = 1, prefix_len = 0;
     bool filter_ok = false, use_slots = false, use_thirds = false, use_wide = false, rt_families = false;
+    bool use_join = false;   // thirds scheme at max_err = 1: the 32-bit main launch is the partitioned join (k_join.hip.h)
     int count_format = SCT_CNT_OFFS64;  // SCT_CNT_*: which compact form of the counts the offsets kernel also writes
 };
 
@@ -146,6 +148,7 @@ struct Lane {
     // work / results
     DevBuf min_e, cnt, route, slots, slots_retry, list_retry, slot_off, wave_base, list_long, list_scan, list_dp, counters, hit_offs, sums, hits,
         part_best, part_cnt, cnt_out;
+    DevBuf j_planes, j_len, j_wave, j_cnt, j_slots, j_tup0, j_cnt0, j_tup1, j_cnt1;   // the partitioned join (k_join.hip.h)
     uint64_t slots_cap = 0, retry_cap = 0;
     // where the kernels write the results the caller sees: the lane's own buffers (copied out afterwards) or, for a stream
     // call whose output arrays are page-locked, those arrays themselves through their device mapping
@@ -176,7 +179,8 @@ struct Lane {
     uint32_t *ctr() const { return counters.as<uint32_t>(); }
     void release() {
         DevBuf *bufs[] = {&segs, &offs64, &offs32, &index_in, &min_e, &cnt, &route, &slots, &slots_retry, &list_retry, &slot_off, &wave_base, &list_long,
-                          &list_scan, &list_dp, &counters, &hit_offs, &sums, &hits, &part_best, &part_cnt, &cnt_out};
+                          &list_scan, &list_dp, &counters, &hit_offs, &sums, &hits, &part_best, &part_cnt, &cnt_out,
+                          &j_planes, &j_len, &j_wave, &j_cnt, &j_slots, &j_tup0, &j_cnt0, &j_tup1, &j_cnt1};
         for (DevBuf *b : bufs) b->release();
         for (hipEvent_t e : pool) (void)hipEventDestroy(e);
         pool.clear();
@@ -215,6 +219,7 @@ struct sct_ctx {
     int thirds_mode = -1;  // -1 = thirds tables by the size of the set, 1 = built whatever the size (next sct_set_barcodes)
     int fb_mode = -1;      // thirds families: -1 / 1 = lookups read the fixed buckets, 0 = offsets + codes
     int wide_mode = -1;    // -1 = by the size of the barcode set, 0 = never, 1 = build and use the wide families whatever the size
+    int join_mode = -1;    // thirds scheme at max_err = 1: -1 / 1 = the partitioned join does the 32-bit rows, 0 = k_filter does
     int slots_mode = -1;       // -1 = by the share of long buckets, 0 = never, 1 = whenever the tables hold them
     double long_share = 1.0;   // share of the seed keys whose bucket does not fit a slot (sct_set_barcodes)
     bool zero_copy = true;     // stream API: kernels read page-locked caller buffers in place instead of uploading them
@@ -383,6 +388,7 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "thirds")) c->thirds_mode = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "fixed_buckets")) c->fb_mode = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "wide")) c->wide_mode = value < 0 ? -1 : (value != 0);  // takes effect at the next sct_set_barcodes
+    else if (!strcmp(key, "join")) c->join_mode = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "slots")) c->slots_mode = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "chunk_rows")) {
         if (value < 0 || value > 0x7FFFFFF0) return fail(SCT_E_ARG, "chunk_rows must be in 0 .. 2^31-16");
@@ -539,6 +545,8 @@ static int batch_params(sct_ctx *c, int32_t max_err, int32_t threads, int count_
     bp.use_slots = c->bl == 16 && !bp.use_thirds && !bp.use_wide &&
                    (c->slots_mode < 0 ? c->long_share <= (max_err <= 1 ? SLOTS_MAX_LONG_SHARE_E1 : SLOTS_MAX_LONG_SHARE_E2) && c->max_bucket <= SLOTS_MAX_BUCKET
                                        : c->slots_mode == 1);
+    // the join reads the fixed buckets and packs a row number into 30 bits of a tuple
+    bp.use_join = bp.use_thirds && max_err == 1 && c->join_mode != 0 && c->have_fb && c->fb_mode != 0;
     bp.count_format = count_format;
     c->last_scheme = !bp.filter_ok ? SCT_SCHEME_NONE : bp.use_thirds ? SCT_SCHEME_THIRDS : bp.use_wide ? SCT_SCHEME_WIDE
                      : (bp.use_slots && !bp.rt_families) ? SCT_SCHEME_QUARTER_SLOTS : SCT_SCHEME_QUARTER_TABLES;
@@ -628,7 +636,32 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.list_defer = l.list_retry.as<int32_t>();
         fa.defer_count = ctr + CTR_RETRY;
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR);
-        launch_filter(bp.max_err, v, fa, blocks_for(n, 256), capped((n + 63) / 64), st);
+        if (bp.use_join && n < ((int64_t)1 << 30)) {
+            // the 32-bit rows through the partitioned join, pass after pass of JOIN_SUB_ROWS rows (the tuple regions are sized for
+            // one pass), then its finish over all rows; k_filter's 64-bit instantiation takes the waves of 32 .. 63-character rows
+            JoinArgs<OffT> ja{};
+            ja.fa = fa;
+            ja.planes = l.j_planes.as<uint2>();
+            ja.jlen = l.j_len.as<uint8_t>();
+            ja.wave_kind = l.j_wave.as<uint8_t>();
+            ja.jcnt = l.j_cnt.as<uint32_t>();
+            ja.jslots = l.j_slots.as<uint32_t>();
+            ja.tup0 = l.j_tup0.as<unsigned long long>();
+            ja.cnt0 = l.j_cnt0.as<uint32_t>();
+            ja.tup1 = l.j_tup1.as<unsigned long long>();
+            ja.cnt1 = l.j_cnt1.as<uint32_t>();
+            for (int64_t r0 = 0; r0 < n; r0 += JOIN_SUB_ROWS) {
+                ja.row0 = r0;
+                ja.row1 = r0 + JOIN_SUB_ROWS < n ? r0 + JOIN_SUB_ROWS : n;
+                sct_launch_join_pass(ja, st);
+            }
+            sct_launch_join_finish(ja, st);
+            SctFilterVariant v64 = v;
+            v64.only64 = true;
+            launch_filter(bp.max_err, v64, fa, 1, capped((n + 63) / 64), st);
+        } else {
+            launch_filter(bp.max_err, v, fa, blocks_for(n, 256), capped((n + 63) / 64), st);
+        }
     }
     {
         // rows with more ties / verified matches than the main launch keeps: once more with larger lists.  How many
@@ -852,6 +885,16 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
                     (unsigned long long)(bad_row + (uint64_t)row_base));
     if (bad_byte != ~0ull) return fail(SCT_E_ARG, "segment bytes contain a value >= 128 (row block starting at row %lld, byte offset %llu in it)",
                                        (long long)row_base, (unsigned long long)bad_byte);
+    if (h[CTR_JOIN_OVERFLOW] && l.bp.use_join) {
+        // a producer block of the partitioned join had more tuples for one partition than its region holds (rows far longer than
+        // the usual 22 characters, or keys that crowd into one partition): the whole batch once more through the filter kernel
+        l.bp.use_join = false;
+        if (int rc = reset_counters(l)) return rc;
+        if (int rc = queue_batch(c, l)) return rc;
+        HIPCHK(hipStreamSynchronize(l.stream));
+        HIPCHK(hipGetLastError());
+        return finish_batch(c, l, row_base, slow);
+    }
     const int64_t n_retried = h[CTR_RETRY];
     if (h[CTR_LONG] || h[CTR_SCAN] || h[CTR_DP]) {
         if (int rc = slow_path(c, l)) return rc;

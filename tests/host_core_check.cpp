@@ -122,6 +122,46 @@ static int anchored_thirds(const std::vector<int> &p, const std::vector<int> &t)
     return b;
 }
 
+
+// The partitioned join's compare (sct_join_distance on a tuple's context, sct_core.h) against the anchored automaton, for every
+// placement of family F whose key matches: the two must give the same distance (0, 1, or 2 = "more than one edit").
+template <int F>
+static long join_vs_automaton(const std::vector<int> &p, const std::vector<int> &t, bool *ok) {
+    uint64_t plo, phi, tlo, thi;
+    planes(p, plo, phi);
+    planes(t, tlo, thi);
+    const int L = (int)t.size();
+    const uint32_t pkey = sct_pattern_key(F, (uint32_t)plo, (uint32_t)phi);
+    const uint32_t va = sct_valid_mask<uint32_t>(L), ve = va & ~1u, l1 = (uint32_t)tlo << 1, h1 = (uint32_t)thi << 1;
+    EmArray<uint32_t> em;
+    em.m[0] = ~l1 & ~h1 & ve; em.m[1] = l1 & ~h1 & ve; em.m[2] = ~l1 & h1 & ve; em.m[3] = l1 & h1 & ve;
+    uint32_t code = 0;
+    for (int j = 0; j < 16; j++) code |= (uint32_t)p[j] << (2 * j);
+    const uint32_t rest = sct_rest_of(SctFamily<F>{}, code);
+    long n_checked = 0;
+    sct_for_each_placement<F>(L, [&](int a, int b) {
+        if (sct_placement_key<F, uint32_t>((uint32_t)tlo, (uint32_t)thi, a, b) != pkey) return;
+        const int want = std::min(wm_anchored<1, F, uint32_t>(em, va, code, a, b), 2);
+        uint32_t got;
+        if (F == SCT_F_T01) {
+            const uint32_t c = sct_join_ctx_t01((uint32_t)tlo, (uint32_t)thi, L, a);
+            got = sct_join_distance(rest, c, 6, (int)(c >> 14), false);
+        } else if (F == SCT_F_T12) {
+            const uint32_t c = sct_join_ctx_t12((uint32_t)tlo, (uint32_t)thi, a);
+            got = sct_join_distance(sct_join_rest_t12(rest), c, 5, (int)(c >> 14), false);
+        } else {
+            const uint32_t c = sct_join_ctx_t02((uint32_t)tlo, (uint32_t)thi, a, b);
+            got = sct_join_distance(rest, c, 5, 5 + (int)(c >> 14) - 1, true);
+        }
+        if ((int)got != want) {
+            printf("FAIL join compare family %d placement (%d, %d) L=%d: automaton %d, join %u\n", F, a, b, L, want, got);
+            *ok = false;
+        }
+        n_checked++;
+    });
+    return n_checked;
+}
+
 // the wide scheme (sixteen 20-bit families, max_err = 2): minimum anchored distance over the placements of family WF whose key
 // equals the pattern's; `lookups` counts the placements
 template <int WF, typename W>
@@ -902,6 +942,35 @@ int main(int argc, char **argv) {
             level = next;
         }
         checked += n_texts;
+    }
+    // 9. the partitioned join's compare == the anchored automaton at max_err = 1, thirds families: planted patterns with 0..3 edits
+    //    and texts over small alphabets (so that keys match by chance, at placements the planted copy does not explain)
+    {
+        long n_join = 0;
+        bool ok = true;
+        for (int it = 0; it < 400000 / scale && ok; it++) {
+            const int alpha = 1 + rnd(4);
+            std::vector<int> p(16), t;
+            for (auto &x : p) x = rnd(alpha);
+            const int pre = rnd(9), post = rnd(9);
+            for (int i = 0; i < pre; i++) t.push_back(rnd(alpha));
+            std::vector<int> core = p;
+            for (int e = rnd(4); e > 0 && !core.empty(); e--) {
+                const int k = rnd(3), at = rnd((int)core.size() + (k == 1 ? 1 : 0));
+                if (k == 0 && at < (int)core.size()) core[at] = rnd(alpha);
+                else if (k == 1) core.insert(core.begin() + at, rnd(alpha));
+                else if (at < (int)core.size()) core.erase(core.begin() + at);
+            }
+            t.insert(t.end(), core.begin(), core.end());
+            for (int i = 0; i < post; i++) t.push_back(rnd(alpha));
+            if (t.size() > 31) t.resize(31);
+            n_join += join_vs_automaton<SCT_F_T01>(p, t, &ok);
+            n_join += join_vs_automaton<SCT_F_T12>(p, t, &ok);
+            n_join += join_vs_automaton<SCT_F_T02>(p, t, &ok);
+        }
+        if (!ok) return 1;
+        if (n_join < 100000) { printf("FAIL join compare: only %ld placements with a matching key\n", n_join); return 1; }
+        checked += n_join;
     }
     printf("OK %ld cases\n", checked);
     return 0;
