@@ -574,6 +574,15 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
             return g_code;
     }
     if (l.hits.ensure(4 * (size_t)(l.slots_cap + l.retry_cap + 1))) return g_code;
+    if (bp.use_join && n < ((int64_t)1 << 30)) {
+        // per row: planes 8 + length 1 + hit count 4 + JOIN_HITS entries 32 bytes; per pass of JOIN_SUB_ROWS rows: the tuple regions
+        const int64_t sub = n < JOIN_SUB_ROWS ? n : JOIN_SUB_ROWS;
+        const size_t prod = (size_t)((sub + 255) / 256) + 1;
+        if (l.j_planes.ensure(8 * n1) || l.j_len.ensure(n1) || l.j_wave.ensure(n1 / 64 + 2) || l.j_cnt.ensure(4 * n1) ||
+            l.j_slots.ensure(4 * (size_t)JOIN_HITS * n1 + 64) || l.j_tup0.ensure(8 * prod * JOIN_P0 * JOIN_CAP0) || l.j_cnt0.ensure(4 * prod * JOIN_P0) ||
+            l.j_tup1.ensure(8 * prod * JOIN_P1 * JOIN_CAP1) || l.j_cnt1.ensure(4 * prod * JOIN_P1))
+            return g_code;
+    }
     l.min_e_ptr = l.min_e.as<uint8_t>();
     l.cnt8_ptr = bp.count_format == SCT_CNT_U8 ? l.cnt_out.as<uint8_t>() : nullptr;
     l.cnt32_ptr = bp.count_format == SCT_CNT_U32 ? l.cnt_out.as<uint32_t>() : nullptr;
@@ -636,7 +645,9 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.list_defer = l.list_retry.as<int32_t>();
         fa.defer_count = ctr + CTR_RETRY;
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR);
-        if (bp.use_join && n < ((int64_t)1 << 30)) {
+        const bool join_ready = l.j_planes.p && l.j_len.p && l.j_wave.p && l.j_cnt.p && l.j_slots.p && l.j_tup0.p && l.j_cnt0.p && l.j_tup1.p && l.j_cnt1.p &&
+                                l.j_planes.cap >= 8 * (size_t)n && fa.tab_fb != nullptr;
+        if (bp.use_join && n < ((int64_t)1 << 30) && join_ready) {
             // the 32-bit rows through the partitioned join, pass after pass of JOIN_SUB_ROWS rows (the tuple regions are sized for
             // one pass), then its finish over all rows; k_filter's 64-bit instantiation takes the waves of 32 .. 63-character rows
             JoinArgs<OffT> ja{};
