@@ -200,7 +200,9 @@ int sct_last_timing_ex(sct_ctx *ctx, const char **names, float *ms, int32_t *lau
 /* Counters of the last sct_run / sct_match_stream / sct_match: [0] segments on the seed-filter path, [1] segments on the exhaustive
  * path, [2] segments on the restricted-start (non-ACGT, k>0) path, [3] total hits, [4] segments the filter path
  * retried with larger lists (more than 6 or 8 verified matches, by the seed tables in use), [5] the seed scheme the filter path
- * used (SCT_SCHEME_*). Fills up to cap entries; returns the number of counters there are (6), or <0. */
+ * used (SCT_SCHEME_*), [6] bits 0..31: batches whose 32-bit rows the partitioned join did (thirds scheme at max_err = 1), bits
+ * 32..39: batches the join handed back to the filter kernel (a tuple region overflowed). Fills up to cap entries; returns the
+ * number of counters there are (7), or <0. */
 enum {
     SCT_SCHEME_NONE = 0,            /* no seed filter: every row went to the exhaustive scan / restricted-start DP */
     SCT_SCHEME_QUARTER_SLOTS = 1,   /* six 16-bit quarter-pair families answered from 8-byte bucket slots (small barcode sets) */

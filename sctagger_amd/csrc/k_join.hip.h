@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) k_join_part0(const JoinArgs<OffT> ja) {
             if (pos < (uint32_t)JOIN_CAP0)
                 ja.tup0[((size_t)prod * JOIN_P0 + q) * JOIN_CAP0 + pos] = join_tuple(r, key & 0xFFFFu, sct_join_ctx_t01(lo, hi, len, t));
             else
-                a.ctr[CTR_JOIN_OVERFLOW] = 1u;
+                atomicOr(&a.ctr[CTR_JOIN_OVERFLOW], 1u);
         }
     }
     __syncthreads();
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_join_part1(const JoinArgs<OffT> ja) {
     auto put = [&](uint32_t q, uint32_t keylow, uint32_t ctx) {
         const uint32_t pos = atomicAdd(&pcnt[q], 1u);
         if (pos < (uint32_t)JOIN_CAP1) ja.tup1[((size_t)prod * JOIN_P1 + q) * JOIN_CAP1 + pos] = join_tuple(r, keylow, ctx);
-        else a.ctr[CTR_JOIN_OVERFLOW] = 1u;
+        else atomicOr(&a.ctr[CTR_JOIN_OVERFLOW], q < 32u ? 2u : 4u);
     };
     {   // T12: exact 11-mer (pattern characters 5..15) at t, the 5 characters in front of it within one edit
         const SctFamily<SCT_F_T12> fam{};

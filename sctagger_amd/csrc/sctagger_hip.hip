@@ -202,6 +202,7 @@ struct sct_ctx {
     bool have_bc = false, have_tables = false, have_thirds = false, have_wide = false, have_fb = false, have_wfb = false;
     uint32_t max_bucket = 0;  // longest bucket of the quarter families (SLOTS_MAX_BUCKET)
     int last_scheme = SCT_SCHEME_NONE;  // seed scheme of the last match call (sct_last_stats [5])
+    int64_t last_join = 0;   // sct_last_stats [6]: batches of the last call the partitioned join did | batches it handed back (overflow) << 32
     int tables_nfam = 0;   // families the seed tables hold (entry indices run up to tables_nfam * np)
     FamTables ft{};
     DevBuf pat, tab_off, tab_ent, tab_code, tab_slot, tab_grp, tab_ent16, tab_fb, tab_wfb;
@@ -548,6 +549,7 @@ static int batch_params(sct_ctx *c, int32_t max_err, int32_t threads, int count_
     // the join reads the fixed buckets and packs a row number into 30 bits of a tuple
     bp.use_join = bp.use_thirds && max_err == 1 && c->join_mode != 0 && c->have_fb && c->fb_mode != 0;
     bp.count_format = count_format;
+    c->last_join = 0;
     c->last_scheme = !bp.filter_ok ? SCT_SCHEME_NONE : bp.use_thirds ? SCT_SCHEME_THIRDS : bp.use_wide ? SCT_SCHEME_WIDE
                      : (bp.use_slots && !bp.rt_families) ? SCT_SCHEME_QUARTER_SLOTS : SCT_SCHEME_QUARTER_TABLES;
     return SCT_OK;
@@ -900,6 +902,7 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
         // a producer block of the partitioned join had more tuples for one partition than its region holds (rows far longer than
         // the usual 22 characters, or keys that crowd into one partition): the whole batch once more through the filter kernel
         l.bp.use_join = false;
+        c->last_join += ((int64_t)1 << 32) | ((int64_t)h[CTR_JOIN_OVERFLOW] << 40);
         if (int rc = reset_counters(l)) return rc;
         if (int rc = queue_batch(c, l)) return rc;
         HIPCHK(hipStreamSynchronize(l.stream));
@@ -929,6 +932,7 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
     }
     if (l.bp.count_format == SCT_CNT_U8 && h[CTR_CNT_OVERFLOW])
         return fail(SCT_E_RANGE, "a row has more than 255 hits: ask for SCT_CNT_U32 or SCT_CNT_OFFS64 counts");
+    if (l.bp.use_join) c->last_join += 1;
     l.n_hits = (int64_t)ctr64(h, CTR_TOTAL);
     l.stats[0] = l.n_seg - h[CTR_SCAN] - h[CTR_DP];
     l.stats[1] = h[CTR_SCAN];
@@ -1436,7 +1440,8 @@ extern "C" int sct_last_stats(sct_ctx *c, int64_t *out, int cap) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
     for (int i = 0; i < 5 && i < cap; i++) out[i] = c->stats[i];
     if (cap > 5) out[5] = c->last_scheme;
-    return 6;
+    if (cap > 6) out[6] = c->last_join;
+    return 7;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -51,7 +51,7 @@ def ragged(bc, n, seed, max_len=63, junk=True):
     return (np.concatenate(rows) if rows else np.empty(0, np.uint8)), offs
 
 
-def both_ways(m, segs, offs, e, t):
+def both_ways(m, segs, offs, e, t, expect_join=True):
     m.set_option("join", 1)
     a = m.match(segs, offs, e, t)
     sa = m.last_stats()
@@ -60,6 +60,8 @@ def both_ways(m, segs, offs, e, t):
     m.set_option("join", 1)
     assert sa["scheme"] == "thirds"
     util.assert_same(a, b, "join vs filter kernel (e=%d t=%d)" % (e, t))
+    if e == 1 and expect_join:      # the join really produced `a` (no silent fall-back to the filter kernel)
+        assert sa["join_batches"] >= 1 and sa["join_fallbacks"] == 0, sa
     return a, sa
 
 
@@ -110,7 +112,8 @@ def test_join_overflow_falls_back_to_the_filter_kernel(m):
     segs = np.frombuffer(b"A" * (31 * n), dtype=np.uint8).copy()
     segs[31 * 100 + 20] = ord("C")
     offs = np.arange(n + 1, dtype=np.int64) * 31
-    a, _ = both_ways(m, segs, offs, 1, 1)
+    a, st = both_ways(m, segs, offs, 1, 1, expect_join=False)
+    assert st["join_fallbacks"] == 1 and st["join_batches"] == 0, st
     want = trie_oracle.match(bc, segs[:offs[300]], offs[:301], 1, threads=1, workers=8)
     assert np.array_equal(a[0][:300], want[0]) and np.array_equal(a[2][:want[2].size], want[2])
     assert (a[0] == 0).all()
@@ -146,7 +149,8 @@ def test_join_several_passes(m):
     m.set_option("join", 1)
     m.run(1, 16)
     a = m.download()
-    assert m.last_stats()["scheme"] == "thirds"
+    st = m.last_stats()
+    assert st["scheme"] == "thirds" and st["join_batches"] == 1 and st["join_fallbacks"] == 0, st
     m.set_option("join", 0)
     m.run(1, 16)
     b = m.download()

@@ -11,4 +11,4 @@ b = m.match(segs, offs, 1, 1)
 print("filter ok", b[2].size, flush=True)
 m.set_option("join", 1)
 a = m.match(segs, offs, 1, 1)
-print("join ok", a[2].size, [np.array_equal(x, y) for x, y in zip(a, b)], flush=True)
+print("join ok", a[2].size, [np.array_equal(x, y) for x, y in zip(a, b)], m.last_stats(), flush=True)
