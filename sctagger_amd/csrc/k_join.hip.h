@@ -24,7 +24,7 @@
 static constexpr int JOIN_P0 = 16;           // T01: 2^20 keys x 32 B = 32 MB -> 16 slices of 2 MB (key >> 16)
 static constexpr int JOIN_P1 = 64;           // T12 and T02: 2^22 keys x 16 B = 64 MB each -> 32 slices each (key >> 17)
 static constexpr int JOIN_CAP0 = 512;        // tuples a producer block (256 rows) may leave in one partition: T01 (mean 128 at 22 characters)
-static constexpr int JOIN_CAP1 = 256;        // ... T12 / T02 (mean 77)
+static constexpr int JOIN_CAP1 = 384;        // ... T12 / T02 (mean 42 / 105; T02 tuples cluster — see join_part_t02 — worst seen 260 with every row active)
 static constexpr int JOIN_GROUP = 16;        // producer blocks per probe block
 static constexpr int64_t JOIN_SUB_ROWS = (int64_t)1 << 22;   // rows per pass (a multiple of 256): the tuple regions hold one pass
 static constexpr int JOIN_HITS = 8;          // entries of a row's list (more: the row goes to the retry launch)
@@ -42,6 +42,13 @@ struct JoinArgs {
     unsigned long long *tup0, *tup1;
     uint32_t *cnt0, *cnt1;        // tuples per (producer block, partition)
 };
+
+// T02's partition of a key.  The key's top five bits are the hi-plane bits of piece B's characters 1..5: the (up to three) placements
+// of a row that share a position of piece B (t2 = t + 10 + d for d = -1, 0, 1) would all fall into one partition, and a producer
+// block's partition fills would vary three times as much.  So the top bits are mixed with key bits 3..7 (piece A's side); bits 0..2
+// stay out of it: the 8 buckets of a 128-byte line belong to one partition, whose footprint in the table stays 2 MB.
+__device__ __forceinline__ uint32_t join_part_t02(uint32_t key) { return ((key >> 17) ^ (key >> 3)) & 31u; }
+__device__ __forceinline__ uint32_t join_key_t02(uint32_t q, uint32_t keylow) { return (((q ^ (keylow >> 3)) & 31u) << 17) | keylow; }
 
 // tuple: bits 0..29 row | bits 30..46 low key bits | bits 47..63 context (sct_join_ctx_*)
 __device__ __forceinline__ unsigned long long join_tuple(int64_t row, uint32_t keylow, uint32_t ctx) {
@@ -201,7 +208,7 @@ __global__ void __launch_bounds__(256) k_join_part1(const JoinArgs<OffT> ja) {
                 const int t2 = t + fam.GAP + d;
                 if (len > 0 && sct_placement_need(fam, E, t, t2) <= len) {
                     const uint32_t key = sct_key_of<uint32_t>(fam, lo, hi, t, t2);
-                    put(32u + (key >> 17), key & 0x1FFFFu, sct_join_ctx_t02(lo, hi, t, t2));
+                    put(32u + join_part_t02(key), key & 0x1FFFFu, sct_join_ctx_t02(lo, hi, t, t2));
                 }
             }
         }
@@ -241,7 +248,8 @@ __global__ void __launch_bounds__(256) k_join_probe(const JoinArgs<OffT> ja, int
             const bool have = i0 + (uint32_t)lane < c;
             const unsigned long long tp = have ? __builtin_nontemporal_load(src + i0 + lane) : 0ull;
             const uint32_t row = (uint32_t)tp & 0x3FFFFFFFu;
-            const uint32_t key = ((uint32_t)ql << KSHIFT) | ((uint32_t)(tp >> 30) & ((1u << KSHIFT) - 1u));
+            const uint32_t keylow = (uint32_t)(tp >> 30) & ((1u << KSHIFT) - 1u);
+            const uint32_t key = FAM == SCT_F_T02 ? join_key_t02((uint32_t)ql, keylow) : (((uint32_t)ql << KSHIFT) | keylow);
             const uint32_t ctx = (uint32_t)(tp >> 47);
             uint32_t w[CAPE / 2];
             if (have) {
