@@ -322,20 +322,27 @@ __global__ void __launch_bounds__(256) k_join_finish(const JoinArgs<OffT> ja) {
 #pragma unroll
     for (int i = 0; i < JOIN_HITS; i++)
         if ((uint32_t)i < c) best = min(best, ent[i] >> 30);
+    // locators -> pattern ids: all of a row's offset reads first, then all its id reads (two rounds of independent loads per lane
+    // instead of a chain of up to sixteen)
+    uint32_t idx[JOIN_HITS], pid[JOIN_HITS];
+    bool use[JOIN_HITS];
+#pragma unroll
+    for (int i = 0; i < JOIN_HITS; i++) {
+        use[i] = (uint32_t)i < c && (ent[i] >> 30) == best;
+        const uint32_t loc = ent[i] & LOC_MASK;
+        idx[i] = loc;
+        if (use[i] && (loc & LOC_INLINE)) {
+            const uint32_t l = loc & (LOC_INLINE - 1u);
+            idx[i] = a.tab_off[l >> 5] + (l & 31u);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < JOIN_HITS; i++) pid[i] = use[i] ? (a.ft.pid16 ? (uint32_t)a.tab_ent16[idx[i]] : a.tab_ent[idx[i]]) : 0u;
     LaneResult<E, K_SLOTS> res;
     res.init();
 #pragma unroll
-    for (int i = 0; i < JOIN_HITS; i++) {
-        if ((uint32_t)i < c && (ent[i] >> 30) == best) {
-            const uint32_t loc = ent[i] & LOC_MASK;
-            uint32_t idx = loc;
-            if (loc & LOC_INLINE) {
-                const uint32_t l = loc & (LOC_INLINE - 1u);
-                idx = a.tab_off[l >> 5] + (l & 31u);
-            }
-            res.add((int)best, a.ft.pid16 ? (uint32_t)a.tab_ent16[idx] : a.tab_ent[idx]);
-        }
-    }
+    for (int i = 0; i < JOIN_HITS; i++)
+        if (use[i]) res.add((int)best, pid[i]);
     const bool line = first + 64 <= a.n && (((uintptr_t)(a.min_e + first)) & 15) == 0 && (a.cnt8 == nullptr || (((uintptr_t)(a.cnt8 + first)) & 15) == 0);
     // more hits than the list holds: entries at the minimum may be missing -> the retry launch does the row from scratch
     res.store(active, r, handed > (uint32_t)JOIN_HITS, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.wave_base, first, a.list_defer, a.defer_count,
