@@ -64,7 +64,8 @@ struct LaneResult {
     __device__ __forceinline__ void store(bool row, int64_t r, bool overflow, bool line, uint8_t *__restrict__ min_e, uint8_t *__restrict__ cnt8,
                                           uint32_t *__restrict__ cnt, uint32_t *__restrict__ slots, uint64_t slots_cap,
                                           uint64_t *__restrict__ wave_base, int64_t first, int32_t *__restrict__ list_defer,
-                                          uint32_t *__restrict__ defer_count, unsigned long long *__restrict__ slot_cursor) {
+                                          uint32_t *__restrict__ defer_count, unsigned long long *__restrict__ slot_cursor,
+                                          unsigned long long base_off = 0) {
         const int lane = threadIdx.x & 63;
         bool defer = row && (overflow || nh > K_SLOTS);
         const uint32_t mine = (row && !defer) ? (uint32_t)nh : 0u;
@@ -76,7 +77,9 @@ struct LaneResult {
         }
         const uint32_t total = __shfl(inc, 63, 64);
         unsigned long long base = 0;
-        if (lane == 0 && total) base = atomicAdd(slot_cursor, (unsigned long long)total);
+        // (base_off: the slot array may be cut into arenas with a cursor each — sct_slot_arena — so that 150 000 waves do not queue
+        // at ONE atomic: the join's finish kernel spent 1.9 of its 2.0 ms there; slots_cap is then the END of the wave's arena)
+        if (lane == 0 && total) base = base_off + atomicAdd(slot_cursor, (unsigned long long)total);
         base = __shfl(base, 0, 64);
         if (base + total > slots_cap) defer = row;  // wave-uniform: no room for this wave's lists
         if (lane == 0) __builtin_nontemporal_store((uint64_t)base, &wave_base[first >> 6]);
@@ -1010,8 +1013,25 @@ struct FilterArgs {
     int32_t *list_long, *list_dp; // routing lists of the main launch (rows the filter cannot take)
     uint32_t *ctr;                // the batch's counter record (CTR_*)
     unsigned long long *slot_cursor;
+    unsigned long long *arena_cursors;   // main launch of a large batch: SLOT_ARENAS cursors, 64 bytes apart (NULL: the one slot_cursor)
+    uint64_t arena_cap;                  // entries of the slot array per arena
     int bl, prefix_len;
 };
+
+// Which cursor a main-launch block reserves its hit lists with, where its arena starts and where it ends.
+static constexpr uint32_t SLOT_ARENAS = 64;
+template <typename OffT>
+__device__ __forceinline__ unsigned long long *sct_slot_arena(const FilterArgs<OffT> &a, unsigned long long &base_off, uint64_t &cap_end) {
+    if (a.arena_cursors == nullptr) {
+        base_off = 0;
+        cap_end = a.slots_cap;
+        return a.slot_cursor;
+    }
+    const uint32_t k = blockIdx.x & (SLOT_ARENAS - 1u);
+    base_off = (unsigned long long)k * a.arena_cap;
+    cap_end = base_off + a.arena_cap;
+    return a.arena_cursors + 8u * k;
+}
 
 // One wave's RPW rows, starting at row (or list position) `first`.
 // SCHEME: 0 = the six quarter families, 1 = thirds (max_err <= 1), 2 = wide (max_err = 2); sct_core.h
@@ -1263,8 +1283,11 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
             const uint32_t v = W_.hl(k, (uint32_t)lane);
             res.add((int)(v >> 30), v & LOC_MASK);
         }
-        res.store(active, r, SL ? nc > CAP : FW::overflowed(hc, L.best[lane]), line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.wave_base, first,
-                  a.list_defer, a.defer_count, a.slot_cursor);
+        unsigned long long arena_off;
+        uint64_t arena_end;
+        unsigned long long *cursor = sct_slot_arena(a, arena_off, arena_end);
+        res.store(active, r, SL ? nc > CAP : FW::overflowed(hc, L.best[lane]), line, a.min_e, a.cnt8, a.cnt, a.slots, arena_end, a.wave_base, first,
+                  a.list_defer, a.defer_count, cursor, arena_off);
     } else {
         // Retry launch: lists of up to CAP entries per row (hundreds of ties at a few million barcodes and two edits) are
         // folded by the whole wave, row after row, in LDS: entries that are not at the row's minimum are struck, then every entry

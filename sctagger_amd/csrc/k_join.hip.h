@@ -345,6 +345,9 @@ __global__ void __launch_bounds__(256) k_join_finish(const JoinArgs<OffT> ja) {
         if (use[i]) res.add((int)best, pid[i]);
     const bool line = first + 64 <= a.n && (((uintptr_t)(a.min_e + first)) & 15) == 0 && (a.cnt8 == nullptr || (((uintptr_t)(a.cnt8 + first)) & 15) == 0);
     // more hits than the list holds: entries at the minimum may be missing -> the retry launch does the row from scratch
-    res.store(active, r, handed > (uint32_t)JOIN_HITS, line, a.min_e, a.cnt8, a.cnt, a.slots, a.slots_cap, a.wave_base, first, a.list_defer, a.defer_count,
-              a.slot_cursor);
+    unsigned long long arena_off;
+    uint64_t arena_end;
+    unsigned long long *cursor = sct_slot_arena(a, arena_off, arena_end);
+    res.store(active, r, handed > (uint32_t)JOIN_HITS, line, a.min_e, a.cnt8, a.cnt, a.slots, arena_end, a.wave_base, first, a.list_defer, a.defer_count,
+              cursor, arena_off);
 }

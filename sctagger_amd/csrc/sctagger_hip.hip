@@ -148,6 +148,7 @@ struct Lane {
     // work / results
     DevBuf min_e, cnt, route, slots, slots_retry, list_retry, slot_off, wave_base, list_long, list_scan, list_dp, counters, hit_offs, sums, hits,
         part_best, part_cnt, cnt_out;
+    DevBuf arena_cur;   // SLOT_ARENAS cursors of the main launch's slot array, 64 bytes apart (sct_slot_arena)
     DevBuf j_planes, j_len, j_wave, j_cnt, j_slots, j_tup0, j_cnt0, j_tup1, j_cnt1;   // the partitioned join (k_join.hip.h)
     uint64_t slots_cap = 0, retry_cap = 0;
     // where the kernels write the results the caller sees: the lane's own buffers (copied out afterwards) or, for a stream
@@ -180,7 +181,7 @@ struct Lane {
     void release() {
         DevBuf *bufs[] = {&segs, &offs64, &offs32, &index_in, &min_e, &cnt, &route, &slots, &slots_retry, &list_retry, &slot_off, &wave_base, &list_long,
                           &list_scan, &list_dp, &counters, &hit_offs, &sums, &hits, &part_best, &part_cnt, &cnt_out,
-                          &j_planes, &j_len, &j_wave, &j_cnt, &j_slots, &j_tup0, &j_cnt0, &j_tup1, &j_cnt1};
+                          &arena_cur, &j_planes, &j_len, &j_wave, &j_cnt, &j_slots, &j_tup0, &j_cnt0, &j_tup1, &j_cnt1};
         for (DevBuf *b : bufs) b->release();
         for (hipEvent_t e : pool) (void)hipEventDestroy(e);
         pool.clear();
@@ -647,6 +648,10 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.list_defer = l.list_retry.as<int32_t>();
         fa.defer_count = ctr + CTR_RETRY;
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR);
+        // large batches: the slot array in SLOT_ARENAS arenas with a cursor each (a block's arena = its index mod SLOT_ARENAS, so an
+        // arena sees 1 / SLOT_ARENAS of the rows and holds K_SLOTS entries for each of them: it cannot overflow either)
+        fa.arena_cursors = (n >= 65536 && l.arena_cur.p) ? l.arena_cur.as<unsigned long long>() : nullptr;
+        fa.arena_cap = l.slots_cap / SLOT_ARENAS;
         const bool join_ready = l.j_planes.p && l.j_len.p && l.j_wave.p && l.j_cnt.p && l.j_slots.p && l.j_tup0.p && l.j_cnt0.p && l.j_tup1.p && l.j_cnt1.p &&
                                 l.j_planes.cap >= 8 * (size_t)n && fa.tab_fb != nullptr;
         if (bp.use_join && n < ((int64_t)1 << 30) && join_ready) {
@@ -690,6 +695,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.list_defer = l.list_scan.as<int32_t>();
         fa.defer_count = ctr + CTR_SCAN;
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR_RETRY);
+        fa.arena_cursors = nullptr;
         launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), capped((n + 3) / 4), st);  // one wave of 4 rows per block, striding
     }
 }
@@ -715,8 +721,9 @@ static void queue_offsets(sct_ctx *c, Lane &l, bool counts_done = false) {
 // l.seg_bytes, l.wide) are already on the device or their copies are queued on the same stream.  The counter record must
 // have been reset (reset_counters) before whatever checks the input wrote to it.
 static int reset_counters(Lane &l) {
-    if (l.counters.ensure(sizeof(uint32_t) * CTR_WORDS)) return g_code;
+    if (l.counters.ensure(sizeof(uint32_t) * CTR_WORDS) || l.arena_cur.ensure(64 * SLOT_ARENAS)) return g_code;
     HIPCHK(hipMemsetAsync(l.counters.p, 0, sizeof(uint32_t) * CTR_WORDS, l.stream));
+    HIPCHK(hipMemsetAsync(l.arena_cur.p, 0, 64 * SLOT_ARENAS, l.stream));
     HIPCHK(hipMemsetAsync(l.ctr() + CTR_BAD_ROW, 0xFF, 16, l.stream));
     return SCT_OK;
 }
