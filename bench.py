@@ -333,10 +333,22 @@ def other_config(name, device, steps, warmup):
         e2e, e2e_elapsed = loops.e2e(steps, warmup, "len8", "u8", "u16")
         res, avg, _ = loops.resident(steps, warmup)
         per_seg, alg_bytes, h = loops.algorithmic_bytes()
-        return {"workload": desc, "seed": SEEDS[name],
+        paths = m.last_stats()
+        extra = {}
+        if paths["scheme"] == "thirds" and max_err == 1:
+            # the partitioned join (option "join"; csrc/k_join.hip.h) instead of the filter kernel's 32-bit main launch: same
+            # results (tests/test_gpu_join.py), about half the HBM traffic, the same time -> an option, timed here for the record
+            m.set_option("join", 1)
+            jres, javg, _ = loops.resident(steps, warmup)
+            jp = m.last_stats()
+            m.set_option("join", 0)
+            extra["resident_with_join"] = {"ms_per_step": jres["ms_per_step"], "kernels_ms": {k: round(v, 4) for k, v in javg.items()},
+                                           "join_batches": jp["join_batches"], "join_fallbacks": jp["join_fallbacks"],
+                                           "note": "k_filter's span covers the join's kernels (tuples, probes per table slice, finish) in this leg"}
+        return {"workload": desc, "seed": SEEDS[name], **extra,
                 "value_device_e2e": n_seg / (e2e["ms_per_step"] * 1e-3), "ms_per_step": e2e["ms_per_step"],
                 "value_resident": n_seg / (res["ms_per_step"] * 1e-3), "ms_per_step_resident": res["ms_per_step"],
-                "steps": steps, "warmup": warmup, "hits_per_segment": round(h, 4), "paths": m.last_stats(),
+                "steps": steps, "warmup": warmup, "hits_per_segment": round(h, 4), "paths": paths,
                 "device_e2e": e2e, "kernels_ms": {k: round(v, 4) for k, v in avg.items()},
                 "roofline": hbm_roofline(loops, avg, desc, "k_filter_counters_%s.json" % name),
                 "roofline_e2e": pcie_roofline(e2e, segs.size),

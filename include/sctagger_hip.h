@@ -170,6 +170,12 @@ int sct_sync(sct_ctx *ctx);
  *                            (takes effect at the next sct_set_barcodes; "no_thirds" switches their USE off and on at any time)
  *   "fixed_buckets"   -1|0|1 thirds families: 1 / -1 (default) = a lookup reads the key's fixed bucket (one line: the rest characters of
  *                            up to 16 / 8 entries), 0 = offsets and codes (two lines).  (The main launch of the wide families always uses theirs.)
+ *   "join"             0|1   thirds families at max_err = 1 with fixed buckets: 1 = the rows of up to 31 characters go through the partitioned
+ *                            join (lookups as 8-byte tuples, partitioned by key range, probed table slice by table slice while the slice
+ *                            sits in L2; csrc/k_join.hip.h) instead of the filter kernel's 32-bit launch; 0 (default) = the filter kernel.
+ *                            Same results; about half the HBM traffic and the same time at 3.6 M barcodes.  May be
+ *                            switched between calls.  A batch whose tuples do not fit their regions is redone by the filter kernel
+ *                            (sct_last_stats [6]).
  *   "wide"            -1|0|1 the sixteen 20-bit seed families of max_err = 2 (sct_core.h): -1 = built and used from 2^20 patterns
  *                            (524 288 barcodes) on (default), 0 = not used, 1 = built whatever the size (takes effect at the
  *                            next sct_set_barcodes) and used

@@ -221,7 +221,8 @@ struct sct_ctx {
     int thirds_mode = -1;  // -1 = thirds tables by the size of the set, 1 = built whatever the size (next sct_set_barcodes)
     int fb_mode = -1;      // thirds families: -1 / 1 = lookups read the fixed buckets, 0 = offsets + codes
     int wide_mode = -1;    // -1 = by the size of the barcode set, 0 = never, 1 = build and use the wide families whatever the size
-    int join_mode = -1;    // thirds scheme at max_err = 1: -1 / 1 = the partitioned join does the 32-bit rows, 0 = k_filter does
+    int join_mode = 0;     // thirds scheme at max_err = 1: 1 = the partitioned join (k_join.hip.h) does the 32-bit rows, 0 (default) = k_filter does:
+                           // the join halves the HBM traffic and takes the same time, so it is an option, not the default
     int slots_mode = -1;       // -1 = by the share of long buckets, 0 = never, 1 = whenever the tables hold them
     double long_share = 1.0;   // share of the seed keys whose bucket does not fit a slot (sct_set_barcodes)
     bool zero_copy = true;     // stream API: kernels read page-locked caller buffers in place instead of uploading them
@@ -390,7 +391,7 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "thirds")) c->thirds_mode = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "fixed_buckets")) c->fb_mode = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "wide")) c->wide_mode = value < 0 ? -1 : (value != 0);  // takes effect at the next sct_set_barcodes
-    else if (!strcmp(key, "join")) c->join_mode = value < 0 ? -1 : (value != 0);
+    else if (!strcmp(key, "join")) c->join_mode = value > 0 ? 1 : 0;
     else if (!strcmp(key, "slots")) c->slots_mode = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "chunk_rows")) {
         if (value < 0 || value > 0x7FFFFFF0) return fail(SCT_E_ARG, "chunk_rows must be in 0 .. 2^31-16");
@@ -548,7 +549,7 @@ static int batch_params(sct_ctx *c, int32_t max_err, int32_t threads, int count_
                    (c->slots_mode < 0 ? c->long_share <= (max_err <= 1 ? SLOTS_MAX_LONG_SHARE_E1 : SLOTS_MAX_LONG_SHARE_E2) && c->max_bucket <= SLOTS_MAX_BUCKET
                                        : c->slots_mode == 1);
     // the join reads the fixed buckets and packs a row number into 30 bits of a tuple
-    bp.use_join = bp.use_thirds && max_err == 1 && c->join_mode != 0 && c->have_fb && c->fb_mode != 0;
+    bp.use_join = bp.use_thirds && max_err == 1 && c->join_mode == 1 && c->have_fb && c->fb_mode != 0;
     bp.count_format = count_format;
     c->last_join = 0;
     c->last_scheme = !bp.filter_ok ? SCT_SCHEME_NONE : bp.use_thirds ? SCT_SCHEME_THIRDS : bp.use_wide ? SCT_SCHEME_WIDE
