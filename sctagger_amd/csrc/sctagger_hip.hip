@@ -571,7 +571,10 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
     if (bp.filter_ok) {
         // the main launch keeps at most K_SLOTS hits per row, the retry launch shares a pool of the same size; the CSR hit
         // array can therefore hold whatever the two launches produce (rows of the scan lists are sized by the slow path)
-        l.slots_cap = (uint64_t)n1 * K_SLOTS;
+        // (rows rounded up to whole rounds of SLOT_ARENAS blocks of 256: every arena then has room for K_SLOTS entries of each of
+        // the rows of the blocks that use it, whatever the number of blocks — no wave is deferred for lack of room in its arena)
+        const uint64_t arena_round = (uint64_t)SLOT_ARENAS * 256;
+        l.slots_cap = ((uint64_t)n1 + arena_round - 1) / arena_round * arena_round * K_SLOTS;
         l.retry_cap = (uint64_t)n1 * K_SLOTS < 65536 ? 65536 : (uint64_t)n1 * K_SLOTS;
         if (l.slots.ensure(4 * l.slots_cap) || l.slots_retry.ensure(4 * l.retry_cap) || l.slot_off.ensure(8 * n1) || l.wave_base.ensure(8 * (n1 / 64 + 2)) ||
             l.list_retry.ensure(4 * n1))
