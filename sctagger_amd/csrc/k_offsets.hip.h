@@ -186,6 +186,121 @@ __global__ void __launch_bounds__(256) k_fill(const uint32_t *__restrict__ cnt, 
     }
 }
 
+// k_offsets and k_fill in one kernel (the filter path's normal case: no row waits for the scan kernels).  A block's 2 048 rows
+// own one contiguous stretch of the hit array: the lists are gathered from the slot arrays into LDS and leave as aligned
+// 16-byte stores (the hit array may be the caller's page-locked buffer: every store instruction is a PCIe write of its own,
+// and a two-byte store per hit made k_fill the slowest step of the tail: 14 MB in 0.34 ms).  A thread owns eight consecutive
+// rows, eight threads the 64 rows of one wave of the main launch (k_fill's rule for where a row's list starts).
+// OutT: uint32_t (hits) or uint16_t (SCT_HITS_U16 straight into the result buffer).
+static constexpr uint32_t FILL_STAGE = 8192;   // entries a block gathers in LDS; a block with more writes them one by one
+template <typename OutT>
+__global__ void __launch_bounds__(256)
+k_offsets_fill(const uint32_t *__restrict__ cnt, int64_t n, const uint64_t *__restrict__ sums, const uint64_t *__restrict__ total,
+               int64_t *__restrict__ hit_offs, uint8_t *__restrict__ cnt8, uint32_t *__restrict__ cnt32, uint32_t *__restrict__ ctr,
+               const uint32_t *__restrict__ slots, const uint32_t *__restrict__ slots_retry, const uint64_t *__restrict__ wave_base,
+               const uint64_t *__restrict__ slot_off, OutT *__restrict__ out, uint64_t out_cap) {
+    static_assert(SCAN_ITEMS == 8, "eight rows per thread, eight threads per wave of the main launch");
+    __shared__ uint64_t lds[8];
+    __shared__ __attribute__((aligned(16))) OutT stage[FILL_STAGE + 16];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t raw[SCAN_ITEMS], v[SCAN_ITEMS];
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        raw[i] = base + i < n ? cnt[base + i] : 0u;
+        v[i] = (uint32_t)scan_value<uint32_t>(raw[i]);
+        s += v[i];
+    }
+    uint64_t tot;
+    const uint64_t first = sums[blockIdx.x];   // hits of the rows before this block
+    const uint64_t run0 = first + block_exclusive_scan(s, &tot, lds);
+    {   // ---- k_offsets' part
+        uint64_t run = run0;
+        bool over = false;
+        const bool whole = base + SCAN_ITEMS <= n;
+        const bool wide8 = cnt8 && whole && ((uintptr_t)(cnt8 + base) & 7) == 0;
+        const bool wide32 = cnt32 && whole && ((uintptr_t)(cnt32 + base) & 15) == 0;
+        uint64_t pack8 = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            if (base + i < n) {
+                hit_offs[base + i] = (int64_t)run;
+                if (cnt8) {
+                    const uint32_t b = v[i] < 255u ? v[i] : 255u;
+                    if (wide8) pack8 |= (uint64_t)b << (8 * i);
+                    else cnt8[base + i] = (uint8_t)b;
+                    over |= v[i] > 255u;
+                }
+                if (cnt32 && !wide32) cnt32[base + i] = v[i];
+            }
+            run += v[i];
+        }
+        if (wide8) *reinterpret_cast<uint64_t *>(cnt8 + base) = pack8;
+        if (wide32) {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u4 *>(cnt32 + base) = u4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<u4 *>(cnt32 + base + 4) = u4{v[4], v[5], v[6], v[7]};
+        }
+        if (over) atomicOr(&ctr[CTR_CNT_OVERFLOW], 1u);
+        if (blockIdx.x == 0 && threadIdx.x == 0) hit_offs[n] = (int64_t)*total;
+    }
+    // ---- k_fill's part (every condition up to the barrier is the same for the whole block)
+    if (*total > out_cap) return;   // more hits than `out` can take: nothing is written, the host enlarges the buffer and fills again
+    if (tot == 0) return;
+    // lists the main launch stored lie back to back from wave_base[r / 64]: a row's list starts behind those of the wave's earlier rows
+    uint32_t own = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) own += (raw[i] != CNT_DEFER && (raw[i] & CNT_RETRIED) == 0u) ? v[i] : 0u;
+    uint32_t inc = own;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 8);
+        if ((int)(threadIdx.x & 7) >= o) inc += t;
+    }
+    uint32_t before = inc - own;
+    constexpr uint32_t PER = 16 / sizeof(OutT);                                   // entries of a 16-byte store
+    const uint32_t sh = (uint32_t)(((uintptr_t)(out + first) & 15) / sizeof(OutT));   // the stretch starts `sh` entries into its first 16 bytes
+    const bool fits = tot <= (uint64_t)FILL_STAGE;
+    uint64_t run = run0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (v[i]) {
+            const int64_t r = base + i;
+            const bool retried = (raw[i] & CNT_RETRIED) != 0u;
+            const uint32_t *src = retried ? slots_retry + slot_off[r] : slots + (wave_base[r >> 6] + before);
+            if (fits) {
+                OutT *dst = stage + sh + (uint32_t)(run - first);
+                for (uint32_t k = 0; k < v[i]; k++) dst[k] = (OutT)src[k];
+            } else {
+                for (uint32_t k = 0; k < v[i]; k++) out[run + k] = (OutT)src[k];
+            }
+            if (!retried) before += v[i];
+            run += v[i];
+        }
+    }
+    if (!fits) return;
+    __syncthreads();
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const uint32_t t32 = (uint32_t)tot;
+    OutT *o0 = out + first - sh;                                                  // 16-byte aligned; entry e of the block = o0[sh + e]
+    const uint32_t v0 = (sh + PER - 1) / PER, v1 = (sh + t32) / PER;             // whole 16-byte groups [v0, v1)
+    if (v1 > v0) {
+        for (uint32_t j = v0 + threadIdx.x; j < v1; j += 256)
+            *reinterpret_cast<u4 *>(o0 + (size_t)j * PER) = *reinterpret_cast<const u4 *>(stage + (size_t)j * PER);
+        // the entries in front of the first whole group and behind the last
+        const uint32_t head_end = v0 * PER, tail_beg = v1 * PER;
+        if (threadIdx.x < PER) {
+            const uint32_t e = sh + threadIdx.x;
+            if (e < head_end) o0[e] = stage[e];
+        } else if (threadIdx.x < 2 * PER) {
+            const uint32_t e = tail_beg + (threadIdx.x - PER);
+            if (e < sh + t32) o0[e] = stage[e];
+        }
+    } else {
+        for (uint32_t e = sh + threadIdx.x; e < sh + t32; e += 256) o0[e] = stage[e];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Index formats of the stream path (include/sctagger_hip.h: SCT_IDX_*): the caller's row index of one chunk ->
 // uint32 offsets relative to the chunk's first byte, checked on the way (CTR_BAD_ROW = smallest offending row of the

@@ -753,12 +753,27 @@ static int queue_batch(sct_ctx *c, Lane &l) {
                                                                          l.list_scan.as<int32_t>(), l.list_dp.as<int32_t>(), l.ctr());
         }
     }
-    queue_offsets(c, l, /* the filter launches wrote the one-byte counts: */ bp.filter_ok);
     if (n > 0 && bp.filter_ok) {
+        // hit counts -> offsets -> hit array: block sums and their scan (span "k_offsets"), then offsets and lists in ONE kernel
+        // (span "k_fill"; k_offsets_fill).  The filter launches wrote the one-byte counts themselves.
+        const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        uint64_t *total = reinterpret_cast<uint64_t *>(l.ctr() + CTR_TOTAL);
+        {
+            Timer t(c, l, "k_offsets");
+            k_sum_blocks<uint32_t><<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), nullptr);
+            k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
+        }
         Timer t(c, l, "k_fill");
-        k_fill<<<blocks_for(n, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
-                                                   l.wave_base.as<uint64_t>(), l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(), n, l.hits_ptr,
-                                                   l.hits_cap, l.ctr(), l.hits16_ptr);
+        if (l.hits16_ptr)
+            k_offsets_fill<uint16_t><<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), total, l.hit_offs.as<int64_t>(), nullptr,
+                                                                  l.cnt32_ptr, l.ctr(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
+                                                                  l.wave_base.as<uint64_t>(), l.slot_off.as<uint64_t>(), l.hits16_ptr, l.hits_cap);
+        else
+            k_offsets_fill<uint32_t><<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), total, l.hit_offs.as<int64_t>(), nullptr,
+                                                                  l.cnt32_ptr, l.ctr(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
+                                                                  l.wave_base.as<uint64_t>(), l.slot_off.as<uint64_t>(), l.hits_ptr, l.hits_cap);
+    } else {
+        queue_offsets(c, l);
     }
     HIPCHK(hipMemcpyAsync(l.h_ctr, l.counters.p, sizeof(uint32_t) * CTR_WORDS, hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
