@@ -724,11 +724,18 @@ static void queue_offsets(sct_ctx *c, Lane &l, bool counts_done = false) {
 // Queue everything a batch needs on the lane's stream — no host synchronisation.  The rows (segs + offsets, l.n_seg,
 // l.seg_bytes, l.wide) are already on the device or their copies are queued on the same stream.  The counter record must
 // have been reset (reset_counters) before whatever checks the input wrote to it.
+// counters: all zero, but "smallest bad row / byte" = ~0 (CTR_BAD_ROW, CTR_BAD_BYTE: words 8..11); slot-arena cursors: zero
+__global__ void __launch_bounds__(256) k_reset_counters(uint32_t *__restrict__ ctr, uint32_t *__restrict__ arena, int arena_words) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < CTR_WORDS) ctr[i] = (i >= CTR_BAD_ROW && i < CTR_BAD_ROW + 4) ? 0xFFFFFFFFu : 0u;
+    if (i < arena_words) arena[i] = 0u;
+}
+
 static int reset_counters(Lane &l) {
     if (l.counters.ensure(sizeof(uint32_t) * CTR_WORDS) || l.arena_cur.ensure(64 * SLOT_ARENAS)) return g_code;
-    HIPCHK(hipMemsetAsync(l.counters.p, 0, sizeof(uint32_t) * CTR_WORDS, l.stream));
-    HIPCHK(hipMemsetAsync(l.arena_cur.p, 0, 64 * SLOT_ARENAS, l.stream));
-    HIPCHK(hipMemsetAsync(l.ctr() + CTR_BAD_ROW, 0xFF, 16, l.stream));
+    // one launch at the head of the batch instead of three memsets (each a launch of its own in front of the first kernel)
+    k_reset_counters<<<(64 * SLOT_ARENAS / 4 + 255) / 256, 256, 0, l.stream>>>(l.ctr(), l.arena_cur.as<uint32_t>(), (int)(64 * SLOT_ARENAS / 4));
+    HIPCHK(hipGetLastError());
     return SCT_OK;
 }
 
