@@ -19,11 +19,16 @@
 // else stay with k_filter: the join replaces its 32-bit main launch only.  Verification needs no automaton at one edit: the two
 // seed pieces are exact, the remaining 5 or 6 pattern characters are compared with the text beside the anchors by mismatch masks
 // (host-checked against the anchored automaton for every placement, tests/host_core_check.cpp).
+//
+// Measured (cfg5, 10 M rows, profiles/r03join_*): the lookups do hit the L2 — 11.3 GB of HBM traffic per batch against the filter
+// kernel's 17.5, 12.4 missed lines per row against 27.1 — and the six kernels take 4.76 ms against the filter kernel's 4.85: what
+// the memory system no longer costs, packing, partitioning, ranking and the per-row atomics do (165 VALU wave-instructions per row
+// against 197).  So this path is an OPTION (sct_set_option "join" = 1), not the default; DESIGN.md 6.3 has the table.
 #pragma once
 
 static constexpr int JOIN_P0 = 16;           // T01: 2^20 keys x 32 B = 32 MB -> 16 slices of 2 MB (key >> 16)
 static constexpr int JOIN_P1 = 64;           // T12 and T02: 2^22 keys x 16 B = 64 MB each -> 32 slices each (key >> 17)
-static constexpr int JOIN_CAP0 = 512;        // tuples a producer block (256 rows) may leave in one partition: T01 (mean 128 at 22 characters)
+static constexpr int JOIN_CAP0 = 512;        // tuples a producer block (256 rows) may leave in one partition: T01 (mean 122 at 22 characters: 8 placements a row)
 static constexpr int JOIN_CAP1 = 384;        // ... T12 / T02 (mean 42 / 105; T02 tuples cluster — see join_part_t02 — worst seen 260 with every row active)
 static constexpr int JOIN_GROUP = 16;        // producer blocks per probe block
 static constexpr int64_t JOIN_SUB_ROWS = (int64_t)1 << 22;   // rows per pass (a multiple of 256): the tuple regions hold one pass
