@@ -161,3 +161,19 @@ def test_join_several_passes(m):
     x = m.match(segs[:offs[k]], offs[:k + 1], 1, 16)
     m.set_option("force_exhaustive", 0)
     assert np.array_equal(a[0][:k], x[0]) and np.array_equal(a[1][:k + 1], x[1]) and np.array_equal(a[2][:x[2].size], x[2])
+
+
+def test_join_is_an_option_not_the_default():
+    """A fresh context runs the thirds scheme at max_err = 1 through the filter kernel: the join measured no faster."""
+    with _native.Matcher(0) as fresh:
+        fresh.set_option("thirds", 1)
+        bc = synth.make_barcodes(20000, seed=26)
+        fresh.set_barcodes(bc)
+        segs, offs = synth.make_segments(20000, bc, seed=26)
+        a = fresh.match(segs, offs, 1, 1)
+        st = fresh.last_stats()
+        assert st["scheme"] == "thirds" and st["join_batches"] == 0 and st["join_fallbacks"] == 0, st
+        fresh.set_option("join", 1)
+        b = fresh.match(segs, offs, 1, 1)
+        assert fresh.last_stats()["join_batches"] == 1
+        util.assert_same(a, b, "default (filter kernel) vs join")
