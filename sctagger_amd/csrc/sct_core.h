@@ -9,6 +9,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 #if defined(__HIPCC__)
 #define SCT_HD __host__ __device__ __forceinline__
 #define SCT_HDM __host__ __device__ __forceinline__
@@ -540,6 +542,56 @@ SCT_HD int wm_anchored(EmFetch &&em, W va, uint32_t code, int t, int t2) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Restricted starts.  With -t > 1 the reference only inserts the windows whose first k raw bytes are all in ACGT (k = the
+// prefix length of its tasks, scTagger.py:681, :689-697), and a query walks a window from its FIRST character: an alignment
+// must begin at an allowed window start s, and text characters skipped in front of the barcode are insertions that cost an edit
+// each (Trie.dfs :587-588 at depth 0).  In the automaton that is a different INITIAL state and nothing else:
+//   A0 = the allowed starts (bit s), A1 = A0 | A0 << 1, A2 = A1 | A1 << 1 (within the text)
+// A_d = positions an alignment can stand at, no barcode character consumed yet, having spent at most d edits — instead of
+// "anywhere, for free" (va).  The seed families stay complete: the leading insertions touch no quarter, so an alignment within E
+// edits still leaves two quarters (one half, two thirds) untouched at exactly their text positions, the placement is enumerated
+// as before, and the value computed under its hypothesis is the cost of a real alignment from an allowed start.  The same masks
+// serve rows cut into overlapping windows of PLANE_MAX characters (k_filter's special launch): a window owns the starts in its
+// first `step` characters.
+// ---------------------------------------------------------------------------------------------------
+// allowed starts of a text of `len` characters from its "byte is not one of ACGT" mask: s is allowed iff s + k <= len and none of
+// the k bytes from s on is bad (k = 0: every position 0..len)
+template <typename W>
+SCT_HD W sct_allowed_starts(W bad, int len, int k) {
+    W blocked = 0;
+    for (int q = 0; q < k; q++) blocked |= bad >> q;
+    const int ns = len - k + 1;
+    const W in = ns <= 0 ? (W)0 : (ns >= (int)(8 * sizeof(W)) ? ~(W)0 : (((W)1 << ns) - 1));
+    return ~blocked & in;
+}
+template <typename W>
+struct SctStarts {
+    W a[3];
+    SCT_HDM void from_allowed(W a0, W va) {
+        a[0] = a0 & va;
+        a[1] = (a[0] | (a[0] << 1)) & va;
+        a[2] = (a[1] | (a[1] << 1)) & va;
+    }
+};
+template <int E, typename W, typename Fam, typename EmFetch>
+SCT_HD int wm_anchored_rest_rs(const Fam &fam, EmFetch &&em, W va, const SctStarts<W> &st, uint32_t rest, int t, int t2) {
+    WmState<E, W> s;
+    s.R0 = st.a[0];   // PA == 0: the anchor keeps bit t of each — "an allowed start at most d characters before t"
+    s.R1 = st.a[1];
+    s.R2 = st.a[2];
+    for (int j = 0; j < fam.PA; j++, rest >>= 2) s.step(em(rest & 3u));
+    if (fam.ADJ) {
+        s.anchor(t, fam.LA + fam.LB);
+    } else {
+        s.anchor(t, fam.LA);
+        for (int j = fam.PA + fam.LA; j < fam.PB; j++, rest >>= 2) s.step(em(rest & 3u));
+        s.anchor(t2, fam.LB);
+    }
+    for (int j = fam.PB + fam.LB; j < fam.BL; j++, rest >>= 2) s.step(em(rest & 3u));
+    return s.result(va);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The same anchored verification for TWO candidates at once, one in each 16-bit half of the state words (X in
 // bits 0..15, Y in bits 16..31).  A run of the automaton only ever needs a window of the text: the left run must
 // arrive exactly at t, so only the positions t - PA - E .. t matter; after an anchor the states sit at the first
@@ -604,22 +656,37 @@ struct WmPair {
     }
 };
 
-template <int E, typename Fam, typename EmX, typename EmY, typename WV>
+// SX / SY: where the alignments may start.  SctFreeStart = anywhere (the usual case); otherwise a functor d -> A_d of the
+// candidate's text (restricted starts, above).
+struct SctFreeStart {};
+template <int E, typename Fam, typename EmX, typename EmY, typename WV, typename SX = SctFreeStart, typename SY = SctFreeStart>
 SCT_HD uint32_t wm_anchored_pair(const Fam &fam, EmX &&emx, EmY &&emy, WV vax, WV vay, uint32_t restx, uint32_t resty,
-                                 int tx, int t2x, int ty, int t2y) {
+                                 int tx, int t2x, int ty, int t2y, SX &&sx = SctFreeStart{}, SY &&sy = SctFreeStart{}) {
+    constexpr bool FREE = std::is_same<typename std::decay<SX>::type, SctFreeStart>::value;
     WmPair<E> s;
     int bx, by;
     if (fam.PA > 0) {  // left run: free start, must arrive exactly at t
         bx = tx - fam.PA - E > 0 ? tx - fam.PA - E : 0;
         by = ty - fam.PA - E > 0 ? ty - fam.PA - E : 0;
-        s.R0 = s.R1 = s.R2 = sct_pk((uint32_t)(vax >> bx), (uint32_t)(vay >> by));
+        if constexpr (FREE) {
+            s.R0 = s.R1 = s.R2 = sct_pk((uint32_t)(vax >> bx), (uint32_t)(vay >> by));
+        } else {
+            s.R0 = sct_pk((uint32_t)(sx(0) >> bx), (uint32_t)(sy(0) >> by));
+            s.R1 = E >= 1 ? sct_pk((uint32_t)(sx(1) >> bx), (uint32_t)(sy(1) >> by)) : 0u;
+            s.R2 = E >= 2 ? sct_pk((uint32_t)(sx(2) >> bx), (uint32_t)(sy(2) >> by)) : 0u;
+        }
         for (int j = 0; j < fam.PA; j++, restx >>= 2, resty >>= 2)
             s.step(sct_pk((uint32_t)(emx(restx & 3u) >> bx), (uint32_t)(emy(resty & 3u) >> by)));
         s.anchor(sct_pk((uint32_t)(tx - bx), (uint32_t)(ty - by)));
-    } else {
+    } else if constexpr (FREE) {
         s.R0 = 0x00010001u;
         s.R1 = 0x00030003u;
         s.R2 = 0x00070007u;
+    } else {
+        // the barcode begins at t: an allowed start at most d characters before it (bit t of A_d), then the closure under insertion
+        s.R0 = sct_pk((uint32_t)(sx(0) >> tx) & 1u, (uint32_t)(sy(0) >> ty) & 1u);
+        s.R1 = E >= 1 ? (sct_pk((uint32_t)(sx(1) >> tx) & 1u, (uint32_t)(sy(1) >> ty) & 1u) | (s.R0 << 1)) : 0u;
+        s.R2 = E >= 2 ? (sct_pk((uint32_t)(sx(2) >> tx) & 1u, (uint32_t)(sy(2) >> ty) & 1u) | (s.R1 << 1)) : 0u;
     }
     const int skip1 = fam.ADJ ? fam.LA + fam.LB : fam.LA;
     bx = tx + skip1;

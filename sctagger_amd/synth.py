@@ -133,3 +133,34 @@ def write_segments_tsv(path, segs, offs, seed=0):
                 f.write("read_%d\t%d\t%d\t%s\n" % (i, rng.integers(0, 4), rng.integers(20, 60), s))
             else:
                 f.write("read_%d\t-1\tNA\t\n" % i)
+
+
+def add_noise_bytes(segs, offs, frac, seed=7, byte=ord("N")):
+    """A copy of `segs` in which a share `frac` of the non-empty rows carries ONE byte outside ACGT at a uniform position
+    (what the reference's raw-byte prefix rule, scTagger.py:681, reacts to).  -> (segs, rows changed)."""
+    rng = np.random.default_rng(seed)
+    lens = np.diff(offs)
+    rows = np.flatnonzero(lens > 0)
+    pick = rows[rng.random(rows.size) < frac]
+    out = segs.copy()
+    pos = offs[pick] + (rng.random(pick.size) * lens[pick]).astype(np.int64)
+    out[pos] = byte
+    return out, pick
+
+
+def lengthen_rows(segs, offs, frac, new_len, seed=8):
+    """A copy of the batch in which a share `frac` of the non-empty rows is padded with random ACGT bytes to `new_len`
+    characters (rows longer than the 63 characters the bit-planes hold).  -> (segs, offs, rows changed)."""
+    rng = np.random.default_rng(seed)
+    lens = np.diff(offs)
+    rows = np.flatnonzero((lens > 0) & (lens < new_len))
+    pick = rows[rng.random(rows.size) < frac]
+    new_lens = lens.copy()
+    new_lens[pick] = new_len
+    new_offs = np.zeros(offs.size, dtype=np.int64)
+    np.cumsum(new_lens, out=new_offs[1:])
+    out = _ACGT[rng.integers(0, 4, size=int(new_offs[-1]), dtype=np.uint8)]
+    # the old bytes go to the head of their rows: byte j of the old buffer -> new_offs[row] + (j - offs[row])
+    row_of = np.repeat(np.arange(lens.size), lens)
+    out[new_offs[row_of] + (np.arange(segs.size) - offs[row_of])] = segs
+    return out, new_offs, pick

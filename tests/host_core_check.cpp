@@ -433,6 +433,196 @@ static bool emulate_filter_wide(const SctSeedTables &T, const std::vector<std::v
     return want == best && want_hits == hits;
 }
 
+
+// ---- restricted starts (sct_core.h: sct_allowed_starts, SctStarts, wm_anchored_rest_rs, wm_anchored_pair with start functors) ----
+// the reference's rule as a plain DP: an alignment begins at an allowed start; characters skipped in front of the pattern cost one
+// edit each (row 0 is the distance back to the nearest allowed start)
+static int brute_restricted(const std::vector<int> &p, const std::vector<int> &t, uint64_t allowed) {
+    const int m = (int)p.size(), n = (int)t.size(), BIG = 1000;
+    std::vector<int> prev(m + 1), cur(m + 1);
+    prev[0] = (allowed & 1) ? 0 : BIG;
+    for (int i = 1; i <= m; i++) prev[i] = std::min(BIG, prev[i - 1] + 1);
+    int best = prev[m];
+    for (int j = 1; j <= n; j++) {
+        cur[0] = std::min(((allowed >> j) & 1) ? 0 : BIG, prev[0] + 1);
+        for (int i = 1; i <= m; i++) cur[i] = std::min({prev[i - 1] + (p[i - 1] != t[j - 1]), prev[i] + 1, cur[i - 1] + 1, BIG});
+        best = std::min(best, cur[m]);
+        std::swap(prev, cur);
+    }
+    return best;
+}
+template <typename W>
+struct StartFn {
+    const SctStarts<W> *s;
+    W operator()(int d) const { return s->a[d]; }
+};
+// minimum over the placements of `fam` (pruned for E) whose key equals the pattern's; the packed pair form must agree with the plain one
+template <int E, typename W, typename Fam>
+static int rs_family(const Fam &fam, const std::vector<int> &p, uint64_t tlo, uint64_t thi, int L, const SctStarts<W> &st, bool *pair_ok) {
+    uint64_t plo, phi;
+    planes(p, plo, phi);
+    const uint32_t pkey = sct_key_of<uint32_t>(fam, (uint32_t)plo, (uint32_t)phi, fam.PA, fam.PB);
+    EmArray<W> em;
+    const W va = sct_valid_mask<W>(L), ve = va & ~(W)1, l1 = (W)tlo << 1, h1 = (W)thi << 1;
+    em.m[0] = ~l1 & ~h1 & ve; em.m[1] = l1 & ~h1 & ve; em.m[2] = ~l1 & h1 & ve; em.m[3] = l1 & h1 & ve;
+    uint32_t code = 0;
+    for (size_t j = 0; j < p.size(); j++) code |= (uint32_t)p[j] << (2 * j);
+    const uint32_t rest = sct_rest_of(fam, code);
+    int best = E + 1, pt = -1, pt2 = -1, pd = 0;
+    sct_for_each_placement_of(fam, L, [&](int a, int b) {
+        if (sct_key_of<W>(fam, (W)tlo, (W)thi, a, b) != pkey) return;
+        const int d = wm_anchored_rest_rs<E, W>(fam, em, va, st, rest, a, b);
+        best = std::min(best, d);
+        if (pt >= 0) {   // this placement and the one before it as the two halves of a pair
+            const uint32_t r = wm_anchored_pair<E>(fam, em, em, va, va, rest, rest, pt, pt2, a, b, StartFn<W>{&st}, StartFn<W>{&st});
+            if ((int)(r & 0xFFFFu) != pd || (int)(r >> 16) != d) *pair_ok = false;
+        }
+        pt = a; pt2 = b; pd = d;
+    }, E);
+    return best;
+}
+template <int E, typename W>
+static int rs_quarters(const std::vector<int> &p, uint64_t tlo, uint64_t thi, int L, const SctStarts<W> &st, int tier, bool *pair_ok) {
+    const int bl = (int)p.size();
+    int b = rs_family<E, W>(sct_family_rt(SCT_F_H1, bl), p, tlo, thi, L, st, pair_ok);
+    if (E >= 1 && tier >= 1) b = std::min(b, rs_family<E, W>(sct_family_rt(SCT_F_H2, bl), p, tlo, thi, L, st, pair_ok));
+    if (E >= 2 && tier >= 2)
+        for (int f = SCT_F_MID; f <= SCT_F_03; f++) b = std::min(b, rs_family<E, W>(sct_family_rt(f, bl), p, tlo, thi, L, st, pair_ok));
+    return b;
+}
+template <int E, typename W>
+static int rs_thirds(const std::vector<int> &p, uint64_t tlo, uint64_t thi, int L, const SctStarts<W> &st, int tier, bool *pair_ok) {
+    int b = rs_family<E, W>(SctFamily<SCT_F_T01>{}, p, tlo, thi, L, st, pair_ok);
+    if (E >= 1 && tier >= 1) {
+        b = std::min(b, rs_family<E, W>(SctFamily<SCT_F_T12>{}, p, tlo, thi, L, st, pair_ok));
+        b = std::min(b, rs_family<E, W>(SctFamily<SCT_F_T02>{}, p, tlo, thi, L, st, pair_ok));
+    }
+    return b;
+}
+template <int WF, typename W>
+static int rs_wide_family(const std::vector<int> &p, uint64_t tlo, uint64_t thi, int L, const SctStarts<W> &st) {
+    uint64_t plo, phi;
+    planes(p, plo, phi);
+    EmArray<W> em;
+    const W va = sct_valid_mask<W>(L), ve = va & ~(W)1, l1 = (W)tlo << 1, h1 = (W)thi << 1;
+    em.m[0] = ~l1 & ~h1 & ve; em.m[1] = l1 & ~h1 & ve; em.m[2] = ~l1 & h1 & ve; em.m[3] = l1 & h1 & ve;
+    uint32_t code = 0;
+    for (int j = 0; j < 16; j++) code |= (uint32_t)p[j] << (2 * j);
+    const uint32_t pkey = sct_wide_pattern_key(WF, (uint32_t)plo, (uint32_t)phi);
+    const typename SctWide<WF>::Base fam{};
+    int best = 3;
+    sct_for_each_wide_placement<WF>(L, [&](int a, int b, int u) {
+        if (sct_wide_key<WF, W>((W)tlo, (W)thi, a, b, u) != pkey) return;
+        best = std::min(best, wm_anchored_rest_rs<2, W>(fam, em, va, st, sct_rest_of(fam, code), a, b));
+    });
+    return best;
+}
+template <typename W>
+static int rs_wide(const std::vector<int> &p, uint64_t tlo, uint64_t thi, int L, const SctStarts<W> &st, int tier) {
+    int b = rs_wide_family<0, W>(p, tlo, thi, L, st);
+    if (tier >= 1) {
+        b = std::min(b, rs_wide_family<1, W>(p, tlo, thi, L, st));
+        b = std::min(b, rs_wide_family<3, W>(p, tlo, thi, L, st));
+        b = std::min(b, rs_wide_family<4, W>(p, tlo, thi, L, st));
+    }
+    if (tier >= 2) {
+        b = std::min(b, rs_wide_family<2, W>(p, tlo, thi, L, st));   b = std::min(b, rs_wide_family<5, W>(p, tlo, thi, L, st));
+        b = std::min(b, rs_wide_family<6, W>(p, tlo, thi, L, st));   b = std::min(b, rs_wide_family<7, W>(p, tlo, thi, L, st));
+        b = std::min(b, rs_wide_family<8, W>(p, tlo, thi, L, st));   b = std::min(b, rs_wide_family<9, W>(p, tlo, thi, L, st));
+        b = std::min(b, rs_wide_family<10, W>(p, tlo, thi, L, st));  b = std::min(b, rs_wide_family<11, W>(p, tlo, thi, L, st));
+        b = std::min(b, rs_wide_family<12, W>(p, tlo, thi, L, st));  b = std::min(b, rs_wide_family<13, W>(p, tlo, thi, L, st));
+        b = std::min(b, rs_wide_family<14, W>(p, tlo, thi, L, st));  b = std::min(b, rs_wide_family<15, W>(p, tlo, thi, L, st));
+    }
+    return b;
+}
+// one text (codes t, "not ACGT" flags bad), prefix length k, every scheme: the anchored minimum under restricted starts must be the
+// restricted DP's value where that is <= E (tier by tier: a minimum of 0 after the first tier, of 1 after the second), more otherwise
+template <int E, typename W>
+static bool check_restricted(const std::vector<int> &p, const std::vector<int> &t, uint64_t bad, int k) {
+    const int L = (int)t.size();
+    uint64_t tlo, thi;
+    planes(t, tlo, thi);
+    const W va = sct_valid_mask<W>(L);
+    const W a0 = sct_allowed_starts<W>((W)bad, L, k);
+    // the definition, byte by byte
+    uint64_t want_a0 = 0;
+    for (int s = 0; s + k <= L; s++) {
+        bool ok = true;
+        for (int q = 0; q < k; q++) ok = ok && !((bad >> (s + q)) & 1);
+        if (ok && s < (int)(8 * sizeof(W))) want_a0 |= 1ull << s;
+    }
+    if ((uint64_t)a0 != (want_a0 & (uint64_t)~(W)0)) { printf("FAIL allowed starts L=%d k=%d\n", L, k); return false; }
+    SctStarts<W> st;
+    st.from_allowed(a0, va);
+    const int want = brute_restricted(p, t, want_a0);
+    bool pair_ok = true;
+    const int bl = (int)p.size();
+    for (int tier = 0; tier <= E; tier++) {
+        const int got = rs_quarters<E, W>(p, tlo, thi, L, st, tier == E ? 2 : tier, &pair_ok);
+        if (want <= tier ? got != want : (tier == E && got <= E)) { printf("FAIL restricted quarters E=%d bl=%d L=%d k=%d tier=%d want=%d got=%d\n", E, bl, L, k, tier, want, got); return false; }
+        if (want > tier && got < std::min(want, E + 1)) { printf("FAIL restricted quarters: %d below the DP's %d\n", got, want); return false; }
+    }
+    if (bl == 16 && E <= 1) {
+        for (int tier = 0; tier <= E; tier++) {
+            const int got = rs_thirds<E, W>(p, tlo, thi, L, st, tier, &pair_ok);
+            if (want <= tier ? got != want : (tier == E && got <= E)) { printf("FAIL restricted thirds E=%d L=%d k=%d tier=%d want=%d got=%d\n", E, L, k, tier, want, got); return false; }
+        }
+    }
+    if (bl == 16 && E == 2) {
+        for (int tier = 0; tier <= 2; tier++) {
+            const int got = rs_wide<W>(p, tlo, thi, L, st, tier);
+            if (want <= tier ? got != want : (tier == 2 && got <= 2)) { printf("FAIL restricted wide L=%d k=%d tier=%d want=%d got=%d\n", L, k, tier, want, got); return false; }
+        }
+    }
+    if (!pair_ok) { printf("FAIL restricted: packed pair differs from the plain automaton (E=%d bl=%d L=%d k=%d)\n", E, bl, L, k); return false; }
+    return true;
+}
+// a long text cut into windows of 63 characters, `step` = 63 - (bl + E - 1) apart, each owning the starts in its first `step`
+// characters (the last one: all of its own): the minimum over the windows is the restricted DP's value over the whole text
+template <int E>
+static bool check_windows(const std::vector<int> &p, const std::vector<int> &t, const std::vector<int> &badv, int k) {
+    const int bl = (int)p.size(), L = (int)t.size(), ov = bl + E - 1, step = 63 - ov;
+    const int nwin = L <= 63 ? 1 : (L - ov + step - 1) / step;
+    // the DP over the whole text (allowed starts as a vector: the text is longer than a word)
+    const int BIG = 1000;
+    std::vector<int> prev(bl + 1), cur(bl + 1);
+    auto allowed = [&](int s) {
+        if (s + k > L) return false;
+        for (int q = 0; q < k; q++) if (badv[s + q]) return false;
+        return true;
+    };
+    prev[0] = allowed(0) ? 0 : BIG;
+    for (int i = 1; i <= bl; i++) prev[i] = std::min(BIG, prev[i - 1] + 1);
+    int want = prev[bl];
+    for (int j = 1; j <= L; j++) {
+        cur[0] = std::min(allowed(j) ? 0 : BIG, prev[0] + 1);
+        for (int i = 1; i <= bl; i++) cur[i] = std::min({prev[i - 1] + (p[i - 1] != t[j - 1]), prev[i] + 1, cur[i - 1] + 1, BIG});
+        want = std::min(want, cur[bl]);
+        std::swap(prev, cur);
+    }
+    int got = E + 1;
+    bool pair_ok = true;
+    for (int w = 0; w < nwin; w++) {
+        const int w0 = w * step, wl = std::min(63, L - w0);
+        if (w == nwin - 1 && w0 + wl != L) { printf("FAIL windows do not cover the text L=%d\n", L); return false; }
+        std::vector<int> tw(t.begin() + w0, t.begin() + w0 + wl);
+        uint64_t bad = 0;
+        for (int i = 0; i < wl; i++) bad |= (uint64_t)badv[w0 + i] << i;
+        uint64_t tlo, thi;
+        planes(tw, tlo, thi);
+        const uint64_t va = sct_valid_mask<uint64_t>(wl);
+        // s + k <= L for the ROW; inside a window that is not the last every owned start has k more characters in the window
+        uint64_t a0 = sct_allowed_starts<uint64_t>(bad, wl, k);
+        if (w != nwin - 1) a0 &= (1ull << step) - 1;
+        SctStarts<uint64_t> st;
+        st.from_allowed(a0, va);
+        got = std::min(got, rs_quarters<E, uint64_t>(p, tlo, thi, wl, st, 2, &pair_ok));
+    }
+    if (std::min(want, E + 1) != got) { printf("FAIL windows E=%d bl=%d L=%d k=%d want=%d got=%d\n", E, bl, L, k, want, got); return false; }
+    if (!pair_ok) { printf("FAIL windows: packed pair differs\n"); return false; }
+    return true;
+}
+
 int main(int argc, char **argv) {
     // argv[1]: divisor of the random-case counts of sections 2 - 2c (the sanitizer build runs a quarter of them)
     const int scale = argc > 1 && atoi(argv[1]) > 0 ? atoi(argv[1]) : 1;
@@ -971,6 +1161,55 @@ int main(int argc, char **argv) {
         if (!ok) return 1;
         if (n_join < 100000) { printf("FAIL join compare: only %ld placements with a matching key\n", n_join); return 1; }
         checked += n_join;
+    }
+    // 10. restricted starts (the reference's raw-byte prefix rule, scTagger.py:681) and rows cut into windows: planted copies
+    //     with 0..3 edits, bad bytes sprinkled over the text, k = 0..3; 32- and 64-bit masks, barcode lengths 8..16
+    {
+        auto plant = [&](int bl, int lmin, int lmax, std::vector<int> &p, std::vector<int> &t, std::vector<int> &badv) {
+            const int alpha = rnd(5) == 0 ? 2 : 4;
+            p.resize(bl);
+            for (auto &x : p) x = rnd(alpha);
+            const int L = lmin + rnd(lmax - lmin + 1);
+            t.resize(L);
+            for (auto &x : t) x = rnd(alpha);
+            std::vector<int> core = p;
+            for (int e = rnd(4); e > 0 && !core.empty(); e--) {
+                const int kind = rnd(3), at = rnd((int)core.size() + (kind == 1 ? 1 : 0));
+                if (kind == 0 && at < (int)core.size()) core[at] = rnd(alpha);
+                else if (kind == 1) core.insert(core.begin() + at, rnd(alpha));
+                else if (at < (int)core.size()) core.erase(core.begin() + at);
+            }
+            if ((int)core.size() <= L) {
+                const int at = rnd(L - (int)core.size() + 1);
+                std::copy(core.begin(), core.end(), t.begin() + at);
+            }
+            badv.assign(L, 0);
+            const int nbad = rnd(4) == 0 ? 0 : 1 + rnd(3);
+            for (int i = 0; i < nbad && L > 0; i++) {
+                const int at = rnd(L);
+                badv[at] = 1;
+                t[at] = 0;   // map_char: a byte outside ACGT matches as A
+            }
+        };
+        for (int it = 0; it < 120000 / scale; it++) {
+            const int bl = it % 3 == 0 ? 8 + rnd(9) : 16, k = rnd(4);
+            std::vector<int> p, t, badv;
+            plant(bl, bl - 2, it % 2 ? 31 : 63, p, t, badv);
+            uint64_t bad = 0;
+            for (size_t i = 0; i < t.size(); i++) bad |= (uint64_t)badv[i] << i;
+            bool ok;
+            if (t.size() <= 31) ok = check_restricted<0, uint32_t>(p, t, bad, k) && check_restricted<1, uint32_t>(p, t, bad, k) && check_restricted<2, uint32_t>(p, t, bad, k);
+            else ok = check_restricted<0, uint64_t>(p, t, bad, k) && check_restricted<1, uint64_t>(p, t, bad, k) && check_restricted<2, uint64_t>(p, t, bad, k);
+            if (!ok) return 1;
+            checked++;
+        }
+        for (int it = 0; it < 30000 / scale; it++) {
+            const int bl = it % 3 == 0 ? 8 + rnd(9) : 16, k = rnd(4);
+            std::vector<int> p, t, badv;
+            plant(bl, 40, 400, p, t, badv);
+            if (!check_windows<1>(p, t, badv, k) || !check_windows<2>(p, t, badv, k)) return 1;
+            checked++;
+        }
     }
     printf("OK %ld cases\n", checked);
     return 0;
