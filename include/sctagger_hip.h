@@ -207,8 +207,11 @@ int sct_last_timing_ex(sct_ctx *ctx, const char **names, float *ms, int32_t *lau
  * path, [2] segments on the restricted-start (non-ACGT, k>0) path, [3] total hits, [4] segments the filter path
  * retried with larger lists (more than 6 or 8 verified matches, by the seed tables in use), [5] the seed scheme the filter path
  * used (SCT_SCHEME_*), [6] bits 0..31: batches whose 32-bit rows the partitioned join did (thirds scheme at max_err = 1), bits
- * 32..39: batches the join handed back to the filter kernel (a tuple region overflowed). Fills up to cap entries; returns the
- * number of counters there are (7), or <0. */
+ * 32..39: batches the join handed back to the filter kernel (a tuple region overflowed), [7] segments (counted in [0]) that the
+ * seed filter took in its SPECIAL launch: rows with a byte outside ACGT while the reference's prefix length k > 0 (restricted window
+ * starts, scTagger.py:681) and rows of more than 63 characters (cut into overlapping 63-character windows, up to 16 of them:
+ * 753 characters at bl = 16, max_err = 2); only what that launch cannot hold reaches [1] / [2]. Fills up to cap entries; returns
+ * the number of counters there are (8), or <0. */
 enum {
     SCT_SCHEME_NONE = 0,            /* no seed filter: every row went to the exhaustive scan / restricted-start DP */
     SCT_SCHEME_QUARTER_SLOTS = 1,   /* six 16-bit quarter-pair families answered from 8-byte bucket slots (small barcode sets) */

@@ -336,11 +336,13 @@ class Matcher:
         return strand[:n], dist[:n], loc_offs, locs
 
     def last_stats(self):
-        out = (ctypes.c_int64 * 7)()
-        k = self._lib.sct_last_stats(self._ctx, out, 7)
+        out = (ctypes.c_int64 * 8)()
+        k = self._lib.sct_last_stats(self._ctx, out, 8)
         if k < 0:
             self._check(k)
         return {"filter": out[0], "exhaustive": out[1], "restricted_start": out[2], "hits": out[3], "retried": out[4],
                 "scheme": SCHEME_NAMES.get(int(out[5]), str(out[5])),
+                # rows (of "filter") the seed filter took in its special launch: restricted window starts, more than 63 characters
+                "special": out[7],
                 # batches of the call that went through the partitioned join / that the join handed back to the filter kernel
                 "join_batches": int(out[6]) & 0xFFFFFFFF, "join_fallbacks": (int(out[6]) >> 32) & 0xFF, "join_overflow_bits": int(out[6]) >> 40}

@@ -7,6 +7,7 @@ struct SctFilterVariant {
     bool thirds;  // the 20/22-bit families of very large barcode sets (max_err <= 1)
     bool wide;    // the sixteen 20-bit families of large barcode sets (max_err = 2)
     bool only64;  // main launch: the 64-bit instantiation only (the partitioned join, k_join.hip.h, has done the 32-bit rows)
+    bool special; // the special launch: the retry launch's shape over list_special, restricted starts and rows cut into windows
 };
 template <typename OffT>
 struct FilterArgs;

@@ -25,7 +25,7 @@ void launch(const SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, un
     // both mask widths are launched over all rows; a wave leaves a group of rows at once if it is not its kind (k_filter).
     // g = grid of the 32-bit instantiation, g64 = the (smaller, striding) grid of the 64-bit one; the striding launches
     // (every one but the main launch's 32-bit instantiation) run one wave per block (FilterWavesPerBlock)
-    if (!v.retry) {
+    if (!v.retry && !v.special) {
         if (v.rt) {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, true, false, OffT><<<g, 256, 0, st>>>(fa);
             k_filter<E, uint64_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, true, false, OffT><<<g64, 64, 0, st>>>(fa);
@@ -45,6 +45,27 @@ void launch(const SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, un
         } else {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
             k_filter<E, uint64_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+        }
+    } else if (v.special) {
+        if (v.rt) {
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT, true><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT, true><<<g64, 64, 0, st>>>(fa);
+        } else if (v.thirds) {
+            if constexpr (E <= 1) {
+                k_filter<E, uint32_t, SCHEME_THIRDS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g, 64, 0, st>>>(fa);
+                k_filter<E, uint64_t, SCHEME_THIRDS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g64, 64, 0, st>>>(fa);
+            }
+        } else if (v.wide) {
+            if constexpr (E == 2) {
+                k_filter<E, uint32_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g, 64, 0, st>>>(fa);
+                k_filter<E, uint64_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g64, 64, 0, st>>>(fa);
+            }
+        } else if (v.slots) {
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, RETRY_RPW_SL, false, true, OffT, true><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, RETRY_RPW_SL, false, true, OffT, true><<<g64, 64, 0, st>>>(fa);
+        } else {
+            k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g, 64, 0, st>>>(fa);
+            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g64, 64, 0, st>>>(fa);
         }
     } else {
         if (v.rt) {

@@ -22,7 +22,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 //   lo, hi   planes of map_char's code (scTagger.py:512-516): any byte that is not A, C, G or T decodes to 0 = 'A'
 //   nonacgt  the row holds such a byte
 template <typename W, typename Fetch>
-__device__ __forceinline__ void sct_decode_words(Fetch &&fetch, int skip, int len, W &lo, W &hi, bool &nonacgt) {
+__device__ __forceinline__ void sct_decode_words_mask(Fetch &&fetch, int skip, int len, W &lo, W &hi, W &bad) {
     constexpr int MAXC = sizeof(W) == 4 ? 31 : 63;
     constexpr int MAXW = (MAXC + 3 + 3) / 4;        // words covering MAXC characters at the worst misalignment: 9 / 17
     constexpr int NR = (MAXW + 7) / 8;              // 32-bit registers per raw plane (8 nibbles each): 2 / 3
@@ -45,7 +45,6 @@ __device__ __forceinline__ void sct_decode_words(Fetch &&fetch, int skip, int le
     }
     // character i sits at raw bit i + skip
     const W keep = len >= (int)(8 * sizeof(W)) ? ~(W)0 : (((W)1 << len) - 1);
-    W bad;
     if constexpr (sizeof(W) == 4) {
         lo = (W)__builtin_amdgcn_alignbit(rl[1], rl[0], (uint32_t)skip) & keep;
         hi = (W)__builtin_amdgcn_alignbit(rh[1], rh[0], (uint32_t)skip) & keep;
@@ -55,6 +54,11 @@ __device__ __forceinline__ void sct_decode_words(Fetch &&fetch, int skip, int le
         hi = ((W)__builtin_amdgcn_alignbit(rh[1], rh[0], (uint32_t)skip) | ((W)__builtin_amdgcn_alignbit(rh[2], rh[1], (uint32_t)skip) << 32)) & keep;
         bad = ((W)__builtin_amdgcn_alignbit(rb[1], rb[0], (uint32_t)skip) | ((W)__builtin_amdgcn_alignbit(rb[2], rb[1], (uint32_t)skip) << 32)) & keep;
     }
+}
+template <typename W, typename Fetch>
+__device__ __forceinline__ void sct_decode_words(Fetch &&fetch, int skip, int len, W &lo, W &hi, bool &nonacgt) {
+    W bad;
+    sct_decode_words_mask<W>(fetch, skip, len, lo, hi, bad);
     nonacgt = bad != 0;
 }
 
@@ -69,6 +73,15 @@ __device__ __forceinline__ void sct_decode_row(const uint8_t *__restrict__ segs,
     // (an address computed as an integer loses its address space: say "global" again, or the loads are issued as flat ones)
     const __attribute__((address_space(1))) uint32_t *wp = (const __attribute__((address_space(1))) uint32_t *)(at & ~(uintptr_t)3);
     sct_decode_words<W>([&](int k) { return __builtin_nontemporal_load(wp + k); }, (int)(at & 3), len, lo, hi, nonacgt);
+}
+
+// ... and with the mask of the bytes that are not one of ACGT (bit i = character i): the special launch derives the allowed
+// window starts from it (sct_allowed_starts, sct_core.h)
+template <typename W>
+__device__ __forceinline__ void sct_decode_row_mask(const uint8_t *__restrict__ segs, int64_t start, int len, W &lo, W &hi, W &bad) {
+    const uintptr_t at = (uintptr_t)segs + (uintptr_t)start;
+    const __attribute__((address_space(1))) uint32_t *wp = (const __attribute__((address_space(1))) uint32_t *)(at & ~(uintptr_t)3);
+    sct_decode_words_mask<W>([&](int k) { return __builtin_nontemporal_load(wp + k); }, (int)(at & 3), len, lo, hi, bad);
 }
 
 // The wave's rows through LDS: in CSR order the rows of a wave are one contiguous stretch of bytes [span_lo, span_hi).

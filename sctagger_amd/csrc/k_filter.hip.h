@@ -174,7 +174,8 @@ struct FamTables {
 };
 
 // WIDE: the placement table holds (t, t2, u) triples of the wide families (sct_core.h), up to 9 combinations of shifts
-template <typename W, int HM, int QC, bool WIDE = false>
+// SP: the special launch (below, filter_rows) — one more array, the start masks of every lane's text
+template <typename W, int HM, int QC, bool WIDE = false, bool SP = false>
 struct FilterWaveLds {
     static constexpr int QCAP = QC;
     typedef typename std::conditional<WIDE || sizeof(W) == 8, uint32_t, uint16_t>::type PtabT;
@@ -194,6 +195,7 @@ struct FilterWaveLds {
     alignas(16) uint32_t hlist[HM][64];  // hlist, qk and qm double as the stage of the ASCII decode (k_decode.hip.h)
     uint32_t qk[QCAP];   // queue: global table entry index f*np + k
     uint32_t qm[QCAP];   //        lane | t << 8 | t2 << 16
+    W al[SP ? 64 : 0][4];  // SP: al[lane][d] = A_d of the lane's text (SctStarts, sct_core.h); no bytes otherwise
 };
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t m) {  // number of set bits of m below this lane
@@ -214,6 +216,16 @@ struct EmLds {
     }
 };
 
+template <typename W>
+struct AlLds {   // d -> A_d of one lane's text (restricted starts), read from LDS
+    uint32_t base;
+    __device__ __forceinline__ explicit AlLds(const W *p)
+        : base((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) W *)p) {}
+    __device__ __forceinline__ W operator()(int d) const {
+        return *(const __attribute__((address_space(3))) W *)(uintptr_t)(base + (uint32_t)d * (uint32_t)sizeof(W));
+    }
+};
+
 // Bucket slots (SL = true, the quarter families): one 8-byte word per key that answers most lookups by itself.
 //   bit 15 clear: bits 0..1 = n <= 3 entries in the bucket, bits 16j+16 .. 16j+31 = the REST characters of entry j
 //                 (sct_rest_of: all the verification needs besides the key); no other table is read unless the
@@ -225,8 +237,11 @@ struct EmLds {
 static constexpr uint32_t QM_INLINE = 0x80000000u;
 static constexpr size_t SLOT_TOTAL = (size_t)SCT_NFAM * (SCT_KEYS + 1);  // slots of the six quarter families
 
-template <int E, typename W, int HM, bool SL, int RPW = 64, bool WIDE = false, bool THIRDS = false>
+template <int E, typename W, int HM, bool SL, int RPW = 64, bool WIDE = false, bool THIRDS = false, bool SP = false>
 struct FilterWave {
+    // SP (special launch): the lanes are WINDOWS of the wave's RPW rows, lane = window * RPW + row; minimum, hit count and hit
+    // list belong to the row
+    __device__ static __forceinline__ uint32_t row_of(uint32_t src) { return SP ? (src & (uint32_t)(RPW - 1)) : src; }
     static constexpr int HMAX = HM;
     // hit list entries per row: the LDS array hlist[HM][64] is shared out among the wave's RPW rows, entry k of row r at
     // [k * RPW + r] — HM per row in the main launch (64 rows), four times as many in the retry launch (16 rows)
@@ -244,7 +259,7 @@ struct FilterWave {
         if constexpr (WIDE) return LOC_INLINE | ((((wf_ << 20) | (meta_kb4(mx) << 16) | key) << LOC_J_BITS) | j);
         else return LOC_INLINE | ((ft.off_base[fam.INDEX] + key) << LOC_J_BITS) | j;
     }
-    FilterWaveLds<W, HM, QCAP, WIDE> &L;
+    FilterWaveLds<W, HM, QCAP, WIDE, SP> &L;
     const uint32_t *__restrict__ tab_off;
     const uint32_t *__restrict__ tab_ent;   // pattern id of every table entry
     const uint32_t *__restrict__ tab_code;  // the same entries as 2-bit codes, character j at bits 2j..2j+1
@@ -284,7 +299,8 @@ struct FilterWave {
     __device__ static __forceinline__ bool overflowed(uint32_t hc, uint32_t best) {
         return best <= (uint32_t)E && ((hc >> (HCNT_OVERFLOW_SHIFT + best)) & 1u) != 0u;
     }
-    __device__ __forceinline__ void insert_hit(uint32_t src, uint32_t d, uint32_t loc) {
+    __device__ __forceinline__ void insert_hit(uint32_t seg_lane, uint32_t d, uint32_t loc) {
+        const uint32_t src = row_of(seg_lane);
         if constexpr (SL) {
             // bucket slots = small barcode sets (up to ~40 k): a row sees few candidates besides the right one, the plain
             // list is enough and 4 % faster at 25 k barcodes (3.16 vs 3.28 ms per 10 M rows)
@@ -340,7 +356,7 @@ struct FilterWave {
 
     template <typename Fam>
     __device__ __forceinline__ void verify2(const Fam &fam, uint32_t nq) {  // the nq <= 128 entries from head
-        using Lds = FilterWaveLds<W, HM, QCAP, WIDE>;
+        using Lds = FilterWaveLds<W, HM, QCAP, WIDE, SP>;
         static_assert(__builtin_offsetof(Lds, qm) == __builtin_offsetof(Lds, qk) + 4 * QCAP && __builtin_offsetof(Lds, qk) % 8 == 0,
                       "the ring runs over qk and qm");
         const uint2 pr = *reinterpret_cast<const uint2 *>(&ring()[(head + 2u * (uint32_t)lane) & (RING - 1)]);
@@ -349,8 +365,13 @@ struct FilterWave {
         const uint32_t sx = (ex >> 16) & 63u, sy = (ey >> 16) & 63u;
         const int tx = (int)((ex >> 22) & 31u), ty = (int)((ey >> 22) & 31u);
         const int t2x = tx + fam.GAP + (int)((ex >> 27) & 7u) - fam.SLACK, t2y = ty + fam.GAP + (int)((ey >> 27) & 7u) - fam.SLACK;
-        const uint32_t r = wm_anchored_pair<E>(fam, EmLds<W>(&L.em[sx][0]), EmLds<W>(&L.em[sy][0]), (uint32_t)L.va[sx],
-                                               (uint32_t)L.va[sy], ex, ey, tx, t2x, ty, t2y);
+        uint32_t r;
+        if constexpr (SP)
+            r = wm_anchored_pair<E>(fam, EmLds<W>(&L.em[sx][0]), EmLds<W>(&L.em[sy][0]), (uint32_t)L.va[sx], (uint32_t)L.va[sy], ex, ey, tx, t2x,
+                                    ty, t2y, AlLds<W>(&L.al[sx][0]), AlLds<W>(&L.al[sy][0]));
+        else
+            r = wm_anchored_pair<E>(fam, EmLds<W>(&L.em[sx][0]), EmLds<W>(&L.em[sy][0]), (uint32_t)L.va[sx], (uint32_t)L.va[sy], ex, ey, tx, t2x,
+                                    ty, t2y);
         const uint32_t dx = r & 0xFFFFu, dy = r >> 16;
         if (vx && dx <= (uint32_t)E) record(fam, ex, dx);
         if (vy && dy <= (uint32_t)E) record(fam, ey, dy);
@@ -378,8 +399,12 @@ struct FilterWave {
             const uint32_t sx = mx & 63u, sy = my & 63u;
             const int tx = (int)((mx >> 8) & 63u), t2x = (int)((mx >> 16) & 63u);
             const int ty = (int)((my >> 8) & 63u), t2y = (int)((my >> 16) & 63u);
-            const uint32_t r = wm_anchored_pair<E>(fam, EmLds<W>(&L.em[sx][0]), EmLds<W>(&L.em[sy][0]), va_of(sx), va_of(sy), rx, ry,
-                                                   tx, t2x, ty, t2y);
+            uint32_t r;
+            if constexpr (SP)
+                r = wm_anchored_pair<E>(fam, EmLds<W>(&L.em[sx][0]), EmLds<W>(&L.em[sy][0]), va_of(sx), va_of(sy), rx, ry, tx, t2x, ty, t2y,
+                                        AlLds<W>(&L.al[sx][0]), AlLds<W>(&L.al[sy][0]));
+            else
+                r = wm_anchored_pair<E>(fam, EmLds<W>(&L.em[sx][0]), EmLds<W>(&L.em[sy][0]), va_of(sx), va_of(sy), rx, ry, tx, t2x, ty, t2y);
             const uint32_t dx = r & 0xFFFFu, dy = r >> 16;
             // what is kept is the entry's LOCATOR; the pattern ids are read once, when the segment is finished
             if (dx <= (uint32_t)E) {
@@ -422,7 +447,7 @@ struct FilterWave {
     // H1 + H2 every barcode at distance <= 1 (one half is untouched).  A segment whose minimum is already settled
     // stops generating candidates for the later families — only the minimum tier is reported.
     __device__ __forceinline__ void settle(uint32_t tier) {
-        if (active && L.best[lane] <= tier) active = false;
+        if (active && L.best[row_of((uint32_t)lane)] <= tier) active = false;
     }
 
     // Once every candidate closer than E has been seen (after settle(E - 1)) a minimum of E is final, and so is the overflow mark of
@@ -430,7 +455,7 @@ struct FilterWave {
     // barcodes the rows whose minimum is two edits tie 40 - 90 ways: 11.5 % of the rows, and they are the ones that run all families.)
     __device__ __forceinline__ void give_up() {
         if constexpr (!SL) {
-            if (active && L.best[lane] == (uint32_t)E && overflowed(L.hcnt[lane], (uint32_t)E)) active = false;
+            if (active && L.best[row_of((uint32_t)lane)] == (uint32_t)E && overflowed(L.hcnt[row_of((uint32_t)lane)], (uint32_t)E)) active = false;
         }
     }
 
@@ -462,9 +487,6 @@ struct FilterWave {
                 }
             }
             uint64_t om = __ballot(!inl);
-#ifdef SCT_ABLATE_SPREAD  // timing-only build: long buckets are dropped (results are wrong)
-            om = 0;
-#endif
             while (om != 0) {  // a long bucket, spread over the lanes: lane i reads the code of entry first + i
                 const int src = __builtin_ctzll(om);
                 om &= om - 1;
@@ -574,7 +596,7 @@ struct FilterWave {
             const int need = sct_placement_need(fam, E, lane, t2);
             const bool ok = need <= maxlen;
             const uint64_t m = __ballot(ok);
-            if (ok) L.ptab[P + (int)lane_rank(m)] = (typename FilterWaveLds<W, HM, QCAP, WIDE>::PtabT)((uint32_t)lane | ((uint32_t)t2 << PF) | ((uint32_t)need << (2 * PF)));
+            if (ok) L.ptab[P + (int)lane_rank(m)] = (typename FilterWaveLds<W, HM, QCAP, WIDE, SP>::PtabT)((uint32_t)lane | ((uint32_t)t2 << PF) | ((uint32_t)need << (2 * PF)));
             P += (int)__popcll(m);
         }
         __builtin_amdgcn_wave_barrier();
@@ -633,10 +655,6 @@ struct FilterWave {
                 e = sv.y;
                 if constexpr (PK) meta = (sl << 16) | ((uint32_t)t << 22) | ((uint32_t)(t2 - t - fam.GAP + fam.SLACK) << 27);
                 else meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
-#ifdef SCT_ABLATE_PUSH  // timing-only build: the slot is loaded but nothing is queued
-                asm volatile("" ::"v"(s), "v"(e), "v"(meta));
-                s = e = 0;
-#endif
             } else if (worker && p < P) {
                 const uint32_t tt = L.ptab[p];
                 const int t = (int)(tt & PFM), t2 = (int)((tt >> PF) & PFM);
@@ -654,10 +672,6 @@ struct FilterWave {
                         e = op.b;
                     }
                     meta = sl | ((uint32_t)t << 8) | ((uint32_t)t2 << 16);
-#ifdef SCT_ABLATE_PUSH  // timing-only build: the bucket range is loaded but nothing is queued
-                    asm volatile("" ::"v"(s), "v"(e), "v"(meta));
-                    s = e = 0;
-#endif
                 }
             }
             p += dp;
@@ -1010,7 +1024,7 @@ struct FilterArgs {
     uint64_t *wave_base;          // main launch: where each wave's lists start in `slots`
     int32_t *list_defer;          // main launch: list_retry; retry launch: list_scan
     uint32_t *defer_count;
-    int32_t *list_long, *list_dp; // routing lists of the main launch (rows the filter cannot take)
+    int32_t *list_special;        // main launch: rows for the special launch (restricted starts, more than PLANE_MAX characters)
     uint32_t *ctr;                // the batch's counter record (CTR_*)
     unsigned long long *slot_cursor;
     unsigned long long *arena_cursors;   // main launch of a large batch: SLOT_ARENAS cursors, 64 bytes apart (NULL: the one slot_cursor)
@@ -1039,13 +1053,26 @@ static constexpr int SCHEME_QUARTERS = 0, SCHEME_THIRDS = 1, SCHEME_WIDE = 2;
 // COOP (main launch of the 32-bit instantiation, four waves per block): the block stages its 256 rows' bytes together
 // (sct_block_stage_load) in `block_lds`, the LDS of all four waves, which nothing else uses yet; `block_flags` = four bytes of LDS.
 // Every wave of the block must make the call, whether or not it has rows (the function synchronises the block).
-template <int E, typename W, int SCHEME, int KS, int HM, int RPW, bool RT, bool SL, typename OffT, bool COOP = false>
-__device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE> &L, int64_t first,
+//
+// SP = the SPECIAL launch (a third launch over the rows the main launch listed in list_special; listed rows, RPW rows per wave as
+// in the retry launch): the rows the planes of ONE lane cannot express as the reference sees them —
+//   * rows with a byte outside ACGT while the reference's prefix length k > 0: its window starts are restricted
+//     (scTagger.py:681; sct_core.h "Restricted starts"): every lane carries the start masks A_0..A_2 of its text;
+//   * rows of more than PLANE_MAX characters: cut into WINDOWS of PLANE_MAX characters, `step` = PLANE_MAX - (bl + E - 1) apart (an
+//     alignment within E edits spans at most bl + E characters, so it lies inside the window that owns its start: the window's
+//     first `step` characters, all of them in the row's last window).  Lane = window * RPW + row: the 64 / RPW lanes of a row
+//     look up and verify their windows like 64 / RPW segments and share the row's minimum and hit list (FilterWave::row_of).
+// Both at once is the general case: a window's allowed starts are its owned starts that the prefix rule allows.  Rows of more than
+// 64 / RPW windows (753 characters at bl = 16, E = 2) and rows whose lists overflow go on to list_long -> the scan kernels.
+template <int E, typename W, int SCHEME, int KS, int HM, int RPW, bool RT, bool SL, typename OffT, bool COOP = false, bool SP = false>
+__device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE, SP> &L, int64_t first,
                                             int64_t n, uint32_t *block_lds = nullptr, int block_lds_bytes = 0, uint8_t *block_flags = nullptr) {
+    static_assert(!SP || (RPW < 64 && !COOP), "the special launch works on listed rows, several lanes per row");
     const int bl = RT ? a.bl : 16;
     const int lane = threadIdx.x & 63;
-    const int64_t gid = first + lane;
-    const bool inrange = lane < RPW && gid < n;
+    const int win = SP ? lane / RPW : 0;                       // SP: which window of its row this lane is
+    const int64_t gid = first + (SP ? (lane & (RPW - 1)) : lane);
+    const bool inrange = (SP || lane < RPW) && gid < n;
     int64_t r = gid;
     if (inrange && a.rows) r = a.rows[gid];  // a retried row: listed explicitly
     int64_t start = 0, len64 = 0;
@@ -1053,8 +1080,20 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     const int len_all = (int)(len64 < 0x7FFFFFFF ? len64 : 0x7FFFFFFF);
     // rows the filter can take by their length: at least bl - E characters (shorter ones cannot match anything: every
     // window the reference inserts is at least that long, scTagger.py:681) and at most PLANE_MAX
-    const bool fits = inrange && len_all >= bl - E && len_all <= PLANE_MAX;
+    bool fits = inrange && len_all >= bl - E && len_all <= PLANE_MAX;
     int len = fits ? len_all : 0;
+    // SP: the lane's window of the row
+    const int sp_ov = bl + E - 1, sp_step = PLANE_MAX - sp_ov;
+    const int nwin = len_all <= PLANE_MAX ? 1 : (len_all - sp_ov + sp_step - 1) / sp_step;
+    const bool toolong = SP && inrange && nwin > 64 / RPW;
+    [[maybe_unused]] const int64_t row_start = start;
+    if constexpr (SP) {
+        const int w0 = win * sp_step;
+        const int wlen = (inrange && win < nwin && !toolong) ? (len_all - w0 < PLANE_MAX ? len_all - w0 : PLANE_MAX) : 0;
+        fits = wlen >= bl - E;
+        len = fits ? wlen : 0;
+        start += w0;
+    }
     const int maxlen = wave_max_i(len);
     // W = uint32_t handles the waves whose longest such row has at most 31 characters (waves without any included:
     // their rows still have to be routed), W = uint64_t the others; a wave leaves at once if it is not its kind
@@ -1063,6 +1102,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     W lo, hi;
     bool nonacgt;
     bool decoded = false;
+    [[maybe_unused]] W badmask = 0;
     if constexpr (COOP) {
         static_assert(RPW == 64, "the cooperative stage belongs to the main launch");
         const int widx = (int)(threadIdx.x >> 6);
@@ -1089,8 +1129,17 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     }
     if (!mykind) return;
     if (!anyrow) return;
+    if constexpr (SP) {
+        if (toolong && win == 0) {   // more windows than the row has lanes: the scan kernels (via k_route_long).  (Such a row adds
+            a.list_defer[atomicAdd(a.defer_count, 1u)] = (int32_t)r;   // nothing to the wave's longest text, so exactly one of the
+            a.cnt[r] = CNT_DEFER;                                       // two mask widths gets here with it.)
+        }
+        sct_decode_row_mask<W>(a.segs, start, len, lo, hi, badmask);
+        nonacgt = badmask != 0;
+        decoded = true;
+    }
     if (!decoded) {
-        using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE>;
+        using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE, SP>;
         static_assert(__builtin_offsetof(Lds, qk) == __builtin_offsetof(Lds, hlist) + 4 * 64 * HM &&
                           __builtin_offsetof(Lds, qm) == __builtin_offsetof(Lds, qk) + 4 * Lds::QCAP && __builtin_offsetof(Lds, hlist) % 16 == 0,
                       "hlist, qk and qm form the decode stage");
@@ -1101,7 +1150,18 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     }
     if (__ballot(nonacgt) != 0) {
         // rare: is one of the offending bytes >= 128?  The reference raises when it reads one (sct_byte_is_read, sct_core.h)
-        if (nonacgt) {
+        if constexpr (SP) {
+            // rows of at most PLANE_MAX characters were checked by the main launch that listed them; of a longer row every window
+            // checks the bytes it owns, against the ROW (a byte is read iff some window the reference inserts covers it)
+            if (nonacgt && len_all > PLANE_MAX) {
+                const int own = win == nwin - 1 ? len : (len < sp_step ? len : sp_step);
+                for (int i = 0; i < own; i++)
+                    if (a.segs[start + i] >= 128 && sct_byte_is_read(a.segs + row_start, len_all, (int64_t)win * sp_step + i, bl, E, a.prefix_len)) {
+                        atomicMin(reinterpret_cast<unsigned long long *>(a.ctr + CTR_BAD_BYTE), (unsigned long long)(start + i));
+                        break;
+                    }
+            }
+        } else if (nonacgt) {
             for (int i = 0; i < len; i++)
                 if (a.segs[start + i] >= 128 && sct_byte_is_read(a.segs + start, len, i, bl, E, a.prefix_len)) {
                     atomicMin(reinterpret_cast<unsigned long long *>(a.ctr + CTR_BAD_BYTE), (unsigned long long)(start + i));
@@ -1117,16 +1177,17 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         // routing (main launch): what k_pack did in round 1
         if (!line && a.cnt8 && (!fits || (nonacgt && a.prefix_len > 0))) a.cnt8[r] = 0;  // with `line` the wave's store covers them
         if (!fits) {
-            if (len_all > PLANE_MAX) {  // not representable in the planes: the exhaustive scan or the DP takes the row
-                a.list_long[atomicAdd(&a.ctr[CTR_LONG], 1u)] = (int32_t)r;
+            if (len_all > PLANE_MAX) {  // more characters than one lane's planes hold: the special launch cuts the row into windows
+                a.list_special[atomicAdd(&a.ctr[CTR_SPECIAL], 1u)] = (int32_t)r;
                 a.cnt[r] = CNT_DEFER;
             } else {
                 if (!line) a.min_e[r] = SCT_NO_HIT;
                 a.cnt[r] = 0;
             }
         } else if (nonacgt && a.prefix_len > 0) {
-            // the reference drops every window whose first k raw bytes are not all in ACGT (scTagger.py:681): restricted-start DP
-            a.list_dp[atomicAdd(&a.ctr[CTR_DP], 1u)] = (int32_t)r;
+            // the reference drops every window whose first k raw bytes are not all in ACGT (scTagger.py:681): the special launch
+            // runs the same families with restricted starts
+            a.list_special[atomicAdd(&a.ctr[CTR_SPECIAL], 1u)] = (int32_t)r;
             a.cnt[r] = CNT_DEFER;
             active = false;
         }
@@ -1149,6 +1210,19 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     L.em[lane][2] = ~l1 & h1 & ve;
     L.em[lane][3] = l1 & h1 & ve;
     if constexpr (sizeof(W) == 4) L.va[lane] = va;
+    if constexpr (SP) {
+        // allowed starts of this window: the prefix rule (k = 0, or no byte outside ACGT: every position) on the starts it owns.
+        // (s + k <= the ROW's length: in a window that is not the last, an owned start has sp_ov >= k more characters in the window)
+        W a0 = sct_allowed_starts<W>(badmask, len, a.prefix_len);
+        if constexpr (sizeof(W) == 8) {   // (32-bit masks: rows of at most 31 characters, one window)
+            if (win < nwin - 1) a0 &= ((W)1 << sp_step) - 1;
+        }
+        SctStarts<W> st;
+        st.from_allowed(a0, va);
+        L.al[lane][0] = st.a[0];
+        L.al[lane][1] = st.a[1];
+        L.al[lane][2] = st.a[2];
+    }
     L.pl[lane].lo = lo;
     L.pl[lane].hi = hi;
     L.slen[lane] = (uint8_t)len;
@@ -1158,7 +1232,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     constexpr bool THIRDS = SCHEME == SCHEME_THIRDS, WIDE = SCHEME == SCHEME_WIDE;
     static_assert(!(SL && (SCHEME != SCHEME_QUARTERS || RT)), "bucket slots exist for the 16-character quarter families only");
     static_assert(!WIDE || (E == 2 && !RT), "the wide families are those of max_err = 2 and 16-character barcodes");
-    FilterWave<E, W, HM, SL, RPW, WIDE, THIRDS> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.tab_fb, a.tab_wfb, a.ft, lane, active, len, lo, hi};
+    FilterWave<E, W, HM, SL, RPW, WIDE, THIRDS, SP> W_{L, a.tab_off, a.tab_ent, a.tab_code, a.tab_slot, a.tab_grp, a.tab_ent16, a.tab_fb, a.tab_wfb, a.ft, lane, active, len, lo, hi};
 #define RUN_FAMILY(FID)                                                         \
     do {                                                                        \
         if constexpr (RT) W_.run_family(sct_family_rt(FID, bl), maxlen);        \
@@ -1253,7 +1327,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
 #undef RUN_FAMILY
     // Locators -> pattern ids, in place, by all lanes of the wave: with RPW rows per wave, 64 / RPW lanes share a row's
     // list, up to four table reads in flight per lane.
-    using FW = FilterWave<E, W, HM, SL, RPW, WIDE, THIRDS>;
+    using FW = FilterWave<E, W, HM, SL, RPW, WIDE, THIRDS, SP>;
     constexpr uint32_t CAP = (uint32_t)FW::CAP;
     {
         constexpr int PARTS = 64 / RPW;
@@ -1272,7 +1346,9 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         }
         __builtin_amdgcn_wave_barrier();
     }
-    const uint32_t hc = active ? L.hcnt[lane] : 0u;
+    // the lanes that own a row's result: every lane with a row (main, retry), the lane of the row's first window (special)
+    const bool ractive = SP ? (lane < RPW && inrange && !toolong) : active;
+    const uint32_t hc = ractive ? L.hcnt[lane] : 0u;
     const uint32_t nc = hc & ~FW::HCNT_OVERFLOW;
     if constexpr (RPW == 64) {
         // main launch: one lane per row folds its (short) list into minimum + distinct pattern ids in registers
@@ -1296,11 +1372,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         constexpr int PER = (int)((CAP + 63) / 64);
         constexpr uint32_t SENT = 0xFFFFFFFFu;
         const bool ovf = SL ? nc > CAP : FW::overflowed(hc, L.best[lane]);
-#ifdef SCT_ABLATE_FINISH  // timing-only build: the lists are cut to one entry before they are folded (results are wrong)
-        const uint32_t n_own = (active && !ovf) ? (nc < 1u ? nc : 1u) : 0u;
-#else
-        const uint32_t n_own = (active && !ovf) ? (nc < CAP ? nc : CAP) : 0u;
-#endif
+        const uint32_t n_own = (ractive && !ovf) ? (nc < CAP ? nc : CAP) : 0u;
         // pass A, row after row: strike what is not at the row's minimum, strike duplicates, count what is left
         uint32_t my_cnt = 0;
         for (int row = 0; row < RPW; row++) {
@@ -1355,7 +1427,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         if (lane == 0 && total) base = atomicAdd(a.slot_cursor, (unsigned long long)total);
         base = __shfl(base, 0, 64);
         const bool no_room = base + total > a.slots_cap;  // wave-uniform
-        if (active && (ovf || no_room)) {
+        if (ractive && (ovf || no_room)) {
             a.list_defer[atomicAdd(a.defer_count, 1u)] = (int32_t)r;
             a.cnt[r] = CNT_DEFER;
         }
@@ -1381,7 +1453,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
             for (int i = 0; i < PER; i++)
                 if (val[i] != SENT) a.slots[start + rank[i]] = val[i];
         }
-        if (active && !ovf && !no_room) {
+        if (ractive && !ovf && !no_room) {
             a.cnt[r] = my_cnt | CNT_RETRIED;
             a.min_e[r] = my_cnt ? (uint8_t)L.best[lane] : (uint8_t)SCT_NO_HIT;
             if (my_cnt) a.slot_off[r] = base + start_own;
@@ -1408,11 +1480,11 @@ struct FilterWavesPerBlock {
 
 // The retry launch without slots waits for table reads at one-wave blocks: four waves per SIMD (at most 128 VGPRs) instead of the
 // three its 160-odd registers would allow.
-template <int E, typename W, int SCHEME, int KS, int HM, int RPW, bool RT, bool SL, typename OffT>
+template <int E, typename W, int SCHEME, int KS, int HM, int RPW, bool RT, bool SL, typename OffT, bool SP = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RPW < 64 && !SL && sizeof(W) == 4) ? 4 : 1)))
 k_filter(const FilterArgs<OffT> a) {
     constexpr int WPB = FilterWavesPerBlock<W, RPW>::value;
-    using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE>;
+    using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE, SP>;
     __shared__ Lds lds[WPB];
     const int64_t n = a.n_dev ? (int64_t)*a.n_dev : a.n;
     const int64_t first = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * RPW;
@@ -1426,7 +1498,7 @@ k_filter(const FilterArgs<OffT> a) {
     } else {
         const int64_t step = (int64_t)gridDim.x * WPB * RPW;
         for (int64_t f = first; f < n; f += step) {
-            filter_rows<E, W, SCHEME, KS, HM, RPW, RT, SL, OffT>(a, lds[0], f, n);
+            filter_rows<E, W, SCHEME, KS, HM, RPW, RT, SL, OffT, false, SP>(a, lds[0], f, n);
             __builtin_amdgcn_wave_barrier();
         }
     }

@@ -127,14 +127,14 @@ __global__ void __launch_bounds__(256) k_join_part0(const JoinArgs<OffT> ja) {
             if (!line && a.cnt8 && (!fits || (nonacgt && a.prefix_len > 0))) a.cnt8[r] = 0;
             if (!fits) {
                 if (len_all > PLANE_MAX) {
-                    a.list_long[atomicAdd(&a.ctr[CTR_LONG], 1u)] = (int32_t)r;
+                    a.list_special[atomicAdd(&a.ctr[CTR_SPECIAL], 1u)] = (int32_t)r;
                     a.cnt[r] = CNT_DEFER;
                 } else {
                     if (!line) a.min_e[r] = SCT_NO_HIT;
                     a.cnt[r] = 0;
                 }
             } else if (nonacgt && a.prefix_len > 0) {
-                a.list_dp[atomicAdd(&a.ctr[CTR_DP], 1u)] = (int32_t)r;
+                a.list_special[atomicAdd(&a.ctr[CTR_SPECIAL], 1u)] = (int32_t)r;
                 a.cnt[r] = CNT_DEFER;
                 active = false;
             }

@@ -22,13 +22,14 @@ static constexpr int THIRDS_MIN_PATTERNS = 1 << 19;  // from here on (8 barcodes
 static constexpr int WIDE_MIN_PATTERNS = 1 << 20;
 static constexpr int PLANE_MAX = 63;       // characters kept in the packed bit-planes
 
-// Per-batch device counters (one 64-byte record per lane, read back by the host in ONE copy when the batch is done).
+// Per-batch device counters (one 128-byte record per lane, read back by the host in ONE copy when the batch is done).
 // 32-bit words:
 enum {
     CTR_SCAN = 0,       // rows listed for the exhaustive scan (list_scan): rows longer than PLANE_MAX, rows the retry launch gave up on
-    CTR_DP = 1,         // rows listed for the restricted-start DP (list_dp): non-ACGT bytes while the reference's prefix length k > 0
+    CTR_DP = 1,         // rows listed for the restricted-start DP (list_dp): what the special launch could not hold of the rows with
+                        // non-ACGT bytes under a prefix length k > 0; all such rows when there are no seed tables
     CTR_RETRY = 2,      // rows the main filter launch hands to the retry launch (list_retry)
-    CTR_LONG = 3,       // rows longer than PLANE_MAX characters, not yet routed (list_long)
+    CTR_LONG = 3,       // rows the special launch hands on (more windows than it has lanes, lists that overflow), not yet routed (list_long)
     CTR_CURSOR = 4,     // (64-bit, words 4-5)  entries used in the main launch's dense hit slots
     CTR_CURSOR_RETRY = 6,  // (64-bit, words 6-7)  the same for the retry launch
     CTR_BAD_ROW = 8,    // (64-bit, words 8-9)  smallest row whose index entry is invalid, ~0 = none
@@ -36,7 +37,8 @@ enum {
     CTR_CNT_OVERFLOW = 12,  // a row's hit count did not fit the requested count format
     CTR_JOIN_OVERFLOW = 13, // partitioned join (k_join.hip.h): a producer block had more tuples for one partition than its region holds
     CTR_TOTAL = 14,     // (64-bit, words 14-15) total number of hits of the batch
-    CTR_WORDS = 16
+    CTR_SPECIAL = 16,   // rows the main launch lists for the special launch (list_special): restricted starts, more than PLANE_MAX characters
+    CTR_WORDS = 32
 };
 
 // Start and length of row r from its CSR offsets, forced into [0, bytes] so that no kernel reads outside the segment

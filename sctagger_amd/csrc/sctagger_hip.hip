@@ -146,7 +146,7 @@ struct Lane {
     const char *host_segs = nullptr;    // zero-copy batches: the same bytes on the host (the slow path copies them to `segs`)
     DevBuf segs, offs64, offs32, index_in;
     // work / results
-    DevBuf min_e, cnt, route, slots, slots_retry, list_retry, slot_off, wave_base, list_long, list_scan, list_dp, counters, hit_offs, sums, hits,
+    DevBuf min_e, cnt, route, slots, slots_retry, list_retry, list_special, slot_off, wave_base, list_long, list_scan, list_dp, counters, hit_offs, sums, hits,
         part_best, part_cnt, cnt_out;
     DevBuf arena_cur;   // SLOT_ARENAS cursors of the main launch's slot array, 64 bytes apart (sct_slot_arena)
     DevBuf j_planes, j_len, j_wave, j_cnt, j_slots, j_tup0, j_cnt0, j_tup1, j_cnt1;   // the partitioned join (k_join.hip.h)
@@ -162,7 +162,7 @@ struct Lane {
     bool direct_min_e = false, direct_cnt = false, direct_hits = false;
     BatchParams bp;
     int64_t n_hits = 0;
-    int64_t stats[5] = {0, 0, 0, 0, 0};
+    int64_t stats[6] = {0, 0, 0, 0, 0, 0};
     bool have_result = false;
     // timing
     std::vector<TimedSpan> timed;
@@ -179,7 +179,7 @@ struct Lane {
     }
     uint32_t *ctr() const { return counters.as<uint32_t>(); }
     void release() {
-        DevBuf *bufs[] = {&segs, &offs64, &offs32, &index_in, &min_e, &cnt, &route, &slots, &slots_retry, &list_retry, &slot_off, &wave_base, &list_long,
+        DevBuf *bufs[] = {&segs, &offs64, &offs32, &index_in, &min_e, &cnt, &route, &slots, &slots_retry, &list_retry, &list_special, &slot_off, &wave_base, &list_long,
                           &list_scan, &list_dp, &counters, &hit_offs, &sums, &hits, &part_best, &part_cnt, &cnt_out,
                           &arena_cur, &j_planes, &j_len, &j_wave, &j_cnt, &j_slots, &j_tup0, &j_cnt0, &j_tup1, &j_cnt1};
         for (DevBuf *b : bufs) b->release();
@@ -235,7 +235,7 @@ struct sct_ctx {
         int launches = 0;
     };
     std::vector<std::pair<const char *, Span>> last_ms;
-    int64_t stats[5] = {0, 0, 0, 0, 0};
+    int64_t stats[6] = {0, 0, 0, 0, 0, 0};   // rows by path: filter, exhaustive scan, restricted-start DP; hits; rows retried; rows of the special launch
 
     Lane &lane0() { return *lanes[0]; }
 };
@@ -577,7 +577,7 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
         l.slots_cap = ((uint64_t)n1 + arena_round - 1) / arena_round * arena_round * K_SLOTS;
         l.retry_cap = (uint64_t)n1 * K_SLOTS < 65536 ? 65536 : (uint64_t)n1 * K_SLOTS;
         if (l.slots.ensure(4 * l.slots_cap) || l.slots_retry.ensure(4 * l.retry_cap) || l.slot_off.ensure(8 * n1) || l.wave_base.ensure(8 * (n1 / 64 + 2)) ||
-            l.list_retry.ensure(4 * n1))
+            l.list_retry.ensure(4 * n1) || l.list_special.ensure(4 * n1))
             return g_code;
     }
     if (l.hits.ensure(4 * (size_t)(l.slots_cap + l.retry_cap + 1))) return g_code;
@@ -636,12 +636,11 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.cnt = l.cnt.as<uint32_t>();
     fa.slot_off = l.slot_off.as<uint64_t>();
     fa.wave_base = l.wave_base.as<uint64_t>();
-    fa.list_long = l.list_long.as<int32_t>();
-    fa.list_dp = l.list_dp.as<int32_t>();
+    fa.list_special = l.list_special.as<int32_t>();
     fa.ctr = ctr;
     fa.bl = c->bl;
     fa.prefix_len = bp.prefix_len;
-    SctFilterVariant v{false, bp.rt_families, bp.use_slots && !bp.rt_families, bp.use_thirds, bp.use_wide};
+    SctFilterVariant v{false, bp.rt_families, bp.use_slots && !bp.rt_families, bp.use_thirds, bp.use_wide, false, false};
     {
         Timer t(c, l, "k_filter");
         fa.n = n;
@@ -701,6 +700,24 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR_RETRY);
         fa.arena_cursors = nullptr;
         launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), capped((n + 3) / 4), st);  // one wave of 4 rows per block, striding
+    }
+    {
+        // rows the main launch listed because one lane's planes cannot express them as the reference sees them (restricted window
+        // starts; more than PLANE_MAX characters): the retry launch's shape with start masks and windows (filter_rows, SP).  Its lists
+        // go to the retry launch's slot array; what it cannot hold goes on to list_long -> the scan kernels of the slow path.
+        Timer t(c, l, "k_filter_special");
+        v.retry = false;
+        v.special = true;
+        fa.n = 0;
+        fa.n_dev = ctr + CTR_SPECIAL;
+        fa.rows = l.list_special.as<int32_t>();
+        fa.slots = l.slots_retry.as<uint32_t>();
+        fa.slots_cap = l.retry_cap;
+        fa.list_defer = l.list_long.as<int32_t>();
+        fa.defer_count = ctr + CTR_LONG;
+        fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR_RETRY);
+        fa.arena_cursors = nullptr;
+        launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), capped((n + 3) / 4), st);
     }
 }
 
@@ -972,6 +989,7 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
     l.stats[2] = h[CTR_DP];
     l.stats[3] = l.n_hits;
     l.stats[4] = n_retried;
+    l.stats[5] = h[CTR_SPECIAL];
     l.have_result = true;
     return SCT_OK;
 }
@@ -1399,7 +1417,7 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
             }
         }
         hit_base += l.n_hits;
-        for (int i = 0; i < 5; i++) c->stats[i] += l.stats[i];
+        for (int i = 0; i < 6; i++) c->stats[i] += l.stats[i];
         return SCT_OK;
     };
 
@@ -1474,7 +1492,8 @@ extern "C" int sct_last_stats(sct_ctx *c, int64_t *out, int cap) {
     for (int i = 0; i < 5 && i < cap; i++) out[i] = c->stats[i];
     if (cap > 5) out[5] = c->last_scheme;
     if (cap > 6) out[6] = c->last_join;
-    return 7;
+    if (cap > 7) out[7] = c->stats[5];
+    return 8;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,198 @@
+"""The seed filter's SPECIAL launch (csrc/k_filter.hip.h, filter_rows SP): rows with a byte outside ACGT while the reference's
+prefix length k > 0 (restricted window starts, /root/reference/scTagger.py:681, :689-697) and rows of more than 63 characters
+(cut into overlapping windows).  Before round 4 these rows went to the all-barcodes scan kernels, ~1000x slower per row.
+Against the oracle at small sizes, against the exhaustive scan at cfg3 size; bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import bruteforce, trie_oracle
+from sctagger_amd import _native, synth
+from tests import util
+from tests.test_gpu_parity import ragged, run_both
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def m():
+    mm = _native.Matcher(0)
+    yield mm
+    mm.close()
+
+
+def rows_of_lengths(bc, lengths, seed, junk=0.0):
+    """One planted row per entry of `lengths` (a barcode with 0..3 edits somewhere inside random ACGT), optional junk bytes."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.arange(256, dtype=np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    rows = []
+    for n in lengths:
+        s = acgt[rng.integers(0, 4, size=n)]
+        b = bc[rng.integers(0, bc.shape[0])].copy()
+        if rng.random() < 0.5:
+            b = comp[b[::-1]]
+        core = list(b)
+        for _ in range(int(rng.integers(0, 4))):
+            k, at = int(rng.integers(0, 3)), int(rng.integers(0, len(core)))
+            if k == 0:
+                core[at] = acgt[rng.integers(0, 4)]
+            elif k == 1:
+                core.insert(at, acgt[rng.integers(0, 4)])
+            elif len(core) > 1:
+                del core[at]
+        core = np.array(core, dtype=np.uint8)
+        if core.size <= n:
+            at = int(rng.integers(0, n - core.size + 1))
+            s[at:at + core.size] = core
+        if junk and n:
+            k = rng.random(n) < junk
+            s[k] = rng.choice(np.frombuffer(b"NnacgtRYX -*", dtype=np.uint8), size=int(k.sum()))
+        rows.append(s)
+    offs = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum([r.size for r in rows], out=offs[1:])
+    return (np.concatenate(rows) if rows else np.empty(0, np.uint8)), offs
+
+
+@pytest.mark.parametrize("e,t,junk", [(2, 16, 0.02), (2, 1, 0.02), (1, 4, 0.03), (2, 64, 0.0), (0, 16, 0.02), (2, 300, 0.04)])
+def test_windowed_and_restricted_rows_vs_oracle(m, e, t, junk):
+    """Lengths around every window boundary (63 | 64; step 63 - (bl + e - 1) = 46 at e = 2: 109 | 110, ...; 16 windows = 753 | 754)."""
+    bc = synth.make_barcodes(500, seed=71)
+    step = 63 - (16 + e - 1)
+    edge = [63, 64, 65, step + 17, step + 18, 2 * step + 16, 2 * step + 17, 2 * step + 18, 15 * step + 17, 16 * step + 16, 16 * step + 17, 16 * step + 18, 900]
+    rng = np.random.default_rng(72 + t)
+    lengths = edge * 6 + list(rng.integers(14, 200, size=900)) + list(rng.integers(200, 760, size=120))
+    segs, offs = rows_of_lengths(bc, lengths, 73 + e, junk)
+    want = trie_oracle.match(bc, segs, offs, e, threads=t, workers=8)
+    a, b = run_both(m, bc, segs, offs, e, t)
+    util.assert_same(a, want, "filter path")
+    util.assert_same(b, want, "exhaustive path")
+    m.set_barcodes(bc)
+    m.match(segs, offs, e, t)
+    st = m.last_stats()
+    lens = np.diff(offs)
+    too_long = int((lens > 16 * step + (16 + e - 1)).sum())   # 16 windows hold 16 * step + (bl + e - 1) characters
+    assert st["special"] >= int((lens > 63).sum())
+    # only rows of more than 16 windows leave the seed filter
+    assert st["exhaustive"] + st["restricted_start"] == too_long, st
+
+
+@pytest.mark.parametrize("bl,e,t", [(12, 2, 16), (9, 1, 4), (14, 2, 64)])
+def test_other_barcode_lengths(m, bl, e, t):
+    """Run-time quarter families (bl != 16): the window step follows bl + e - 1."""
+    bc = synth.make_barcodes(300, bl=bl, seed=81)
+    rng = np.random.default_rng(82)
+    segs, offs = rows_of_lengths(bc, list(rng.integers(6, 260, size=1200)), 83, junk=0.02)
+    want = trie_oracle.match(bc, segs, offs, e, threads=t, workers=8)
+    a, b = run_both(m, bc, segs, offs, e, t)
+    util.assert_same(a, want, "filter path")
+    util.assert_same(b, want, "exhaustive path")
+    m.set_barcodes(bc)
+    m.match(segs, offs, e, t)
+    st = m.last_stats()
+    assert st["exhaustive"] == 0 and st["restricted_start"] == 0 and st["special"] > 0, st
+
+
+@pytest.mark.parametrize("e", [0, 1])
+def test_thirds_scheme(m, e):
+    """The 20/22-bit families of large barcode sets take the same special launch."""
+    bc = synth.make_barcodes(2000, seed=91)
+    rng = np.random.default_rng(92)
+    segs, offs = rows_of_lengths(bc, list(rng.integers(14, 300, size=1500)), 93, junk=0.02)
+    want = trie_oracle.match(bc, segs, offs, e, threads=16, workers=8)
+    m.set_option("thirds", 1)
+    try:
+        m.set_barcodes(bc)
+        for fb in (1, 0):
+            m.set_option("fixed_buckets", fb)
+            got = m.match(segs, offs, e, 16)
+            st = m.last_stats()
+            assert st["scheme"] == "thirds" and st["exhaustive"] == 0 and st["restricted_start"] == 0 and st["special"] > 0, st
+            util.assert_same(got, want, "thirds, fixed_buckets=%d" % fb)
+        if e == 1:
+            m.set_option("join", 1)
+            got = m.match(segs, offs, e, 16)
+            m.set_option("join", 0)
+            util.assert_same(got, want, "thirds through the join")
+    finally:
+        m.set_option("fixed_buckets", -1)
+        m.set_option("thirds", -1)
+        m.set_barcodes(bc)
+
+
+def test_goldens_stay_on_the_seed_filter(m):
+    """g3 (t = 1 / 4 / 16), g7 — no row leaves the seed filter any more."""
+    seen = 0
+    for name, lr, sr, e, t, bl, exp in util.golden_cases():
+        if name not in ("g3", "g7"):
+            continue
+        bcs, names, segs, offs = util.read_inputs(lr, sr)
+        m.set_barcodes(util.bc_matrix(bcs, bl))
+        got = m.match(segs, offs, e, t)
+        st = m.last_stats()
+        assert st["exhaustive"] == 0 and st["restricted_start"] == 0, (name, e, t, st)
+        assert util.render(bcs, names, segs, offs, *got) == open(exp).read(), (name, e, t)
+        seen += 1
+    assert seen >= 11
+
+
+def test_many_ties_in_special_rows(m):
+    """Rows of the special launch whose lists overflow (hundreds of ties) go on to the scan kernels and still come out right."""
+    rng = np.random.default_rng(5)
+    bc = np.full((600, 16), ord("A"), dtype=np.uint8)
+    for i in range(1, 600):
+        bc[i, rng.integers(0, 16, size=rng.integers(1, 3))] = ord("C")
+    segs = np.frombuffer(b"A" * 30 + b"N" + b"A" * 30 + b"A" * 100 + b"ACGT" * 20 + b"NAAAAAAAAAAAAAAAAAAAAAAAA", dtype=np.uint8)
+    offs = np.array([0, 61, 161, 241, 266], dtype=np.int64)
+    for t in (1, 16):
+        want = trie_oracle.match(bc, segs, offs, 2, threads=t)
+        a, b = run_both(m, bc, segs, offs, 2, t)
+        util.assert_same(a, want, "filter path t=%d" % t)
+        util.assert_same(b, want, "exhaustive path t=%d" % t)
+
+
+def _compare_subset_with_exhaustive(m, bc, segs, offs, got, rows, e, t):
+    """The rows `rows` of a batch once more as a batch of their own through the exhaustive scan / restricted-start DP."""
+    lens = np.diff(offs)
+    sub_offs = np.zeros(rows.size + 1, dtype=np.int64)
+    np.cumsum(lens[rows], out=sub_offs[1:])
+    idx = np.repeat(offs[rows] - sub_offs[:-1], lens[rows]) + np.arange(int(sub_offs[-1]))
+    sub_segs = segs[idx]
+    m.set_option("force_exhaustive", 1)
+    try:
+        want = m.match(sub_segs, sub_offs, e, t)
+    finally:
+        m.set_option("force_exhaustive", 0)
+    me, ho, hits = got
+    assert np.array_equal(me[rows], want[0])
+    cnt = np.diff(ho)
+    assert np.array_equal(cnt[rows], np.diff(want[1]))
+    hidx = np.repeat(ho[rows] - want[1][:-1], cnt[rows]) + np.arange(int(want[1][-1]))
+    assert np.array_equal(hits[hidx], want[2])
+
+
+@pytest.mark.parametrize("n,frac_n,frac_long", [(10_000_000, 0.01, 0.01), (2_000_000, 0.10, 0.0)])
+def test_cfg3_with_noise_equals_exhaustive(m, n, frac_n, frac_long):
+    """cfg3's shape (25 k barcodes, e <= 2, the reference's default -t 16) with 1 % / 10 % of the rows carrying one N and 1 % of
+    the rows 80 characters long: every such row, and a sample of the others, equals the exhaustive scan."""
+    import bench
+    bc = synth.make_barcodes(25_000, seed=3)
+    segs, offs = bench.make_batch(n, bc, 3)
+    rows_long = np.empty(0, np.int64)
+    if frac_long:
+        segs, offs, rows_long = synth.lengthen_rows(segs, offs, frac_long, 80)
+    segs, rows_n = synth.add_noise_bytes(segs, offs, frac_n)
+    m.set_barcodes(bc)
+    m.upload_segments(segs, offs)
+    m.run(2, 16)
+    got = m.download()
+    st = m.last_stats()
+    special = np.union1d(rows_n, rows_long)
+    assert st["special"] == special.size and st["exhaustive"] == 0 and st["restricted_start"] == 0, st
+    rng = np.random.default_rng(11)
+    others = rng.choice(offs.size - 1, size=40_000, replace=False)
+    _compare_subset_with_exhaustive(m, bc, segs, offs, got, np.union1d(special, others), 2, 16)
+    # the stream entry gives the same arrays
+    lens = np.diff(offs).astype(np.uint8)
+    me, cnt, hits = m.match_stream(segs, lens, 2, 16, index_format=_native.IDX_LEN8, count_format=_native.CNT_U8, hits_format=_native.HITS_U16)
+    assert np.array_equal(me, got[0]) and np.array_equal(cnt, np.diff(got[1]).astype(np.uint8)) and np.array_equal(hits.astype(np.uint32), got[2])
