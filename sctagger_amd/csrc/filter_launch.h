@@ -8,6 +8,7 @@ struct SctFilterVariant {
     bool wide;    // the sixteen 20-bit families of large barcode sets (max_err = 2)
     bool only64;  // main launch: the 64-bit instantiation only (the partitioned join, k_join.hip.h, has done the 32-bit rows)
     bool special; // the special launch: the retry launch's shape over list_special, restricted starts and rows cut into windows
+    bool special16; // ... its first stage with bucket slots: 16 rows per wave (the rows it hands on take the 4-row shape)
 };
 template <typename OffT>
 struct FilterArgs;

@@ -46,6 +46,9 @@ void launch(const SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, un
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
             k_filter<E, uint64_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
         }
+    } else if (v.special && v.special16) {
+        k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, SPECIAL_RPW_SL, false, true, OffT, true><<<g, 64, 0, st>>>(fa);
+        k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, SPECIAL_RPW_SL, false, true, OffT, true><<<g64, 64, 0, st>>>(fa);
     } else if (v.special) {
         if (v.rt) {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT, true><<<g, 64, 0, st>>>(fa);

@@ -92,7 +92,7 @@ __device__ __forceinline__ void sct_decode_row_mask(const uint8_t *__restrict__ 
 typedef uint32_t sct_u4 __attribute__((ext_vector_type(4)));
 template <typename W>
 __device__ __forceinline__ bool sct_decode_rows_staged(const uint8_t *__restrict__ segs, int64_t start, int len, uint32_t *stage, int stage_bytes,
-                                                       W &lo, W &hi, bool &nonacgt) {
+                                                       W &lo, W &hi, W &bad) {
     const int lane = threadIdx.x & 63;
     // stretch of the rows that are decoded (len > 0); lanes without one do not widen it
     const uint64_t a = (uint64_t)(uintptr_t)segs + (uint64_t)start;
@@ -104,8 +104,7 @@ __device__ __forceinline__ bool sct_decode_rows_staged(const uint8_t *__restrict
         smax = y > smax ? y : smax;
     }
     if (smax <= smin) {  // nothing to decode in this wave
-        lo = hi = 0;
-        nonacgt = false;
+        lo = hi = bad = 0;
         return true;
     }
     const uint64_t base = smin & ~15ull;
@@ -120,7 +119,7 @@ __device__ __forceinline__ bool sct_decode_rows_staged(const uint8_t *__restrict
     __builtin_amdgcn_wave_barrier();
     const uint32_t so = len > 0 ? (uint32_t)(a - base) : 0u;
     const uint32_t *wp = stage + (so >> 2);
-    sct_decode_words<W>([&](int k) { return wp[k]; }, (int)(so & 3u), len, lo, hi, nonacgt);
+    sct_decode_words_mask<W>([&](int k) { return wp[k]; }, (int)(so & 3u), len, lo, hi, bad);
     __builtin_amdgcn_wave_barrier();  // the stage is the filter's queue and hit lists from here on
     return true;
 }
@@ -146,11 +145,27 @@ __device__ __forceinline__ void sct_block_stage_load(const uint8_t *__restrict__
     }
 }
 // ... and a lane's row out of that stage (start = the row's byte offset in the buffer, lo = the block stretch's)
+// -> the row's byte offset inside the stage (so that the caller can look at its raw bytes while they are there)
 template <typename W>
-__device__ __forceinline__ void sct_decode_row_from_block_stage(const uint8_t *__restrict__ segs, int64_t lo, int64_t start, int len, const uint32_t *stage,
-                                                                W &plo, W &phi, bool &nonacgt) {
+__device__ __forceinline__ uint32_t sct_decode_row_from_block_stage(const uint8_t *__restrict__ segs, int64_t lo, int64_t start, int len, const uint32_t *stage,
+                                                                    W &plo, W &phi, W &bad) {
     const uint64_t base = ((uint64_t)(uintptr_t)segs + (uint64_t)lo) & ~127ull;
     const uint32_t so = len > 0 ? (uint32_t)((uint64_t)(uintptr_t)segs + (uint64_t)start - base) : 0u;
     const uint32_t *wp = stage + (so >> 2);
-    sct_decode_words<W>([&](int k) { return wp[k]; }, (int)(so & 3u), len, plo, phi, nonacgt);
+    sct_decode_words_mask<W>([&](int k) { return wp[k]; }, (int)(so & 3u), len, plo, phi, bad);
+    return so;
+}
+
+// Bytes >= 128: the reference raises when it reads one (sct_byte_is_read, sct_core.h).  Only bytes that are not one of ACGT can
+// be such a byte: `bad` = their positions in the row.  row = the row's bytes (in memory, or still in the LDS stage), `at` = the row's
+// offset in the caller's buffer (what the error message quotes).  Rare: called for rows with a bad byte only.
+__device__ __forceinline__ void sct_report_high_bytes(const uint8_t *row, int len, uint64_t bad, int64_t at, int bl, int max_err, int k, uint32_t *ctr) {
+    while (bad != 0) {
+        const int i = __builtin_ctzll(bad);
+        bad &= bad - 1;
+        if (row[i] >= 128 && sct_byte_is_read(row, len, i, bl, max_err, k)) {
+            atomicMin(reinterpret_cast<unsigned long long *>(ctr + CTR_BAD_BYTE), (unsigned long long)(at + i));
+            break;
+        }
+    }
 }

@@ -157,6 +157,11 @@ static constexpr int K_RETRY = 32, H_RETRY = 80;  // retry launch: 80 x 256 B of
 // retry launch with slots: 4 rows per wave as well (cfg3's 8 854 retried rows: 0.105 ms with 16 rows per wave, 0.073 with 4, 0.116 with 2)
 static constexpr int RETRY_RPW_SL = 4;
 static constexpr int H_RETRY_SL = H_RETRY * RETRY_RPW_SL / 16;
+// special launch with slots, first stage: 16 rows per wave — 4 window lanes and 80 hit-list entries per row in the same LDS.  Rows
+// of more than 4 windows (201 characters at bl = 16, E = 2) or with longer lists go to the second stage, the retry launch's shape
+// (4 rows per wave, 16 windows, 320 entries).  95 k one-window rows: 0.345 ms at 4 rows per wave (the waves are latency-bound and
+// LDS limits how many are resident), see DESIGN.md for the two-stage figure.
+static constexpr int SPECIAL_RPW_SL = 16;
 // without slots (larger barcode sets): the same 320 entries per row for 4 rows per wave — a quarter of the LDS per (one-wave) block,
 // four times the waves per CU; these launches wait for table reads and are short of waves, not of lanes.  Retry launch per 1 M
 // rows with 16 / 8 / 4 rows per wave: 3.6 M barcodes wide scheme 5.4 / 4.0 / 4.1 ms, 1 M wide 5.0 / 5.0 / 4.7, 3.6 M quarters
@@ -999,6 +1004,13 @@ struct FilterWave {
 // OffT: type of the CSR offsets (FilterArgs).
 //
 // Everything a launch needs besides its template parameters.
+// What the main launch leaves for the special launch about a row of at most PLANE_MAX characters it lists (a byte outside ACGT
+// under a prefix length k > 0): planes, the positions of the bytes that are not one of ACGT, length — the special launch need not
+// read the row again (over the PCIe link, when the rows are the caller's page-locked buffer: 0.76 instead of 0.35 ms per 95 k rows).
+struct __attribute__((aligned(32))) SctSpecialRec {
+    uint64_t lo, hi, bad, len;
+};
+
 template <typename OffT>
 struct FilterArgs {
     const uint8_t *segs;          // the rows' ASCII bytes (padded by 64 bytes past the end)
@@ -1025,6 +1037,10 @@ struct FilterArgs {
     int32_t *list_defer;          // main launch: list_retry; retry launch: list_scan
     uint32_t *defer_count;
     int32_t *list_special;        // main launch: rows for the special launch (restricted starts, more than PLANE_MAX characters)
+    SctSpecialRec *rec_out;       // ... and what it knows about them, entry for entry (first rec_cap list positions); the special launch's
+                                  // first stage: the same for the rows it hands to the second (beside list_defer)
+    const SctSpecialRec *rec_in;  // special launch: the records of its listed rows
+    uint32_t rec_cap;
     uint32_t *ctr;                // the batch's counter record (CTR_*)
     unsigned long long *slot_cursor;
     unsigned long long *arena_cursors;   // main launch of a large batch: SLOT_ARENAS cursors, 64 bytes apart (NULL: the one slot_cursor)
@@ -1099,10 +1115,8 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     // their rows still have to be routed), W = uint64_t the others; a wave leaves at once if it is not its kind
     const bool mykind = (maxlen <= 31) == (sizeof(W) == 4);
     const bool anyrow = __ballot(inrange) != 0;
-    W lo, hi;
-    bool nonacgt;
-    bool decoded = false;
-    [[maybe_unused]] W badmask = 0;
+    W lo, hi, badmask = 0;
+    bool decoded = false, high_checked = false;
     if constexpr (COOP) {
         static_assert(RPW == 64, "the cooperative stage belongs to the main launch");
         const int widx = (int)(threadIdx.x >> 6);
@@ -1121,7 +1135,13 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
                 __syncthreads();
                 // (a row outside the block's stretch means an inconsistent index: the call fails on CTR_BAD_ROW; it must not read past the stage)
                 const int dl = (start >= A && start + len <= B) ? len : 0;
-                sct_decode_row_from_block_stage<W>(a.segs, A, start, dl, block_lds, lo, hi, nonacgt);
+                const uint32_t so = sct_decode_row_from_block_stage<W>(a.segs, A, start, dl, block_lds, lo, hi, badmask);
+                // rare: a byte outside ACGT — is it >= 128?  Looked up while the row's bytes are still in LDS (from the caller's
+                // page-locked buffer every byte load is a round trip over the link: k_filter 4.03 -> 5.23 ms with 10 % such rows)
+                if (__ballot(badmask != 0) != 0) {
+                    if (badmask != 0) sct_report_high_bytes(reinterpret_cast<const uint8_t *>(block_lds) + so, dl, (uint64_t)badmask, start, bl, E, a.prefix_len, a.ctr);
+                }
+                high_checked = true;
                 __syncthreads();   // the stage is every wave's working LDS from here on
                 decoded = true;
             }
@@ -1129,15 +1149,26 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     }
     if (!mykind) return;
     if (!anyrow) return;
+    [[maybe_unused]] bool has_rec = false;
     if constexpr (SP) {
         if (toolong && win == 0) {   // more windows than the row has lanes: the scan kernels (via k_route_long).  (Such a row adds
-            a.list_defer[atomicAdd(a.defer_count, 1u)] = (int32_t)r;   // nothing to the wave's longest text, so exactly one of the
-            a.cnt[r] = CNT_DEFER;                                       // two mask widths gets here with it.)
+            const uint32_t k = atomicAdd(a.defer_count, 1u);            // nothing to the wave's longest text, so exactly one of the
+            a.list_defer[k] = (int32_t)r;                               // two mask widths gets here with it.)
+            a.cnt[r] = CNT_DEFER;
         }
-        sct_decode_row_mask<W>(a.segs, start, len, lo, hi, badmask);
-        nonacgt = badmask != 0;
+        // a row of one window: the listing launch left its planes; longer rows are decoded from their bytes
+        SctSpecialRec rec{0, 0, 0, ~0ull};
+        if (a.rec_in != nullptr && inrange && win == 0 && (uint64_t)gid < (uint64_t)a.rec_cap && len_all <= PLANE_MAX) rec = a.rec_in[gid];
+        has_rec = rec.len != ~0ull;   // (the first stage marks the rows it hands on without planes)
+        sct_decode_row_mask<W>(a.segs, start, has_rec ? 0 : len, lo, hi, badmask);
+        if (has_rec) {
+            lo = len > 0 ? (W)rec.lo : (W)0;
+            hi = len > 0 ? (W)rec.hi : (W)0;
+            badmask = len > 0 ? (W)rec.bad : (W)0;
+        }
         decoded = true;
     }
+    [[maybe_unused]] const W lo0 = lo, hi0 = hi, bad0 = badmask;
     if (!decoded) {
         using Lds = FilterWaveLds<W, HM, QueueCap<SL, HM, W>::value, SCHEME == SCHEME_WIDE, SP>;
         static_assert(__builtin_offsetof(Lds, qk) == __builtin_offsetof(Lds, hlist) + 4 * 64 * HM &&
@@ -1145,28 +1176,29 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
                       "hlist, qk and qm form the decode stage");
         constexpr int STAGE_BYTES = 4 * (64 * HM + 2 * Lds::QCAP);
         // all rows: one coalesced pass over the wave's stretch of bytes; listed rows lie anywhere: word by word
-        if (a.rows != nullptr || !sct_decode_rows_staged<W>(a.segs, start, len, &L.hlist[0][0], STAGE_BYTES, lo, hi, nonacgt))
-            sct_decode_row<W>(a.segs, start, len, lo, hi, nonacgt);
+        if (a.rows != nullptr || !sct_decode_rows_staged<W>(a.segs, start, len, &L.hlist[0][0], STAGE_BYTES, lo, hi, badmask))
+            sct_decode_row_mask<W>(a.segs, start, len, lo, hi, badmask);
     }
-    if (__ballot(nonacgt) != 0) {
+    const bool nonacgt = badmask != 0;
+    if (!high_checked && __ballot(nonacgt) != 0) {
         // rare: is one of the offending bytes >= 128?  The reference raises when it reads one (sct_byte_is_read, sct_core.h)
         if constexpr (SP) {
             // rows of at most PLANE_MAX characters were checked by the main launch that listed them; of a longer row every window
             // checks the bytes it owns, against the ROW (a byte is read iff some window the reference inserts covers it)
             if (nonacgt && len_all > PLANE_MAX) {
                 const int own = win == nwin - 1 ? len : (len < sp_step ? len : sp_step);
-                for (int i = 0; i < own; i++)
+                uint64_t bad = (uint64_t)badmask & (own >= 64 ? ~0ull : ((1ull << own) - 1ull));
+                while (bad != 0) {
+                    const int i = __builtin_ctzll(bad);
+                    bad &= bad - 1;
                     if (a.segs[start + i] >= 128 && sct_byte_is_read(a.segs + row_start, len_all, (int64_t)win * sp_step + i, bl, E, a.prefix_len)) {
                         atomicMin(reinterpret_cast<unsigned long long *>(a.ctr + CTR_BAD_BYTE), (unsigned long long)(start + i));
                         break;
                     }
+                }
             }
         } else if (nonacgt) {
-            for (int i = 0; i < len; i++)
-                if (a.segs[start + i] >= 128 && sct_byte_is_read(a.segs + start, len, i, bl, E, a.prefix_len)) {
-                    atomicMin(reinterpret_cast<unsigned long long *>(a.ctr + CTR_BAD_BYTE), (unsigned long long)(start + i));
-                    break;
-                }
+            sct_report_high_bytes(a.segs + start, len, (uint64_t)badmask, start, bl, E, a.prefix_len, a.ctr);
         }
     }
     bool active = fits;
@@ -1187,7 +1219,9 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         } else if (nonacgt && a.prefix_len > 0) {
             // the reference drops every window whose first k raw bytes are not all in ACGT (scTagger.py:681): the special launch
             // runs the same families with restricted starts
-            a.list_special[atomicAdd(&a.ctr[CTR_SPECIAL], 1u)] = (int32_t)r;
+            const uint32_t k = atomicAdd(&a.ctr[CTR_SPECIAL], 1u);
+            a.list_special[k] = (int32_t)r;
+            if (a.rec_out != nullptr && k < a.rec_cap) a.rec_out[k] = SctSpecialRec{(uint64_t)lo, (uint64_t)hi, (uint64_t)badmask, (uint64_t)len};
             a.cnt[r] = CNT_DEFER;
             active = false;
         }
@@ -1428,7 +1462,12 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         base = __shfl(base, 0, 64);
         const bool no_room = base + total > a.slots_cap;  // wave-uniform
         if (ractive && (ovf || no_room)) {
-            a.list_defer[atomicAdd(a.defer_count, 1u)] = (int32_t)r;
+            const uint32_t k = atomicAdd(a.defer_count, 1u);
+            a.list_defer[k] = (int32_t)r;
+            if constexpr (SP) {   // first stage of the special launch: the planes go along with the row
+                if (a.rec_out != nullptr && k < a.rec_cap)
+                    a.rec_out[k] = has_rec ? SctSpecialRec{(uint64_t)lo0, (uint64_t)hi0, (uint64_t)bad0, (uint64_t)len_all} : SctSpecialRec{0, 0, 0, ~0ull};
+            }
             a.cnt[r] = CNT_DEFER;
         }
         const uint32_t start_own = inc - my_cnt;

@@ -87,8 +87,8 @@ __global__ void __launch_bounds__(256) k_join_part0(const JoinArgs<OffT> ja) {
     if (threadIdx.x < JOIN_P0) pcnt[threadIdx.x] = 0;
     if (lane == 0) reinterpret_cast<uint8_t *>(&block_flags)[widx] = !anyrow ? 2 : (mykind ? 1 : 0);
     __syncthreads();
-    uint32_t lo = 0, hi = 0;
-    bool nonacgt = false, decoded = false;
+    uint32_t lo = 0, hi = 0, badmask = 0;
+    bool decoded = false;
     {
         const uint32_t f4 = block_flags;
         if ((f4 & 0xFFu) != 0u && (f4 & 0xFF00u) != 0u && (f4 & 0xFF0000u) != 0u && (f4 & 0xFF000000u) != 0u) {
@@ -101,24 +101,19 @@ __global__ void __launch_bounds__(256) k_join_part0(const JoinArgs<OffT> ja) {
                 sct_block_stage_load(a.segs, A, B, stage);
                 __syncthreads();
                 const int dl = (start >= A && start + len <= B) ? len : 0;
-                sct_decode_row_from_block_stage<uint32_t>(a.segs, A, start, dl, stage, lo, hi, nonacgt);
+                sct_decode_row_from_block_stage<uint32_t>(a.segs, A, start, dl, stage, lo, hi, badmask);
                 decoded = true;
             }
         }
     }
     const bool mine = mykind && anyrow;      // this wave's rows are the join's
-    if (mine && !decoded) sct_decode_row<uint32_t>(a.segs, start, len, lo, hi, nonacgt);
+    if (mine && !decoded) sct_decode_row_mask<uint32_t>(a.segs, start, len, lo, hi, badmask);
+    const bool nonacgt = badmask != 0;
     if (lane == 0 && first < n) ja.wave_kind[first >> 6] = mine ? 1 : 0;
     bool active = false;
     if (mine) {
         if (__ballot(nonacgt) != 0) {
-            if (nonacgt) {
-                for (int i = 0; i < len; i++)
-                    if (a.segs[start + i] >= 128 && sct_byte_is_read(a.segs + start, len, i, bl, E, a.prefix_len)) {
-                        atomicMin(reinterpret_cast<unsigned long long *>(a.ctr + CTR_BAD_BYTE), (unsigned long long)(start + i));
-                        break;
-                    }
-            }
+            if (nonacgt) sct_report_high_bytes(a.segs + start, len, (uint64_t)badmask, start, bl, E, a.prefix_len, a.ctr);
         }
         active = fits;
         const bool line = first + 64 <= a.n && (((uintptr_t)(a.min_e + first)) & 15) == 0 && (a.cnt8 == nullptr || (((uintptr_t)(a.cnt8 + first)) & 15) == 0);
@@ -134,7 +129,9 @@ __global__ void __launch_bounds__(256) k_join_part0(const JoinArgs<OffT> ja) {
                     a.cnt[r] = 0;
                 }
             } else if (nonacgt && a.prefix_len > 0) {
-                a.list_special[atomicAdd(&a.ctr[CTR_SPECIAL], 1u)] = (int32_t)r;
+                const uint32_t k = atomicAdd(&a.ctr[CTR_SPECIAL], 1u);
+                a.list_special[k] = (int32_t)r;
+                if (a.rec_out != nullptr && k < a.rec_cap) a.rec_out[k] = SctSpecialRec{(uint64_t)lo, (uint64_t)hi, (uint64_t)badmask, (uint64_t)len};
                 a.cnt[r] = CNT_DEFER;
                 active = false;
             }

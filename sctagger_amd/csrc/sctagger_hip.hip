@@ -146,11 +146,12 @@ struct Lane {
     const char *host_segs = nullptr;    // zero-copy batches: the same bytes on the host (the slow path copies them to `segs`)
     DevBuf segs, offs64, offs32, index_in;
     // work / results
-    DevBuf min_e, cnt, route, slots, slots_retry, list_retry, list_special, slot_off, wave_base, list_long, list_scan, list_dp, counters, hit_offs, sums, hits,
+    DevBuf min_e, cnt, route, slots, slots_retry, list_retry, list_special, list_special2, rec_special, rec_special2, slot_off, wave_base, list_long, list_scan, list_dp, counters, hit_offs, sums, hits,
         part_best, part_cnt, cnt_out;
     DevBuf arena_cur;   // SLOT_ARENAS cursors of the main launch's slot array, 64 bytes apart (sct_slot_arena)
     DevBuf j_planes, j_len, j_wave, j_cnt, j_slots, j_tup0, j_cnt0, j_tup1, j_cnt1;   // the partitioned join (k_join.hip.h)
     uint64_t slots_cap = 0, retry_cap = 0;
+    uint32_t rec_cap = 0;       // entries of rec_special / rec_special2 (SctSpecialRec): the first rec_cap rows of list_special / list_special2
     // where the kernels write the results the caller sees: the lane's own buffers (copied out afterwards) or, for a stream
     // call whose output arrays are page-locked, those arrays themselves through their device mapping
     uint8_t *min_e_ptr = nullptr;
@@ -179,7 +180,7 @@ struct Lane {
     }
     uint32_t *ctr() const { return counters.as<uint32_t>(); }
     void release() {
-        DevBuf *bufs[] = {&segs, &offs64, &offs32, &index_in, &min_e, &cnt, &route, &slots, &slots_retry, &list_retry, &list_special, &slot_off, &wave_base, &list_long,
+        DevBuf *bufs[] = {&segs, &offs64, &offs32, &index_in, &min_e, &cnt, &route, &slots, &slots_retry, &list_retry, &list_special, &list_special2, &rec_special, &rec_special2, &slot_off, &wave_base, &list_long,
                           &list_scan, &list_dp, &counters, &hit_offs, &sums, &hits, &part_best, &part_cnt, &cnt_out,
                           &arena_cur, &j_planes, &j_len, &j_wave, &j_cnt, &j_slots, &j_tup0, &j_cnt0, &j_tup1, &j_cnt1};
         for (DevBuf *b : bufs) b->release();
@@ -577,8 +578,12 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
         l.slots_cap = ((uint64_t)n1 + arena_round - 1) / arena_round * arena_round * K_SLOTS;
         l.retry_cap = (uint64_t)n1 * K_SLOTS < 65536 ? 65536 : (uint64_t)n1 * K_SLOTS;
         if (l.slots.ensure(4 * l.slots_cap) || l.slots_retry.ensure(4 * l.retry_cap) || l.slot_off.ensure(8 * n1) || l.wave_base.ensure(8 * (n1 / 64 + 2)) ||
-            l.list_retry.ensure(4 * n1) || l.list_special.ensure(4 * n1))
+            l.list_retry.ensure(4 * n1) || l.list_special.ensure(4 * n1) || l.list_special2.ensure(4 * n1))
             return g_code;
+        // planes of the rows listed for the special launch: room for an eighth of the rows (the others are decoded from their bytes)
+        const uint64_t rc = n1 / 8 < 65536 ? 65536 : n1 / 8;
+        l.rec_cap = (uint32_t)(rc < 0x7FFFFFFFull ? rc : 0x7FFFFFFFull);
+        if (l.rec_special.ensure(sizeof(SctSpecialRec) * (size_t)l.rec_cap) || l.rec_special2.ensure(sizeof(SctSpecialRec) * (size_t)l.rec_cap)) return g_code;
     }
     if (l.hits.ensure(4 * (size_t)(l.slots_cap + l.retry_cap + 1))) return g_code;
     if (bp.use_join && n < ((int64_t)1 << 30)) {
@@ -637,10 +642,13 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.slot_off = l.slot_off.as<uint64_t>();
     fa.wave_base = l.wave_base.as<uint64_t>();
     fa.list_special = l.list_special.as<int32_t>();
+    fa.rec_out = l.rec_special.as<SctSpecialRec>();
+    fa.rec_in = nullptr;
+    fa.rec_cap = l.rec_cap;
     fa.ctr = ctr;
     fa.bl = c->bl;
     fa.prefix_len = bp.prefix_len;
-    SctFilterVariant v{false, bp.rt_families, bp.use_slots && !bp.rt_families, bp.use_thirds, bp.use_wide, false, false};
+    SctFilterVariant v{false, bp.rt_families, bp.use_slots && !bp.rt_families, bp.use_thirds, bp.use_wide, false, false, false};
     {
         Timer t(c, l, "k_filter");
         fa.n = n;
@@ -690,6 +698,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         // to the exhaustive scan (list_scan).
         Timer t(c, l, "k_filter_retry");
         v.retry = true;
+        fa.rec_out = nullptr;
         fa.n = 0;
         fa.n_dev = ctr + CTR_RETRY;
         fa.rows = l.list_retry.as<int32_t>();
@@ -705,18 +714,34 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         // rows the main launch listed because one lane's planes cannot express them as the reference sees them (restricted window
         // starts; more than PLANE_MAX characters): the retry launch's shape with start masks and windows (filter_rows, SP).  Its lists
         // go to the retry launch's slot array; what it cannot hold goes on to list_long -> the scan kernels of the slow path.
+        // With bucket slots (the BASELINE shapes) in two stages: 16 rows per wave first — up to 4 windows and 80 list entries per row —,
+        // then 4 rows per wave for what that hands on.
         Timer t(c, l, "k_filter_special");
         v.retry = false;
         v.special = true;
         fa.n = 0;
-        fa.n_dev = ctr + CTR_SPECIAL;
-        fa.rows = l.list_special.as<int32_t>();
         fa.slots = l.slots_retry.as<uint32_t>();
         fa.slots_cap = l.retry_cap;
-        fa.list_defer = l.list_long.as<int32_t>();
-        fa.defer_count = ctr + CTR_LONG;
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR_RETRY);
         fa.arena_cursors = nullptr;
+        fa.n_dev = ctr + CTR_SPECIAL;
+        fa.rows = l.list_special.as<int32_t>();
+        fa.rec_in = l.rec_special.as<SctSpecialRec>();
+        fa.rec_out = nullptr;
+        if (v.slots) {
+            v.special16 = true;
+            fa.list_defer = l.list_special2.as<int32_t>();
+            fa.defer_count = ctr + CTR_SPECIAL2;
+            fa.rec_out = l.rec_special2.as<SctSpecialRec>();
+            launch_filter(bp.max_err, v, fa, capped((n + 15) / 16), capped((n + 15) / 16), st);
+            v.special16 = false;
+            fa.n_dev = ctr + CTR_SPECIAL2;
+            fa.rows = l.list_special2.as<int32_t>();
+            fa.rec_in = l.rec_special2.as<SctSpecialRec>();
+            fa.rec_out = nullptr;
+        }
+        fa.list_defer = l.list_long.as<int32_t>();
+        fa.defer_count = ctr + CTR_LONG;
         launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), capped((n + 3) / 4), st);
     }
 }
