@@ -40,6 +40,8 @@ if ROOT not in sys.path:
 
 from sctagger_amd import _native, shard, synth  # noqa: E402
 
+THREADS = 16   # the reference's default -t (/root/reference/scTagger.py:92-93): every timed call passes it (prefix length k = 2)
+
 WORKLOADS = {
     # name: (segments per GPU, barcodes, bl, max_err)
     "cfg2": (1_000_000, 5_000, 16, 2),
@@ -166,7 +168,7 @@ class Loops:
             except Exception:
                 pass
 
-    def e2e(self, steps, warmup, index_format, count_format, hits_format, zero_copy=True):
+    def e2e(self, steps, warmup, index_format, count_format, hits_format, zero_copy=True, threads=THREADS):
         m, n_seg = self.m, self.n_seg
         ifmt, cfmt = IDX[index_format], CNT[count_format]
         if 2 * self.bc.shape[0] > 65536:
@@ -180,7 +182,7 @@ class Loops:
         pcnt = m.host_array(n_seg + 1, _native._CNT_DTYPE[cfmt])
 
         def step():
-            return m.match_stream(self.psegs, pidx, self.max_err, 1, index_format=ifmt, count_format=cfmt, min_e=self.pme, counts=pcnt,
+            return m.match_stream(self.psegs, pidx, self.max_err, threads, index_format=ifmt, count_format=cfmt, min_e=self.pme, counts=pcnt,
                                   copy_hits=False, hits_format=hfmt)
         for _ in range(warmup):
             step()
@@ -200,7 +202,7 @@ class Loops:
         d2h_bytes = int(n_seg + pcnt[:n_seg + (1 if cfmt == _native.CNT_OFFS64 else 0)].nbytes + r[2].itemsize * self.hits)
         avg = {k: float(np.mean([x[0] for x in v])) for k, v in spans.items()}
         launches = {k: int(v[-1][1]) for k, v in spans.items()}
-        e2e = {"ms_per_step": 1e3 * elapsed / max(steps, 1), "index_format": index_format, "count_format": count_format,
+        e2e = {"ms_per_step": 1e3 * elapsed / max(steps, 1), "threads": threads, "index_format": index_format, "count_format": count_format,
                "hits_format": hits_format, "host_to_device_bytes": h2d_bytes, "device_to_host_bytes": d2h_bytes,
                "zero_copy": bool(zero_copy), "chunks": launches.get("k_filter", 0),
                "spans_ms": {k: round(v, 4) for k, v in avg.items()}}
@@ -209,17 +211,17 @@ class Loops:
             e2e["pcie_peak_GBps"] = PCIE_PEAK_GBS
         return e2e, elapsed
 
-    def resident(self, steps, warmup):
+    def resident(self, steps, warmup, threads=THREADS):
         m = self.m
         m.upload_segments(self.psegs, self.offs)
         for _ in range(max(1, min(warmup, 2))):
-            m.run(self.max_err, threads=1)
+            m.run(self.max_err, threads=threads)
         self.device_sync()
         self.barrier()
         per_kernel = {}
         t0 = time.perf_counter()
         for _ in range(steps):
-            self.hits = m.run(self.max_err, threads=1)
+            self.hits = m.run(self.max_err, threads=threads)
             for name, ms in m.last_timing():
                 per_kernel.setdefault(name, []).append(ms)
         self.device_sync()
@@ -227,6 +229,19 @@ class Loops:
         self.barrier()
         return {"ms_per_step": 1e3 * elapsed / max(steps, 1)}, {k: float(np.mean(v)) for k, v in per_kernel.items()}, elapsed
 
+    def pageable(self, steps, warmup, threads=THREADS):
+        """INTEGRATION.md §2's call as a maintainer pastes it: sct_match on ordinary (pageable) numpy arrays, int64 offsets in,
+        int64 CSR + a malloc'ed uint32 hit array out.  The library page-locks the arrays for the duration of the call."""
+        segs, offs = np.array(self.segs, copy=True), np.array(self.offs, copy=True)
+        for _ in range(max(1, warmup)):
+            self.m.match(segs, offs, self.max_err, threads)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = self.m.match(segs, offs, self.max_err, threads)
+        dt = (time.perf_counter() - t0) / max(steps, 1)
+        return {"ms_per_step": 1e3 * dt, "value": self.n_seg / dt, "hits": int(r[2].size), "threads": threads,
+                "what": "sct_match(ctx, segs, offs int64, n, max_err, threads, min_e, hit_offs int64, &hits, &n_hits) on pageable numpy arrays "
+                        "(INTEGRATION.md §2), result copied into a fresh numpy array as the binding there does"}
     def algorithmic_bytes(self):
         """per segment (L + 4) in + (1 + 4 + 4 h) out, plus the barcode set read once per launch."""
         h = self.hits / float(self.n_seg)
@@ -357,6 +372,75 @@ def other_config(name, device, steps, warmup):
         m.close()
 
 
+def noise_config(m, bc, segs, offs, max_err, steps, warmup, clean_e2e_ms, clean_resident_ms, frac=0.01):
+    """cfg3 with `frac` of the rows carrying one byte outside ACGT, at the reference's default -t 16: those rows' window starts are
+    restricted (/root/reference/scTagger.py:681) and the seed filter takes them in its special launch (until round 4: the
+    all-barcodes DP, 685 ms per 10 M rows at 1 %).  Same Matcher, same barcodes; -> its entry of `other_configs`."""
+    noisy, rows = synth.add_noise_bytes(segs, offs, frac)
+    loops = Loops(m, bc, noisy, offs, max_err)
+    e2e, _ = loops.e2e(steps, warmup, "len8", "u8", "u16")
+    res, avg, _ = loops.resident(steps, warmup)
+    paths = m.last_stats()
+    n_seg = offs.size - 1
+    out = {"workload": "cfg3 with one 'N' in %g %% of the non-empty rows (%d rows), -t %d" % (100 * frac, rows.size, THREADS),
+           "ms_per_step": e2e["ms_per_step"], "ms_per_step_resident": res["ms_per_step"],
+           "value_device_e2e": n_seg / (e2e["ms_per_step"] * 1e-3), "value_resident": n_seg / (res["ms_per_step"] * 1e-3),
+           "ms_per_step_clean": clean_e2e_ms, "ms_per_step_resident_clean": clean_resident_ms,
+           "step_over_clean": round(e2e["ms_per_step"] / clean_e2e_ms, 3) if clean_e2e_ms else None,
+           "resident_over_clean": round(res["ms_per_step"] / clean_resident_ms, 3) if clean_resident_ms else None,
+           "paths": paths, "device_e2e_spans_ms": e2e["spans_ms"], "kernels_ms": {k: round(v, 4) for k, v in avg.items()},
+           "before_round_4": "profiles/r04_noise_cliff_before.jsonl: 685 ms per step (k_dp_count 627 ms + k_dp_fill 48 ms)"}
+    m.sync()
+    m.release_host_arrays()
+    return out
+
+
+def strong_scaling(bc, segs, offs, max_err, device, ks=(1, 2, 4)):
+    """The route the command takes with `--devices d0 d1 ...`: ONE input, match_trie.run_get_matches_prefix_arrays(e, t, devices),
+    one host thread + context per entry, contiguous rid ranges, results concatenated on the host (the reference's Pool fan-out and
+    merge, /root/reference/scTagger.py:703-715).  Timed here with every entry on THIS box's one device: what it shows is the
+    host side (thread spans, time outside the library = upper bound of GIL-held time, the concatenation), not a speed-up."""
+    from sctagger_amd import match_trie
+    m = _native.Matcher(device)
+    out = []
+    try:
+        psegs = m.host_array(segs.size, np.uint8)
+        psegs[:] = segs
+        poffs = m.host_array(offs.size, np.int64)
+        poffs[:] = offs
+        match_trie.set_inputs([b.tobytes().decode() for b in bc], None, psegs, poffs)
+        for k in ks:
+            best = None
+            for _ in range(2):
+                spans = {}
+                t0 = time.perf_counter()
+                r = match_trie.run_get_matches_prefix_arrays(max_err, THREADS, devices=(device,) * k, spans=spans)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, spans, int(r[2].size))
+            dt, spans, hits = best
+            th = spans["threads"]
+            out.append({"devices": [device] * k, "seconds": round(dt, 4), "segments_per_s": (offs.size - 1) / dt, "hits": hits,
+                        "threads": [{kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in t.items()} for t in th],
+                        "in_library_s_max": round(max(t["context_s"] + t["set_barcodes_s"] + t["match_s"] + t["close_s"] for t in th), 4),
+                        "outside_library_s_max": round(max(t["slice_s"] for t in th), 4),
+                        "all_threads_done_s": round(spans["all_threads_done_s"], 4), "concat_s": round(spans["concat_s"], 4)})
+    finally:
+        m.close()
+    return {"what": strong_scaling.__doc__.split("\n")[0].strip(), "rows": int(offs.size - 1), "threads_flag": THREADS, "runs": out,
+            "note": "all entries are the same physical device here; on an 8-GPU node the per-thread match_s would run side by side. "
+                    "in_library = ctypes calls (GIL released); outside_library = numpy slicing of the shard (GIL held at most that long)"}
+
+
+def host_memcpy_GBps(nbytes=1 << 28):
+    a = np.ones(nbytes, dtype=np.uint8)
+    b = np.empty_like(a)
+    np.copyto(b, a)
+    t0 = time.perf_counter()
+    np.copyto(b, a)
+    return round(nbytes / (time.perf_counter() - t0) / 1e9, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -444,6 +528,11 @@ def main():
     if args.mode == "both" and world == 1 and args.index_format != "offs32" and offs[-1] < 2 ** 31:
         e2e_offs32, _ = loops.e2e(args.steps, args.warmup, "offs32", args.count_format, args.hits_format, args.zero_copy)
 
+    # INTEGRATION.md §2's exact call (pageable numpy arrays, 64-bit formats both ways), for the record
+    pageable = None
+    if args.mode == "both" and world == 1:
+        pageable = loops.pageable(max(2, min(args.steps, 5)), 1)
+
     # ---- figure (i): the same kernels on a batch that is resident in HBM (roofline of the dominant kernel) -------------
     res = None
     avg = {}
@@ -462,7 +551,7 @@ def main():
         best = None
         for _ in range(2):
             t0 = time.perf_counter(); m.upload_segments(loops.psegs, poffs); t1 = time.perf_counter()
-            m.run(max_err, threads=1); t2 = time.perf_counter()
+            m.run(max_err, threads=THREADS); t2 = time.perf_counter()
             m.download_into(loops.pme, pho, phi); t3 = time.perf_counter()
             cur = (t1 - t0, t2 - t1, t3 - t2)
             best = cur if best is None or sum(cur) < sum(best) else best
@@ -473,11 +562,19 @@ def main():
 
     headline_elapsed = e2e_elapsed if e2e_elapsed is not None else res_elapsed
     headline_elapsed, total_segments = shard.reduce_timing(dist, headline_elapsed, n_seg)
-    mine = {"rank": rank, "device": device, "numa_node": numa, "segments": n_seg, "seed": seed, "workload": wl,
+    mine = {"rank": rank, "device": device, "devices_visible": ndev, "pci_bus_id": _native.device_pci_bus_id(device), "numa_node": numa,
+            "cpus_allowed": len(os.sched_getaffinity(0)), "host_memcpy_GBps": host_memcpy_GBps(),
+            "k_filter_input_GBps": e2e.get("k_filter_input_GBps") if e2e else None,
+            "segments": n_seg, "seed": seed, "workload": wl,
             "e2e_ms_per_step": round(e2e["ms_per_step"], 4) if e2e else None,
             "resident_ms_per_step": round(res["ms_per_step"], 4) if res else None,
             "e2e_spans_ms": e2e["spans_ms"] if e2e else None}
     per_rank = shard.gather_objects(dist, mine)
+    if world > 1 and ndev >= world and len({p["device"] for p in per_rank}) < world:
+        # every rank must have a GPU of its own when the box has enough of them: a scaling figure from ranks that share one is void
+        if rank == 0:
+            sys.stderr.write("bench.py: %d ranks resolved to devices %s on a box with %d devices\n" % (world, [p["device"] for p in per_rank], ndev))
+        sys.exit(3)
     res_all = None
     if res is not None:
         res_all, _ = shard.reduce_timing(dist, res["ms_per_step"], n_seg)
@@ -494,7 +591,7 @@ def main():
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": workload_desc, "segments_per_gpu": n_seg, "barcodes": n_bc, "max_err": max_err,
+            "config": {"workload": workload_desc, "segments_per_gpu": n_seg, "barcodes": n_bc, "max_err": max_err, "threads": THREADS,
                        "path": "exhaustive" if args.force_exhaustive else "seed-filter", "paths": m.last_stats(),
                        "seam": "sct_match_stream: %s index in, %s counts + %s hit lists out, page-locked host buffers" % (
                            args.index_format, args.count_format, hits_format)},
@@ -503,6 +600,8 @@ def main():
             "value_device_e2e": (total_segments / (ms_per_step / 1e3)) if e2e else None,
             "value_resident": (total_segments / (res_all / 1e3)) if res_all else None,
             "value_device_e2e_offs32": (n_seg / (e2e_offs32["ms_per_step"] * 1e-3)) if e2e_offs32 else None,
+            "value_sct_match_pageable": pageable["value"] if pageable else None,
+            "sct_match_pageable": pageable,
             "ms_per_step_resident": res_all,
             "hits_per_segment": round(h, 4),
             "device_e2e": e2e,
@@ -514,11 +613,21 @@ def main():
             "per_rank": per_rank,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(bc, segs, offs, max_err, args.cpu_sample)
+            # the reference's pool at -t 16 (its default), 64 and the host's core count (4^k >= t prefix tasks, each of which scans
+            # every segment: more tasks are not always faster); `cpu_baseline` = the best of the ladder, all of it listed
             cores = host_cores()
-            if cores > 16:
-                # the reference's pool at -t = core count (north_star: "on the GPU box's host cores"): 4^k >= t prefix tasks
-                out["cpu_baseline_all_cores"] = cpu_baseline(bc, segs, offs, max_err, args.cpu_sample, threads=cores, workers=cores)
+            ladder = [cpu_baseline(bc, segs, offs, max_err, args.cpu_sample, threads=t, workers=min(t, cores)) for t in sorted({16, min(64, max(cores, 16)), max(cores, 16)})]
+            best = max(ladder, key=lambda b: b["value"])
+            out["cpu_baseline"] = dict(best, ladder=[{"threads_flag": int(b["sample"].split("reference -t ")[1].split(" ")[0]), "value": b["value"],
+                                                      "cores": b["cores"], "seconds": b["seconds"]} for b in ladder])
+        if world == 1 and not args.no_other_configs and args.mode == "both" and not args.segments and wl == "cfg3":
+            try:
+                noise = noise_config(m, bc, segs, offs, max_err, max(2, min(args.steps, 5)), 1,
+                                     e2e["ms_per_step"] if e2e else None, res["ms_per_step"] if res else None)
+            except Exception as e:
+                noise = {"error": repr(e)}
+        else:
+            noise = None
         m.close()
         m = None
         if world == 1 and not args.no_other_configs and args.mode == "both" and not args.segments and wl == "cfg3":
@@ -528,7 +637,12 @@ def main():
                     oc[name] = other_config(name, device, max(2, min(args.steps, 5)), 1)
                 except Exception as e:   # informative; the bench line must come out
                     oc[name] = {"error": repr(e)}
+            oc["cfg3_noise"] = noise
             out["other_configs"] = oc
+            try:
+                out["strong_scaling_one_input"] = strong_scaling(bc, segs, offs, max_err, device)
+            except Exception as e:
+                out["strong_scaling_one_input"] = {"error": repr(e)}
         if world == 1 and not args.no_cli and args.mode == "both":
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -190,8 +190,17 @@ int sct_sync(sct_ctx *ctx);
  *   "register"         0|1   1 (default): pageable segs / index / min_e / counts buffers of a stream call of at least 4 MB of
  *                            segments are page-locked for the duration of the call (hipHostRegister) and then read and
  *                            written in place as well; 0: they go through staged copies
+ *   "fail_alloc_at"    k     TEST HOOK for the error paths (error codes instead of the reference's asserts,
+ *                            scTagger.py:140-143, :760-761): the k-th allocation attempt the context makes from now on — device
+ *                            memory, page-locked host memory, page-locking of a caller buffer, a lane's stream — fails once as if
+ *                            memory had run out (SCT_E_NOMEM; a caller buffer that cannot be page-locked is copied instead,
+ *                            silently); 0 = off.  sct_get_option "alloc_calls" counts the attempts since it was set.
  */
 int sct_set_option(sct_ctx *ctx, const char *key, int64_t value);
+/* Reads an option back ("join", "lanes", "chunk_rows", "zero_copy", "force_exhaustive", "fail_alloc_at") or one of the read-only
+ * values "alloc_calls" (allocation attempts since "fail_alloc_at" was last set), "device_free_bytes", "device_total_bytes"
+ * (hipMemGetInfo of the context's device). */
+int sct_get_option(sct_ctx *ctx, const char *key, int64_t *value);
 
 /*
  * Device time of the last sct_run / sct_match_stream / sct_match by kernel name, measured with HIP events on the stream

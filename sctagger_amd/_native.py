@@ -21,7 +21,7 @@ EXPORTS = (
     "sct_device_count", "sct_create", "sct_destroy", "sct_last_error", "sct_prefix_len", "sct_set_barcodes",
     "sct_match", "sct_free_hits", "sct_upload_segments", "sct_run", "sct_download", "sct_sync", "sct_set_option",
     "sct_last_timing", "sct_last_stats", "sct_wl_set", "sct_wl_count", "sct_adapter_align", "sct_free_locs",
-    "sct_host_alloc", "sct_host_free", "sct_match_stream", "sct_last_timing_ex", "sct_device_pci_bus_id",
+    "sct_host_alloc", "sct_host_free", "sct_match_stream", "sct_last_timing_ex", "sct_device_pci_bus_id", "sct_get_option",
 )
 
 # index / count formats of sct_match_stream (include/sctagger_hip.h)
@@ -69,6 +69,7 @@ def load():
     lib.sct_download.argtypes = [vp, vp, vp, vp]
     lib.sct_sync.argtypes = [vp]
     lib.sct_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+    lib.sct_get_option.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i64)]
     lib.sct_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     lib.sct_last_timing_ex.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32), ctypes.c_int]
     lib.sct_match_stream.argtypes = [vp, vp, i64, vp, i32, i64, i32, i32, vp, vp, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
@@ -163,6 +164,11 @@ class Matcher:
 
     def set_option(self, key, value):
         self._check(self._lib.sct_set_option(self._ctx, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = ctypes.c_int64()
+        self._check(self._lib.sct_get_option(self._ctx, key.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def set_barcodes(self, bc, bl=None):
         """bc: uint8[n, bl] array, or a list of equal-length str/bytes (forward barcodes)."""

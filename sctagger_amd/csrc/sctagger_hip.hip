@@ -94,6 +94,26 @@ static inline unsigned blocks_for(int64_t n, int per) {
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
+// Fault injection for the tests of the error paths (option "fail_alloc_at" = k: the k-th allocation attempt the context makes from
+// now on — hipMalloc in DevBuf::ensure, hipHostMalloc, hipHostRegister, a lane's stream — fails once, as if memory had run out;
+// option "alloc_calls" reads how many attempts there were).  The counters live in the context the calling thread's API call
+// belongs to (FaultScope); outside an API call nothing is counted.
+struct FaultCounters {
+    int64_t fail_at = 0;   // > 0: attempts left until the injected failure
+    int64_t calls = 0;     // attempts since "fail_alloc_at" was last set
+};
+static thread_local FaultCounters *t_fault = nullptr;
+struct FaultScope {
+    FaultCounters *prev;
+    explicit FaultScope(FaultCounters *f) : prev(t_fault) { t_fault = f; }
+    ~FaultScope() { t_fault = prev; }
+};
+static bool inject_alloc_failure() {
+    if (!t_fault) return false;
+    t_fault->calls++;
+    return t_fault->fail_at > 0 && --t_fault->fail_at == 0;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -103,9 +123,10 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
+        hipError_t e = inject_alloc_failure() ? hipErrorOutOfMemory : hipMalloc(&p, want);
         if (e != hipSuccess) {
             (void)hipGetLastError();
+            p = nullptr;
             return fail(e == hipErrorOutOfMemory ? SCT_E_NOMEM : SCT_E_HIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
         }
         cap = want;
@@ -235,6 +256,7 @@ struct sct_ctx {
         double ms = 0;
         int launches = 0;
     };
+    FaultCounters fault;       // test-only fault injection (options "fail_alloc_at", "alloc_calls")
     std::vector<std::pair<const char *, Span>> last_ms;
     int64_t stats[6] = {0, 0, 0, 0, 0, 0};   // rows by path: filter, exhaustive scan, restricted-start DP; hits; rows retried; rows of the special launch
 
@@ -281,13 +303,14 @@ static void collect_timing(sct_ctx *c, Lane &l) {
 
 static int lane_create(Lane **out) {
     Lane *l = new Lane();
-    hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
+    hipError_t e = inject_alloc_failure() ? hipErrorOutOfMemory : hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&l->done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&l->h_ctr, sizeof(uint32_t) * CTR_WORDS, hipHostMallocDefault);
+    if (e == hipSuccess) e = inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc((void **)&l->h_ctr, sizeof(uint32_t) * CTR_WORDS, hipHostMallocDefault);
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         l->release();
         delete l;
-        return fail(SCT_E_HIP, "creating a lane: %s", hipGetErrorString(e));
+        return fail(e == hipErrorOutOfMemory ? SCT_E_NOMEM : SCT_E_HIP, "creating a lane: %s", hipGetErrorString(e));
     }
     *out = l;
     return SCT_OK;
@@ -362,10 +385,13 @@ extern "C" void sct_destroy(sct_ctx *c) {
 // (copies from or to pageable buffers are staged through a bounce buffer by the runtime and block the calling thread)
 extern "C" void *sct_host_alloc(sct_ctx *c, size_t bytes) {
     if (!c) return nullptr;
+    FaultScope fs(&c->fault);
     if (hipSetDevice(c->device) != hipSuccess) return nullptr;
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
-        fail(SCT_E_HIP, "hipHostMalloc(%zu) failed", bytes);
+    const hipError_t e = inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(e == hipErrorOutOfMemory ? SCT_E_NOMEM : SCT_E_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));   // sct_last_error tells which
         return nullptr;
     }
     return p;
@@ -375,6 +401,24 @@ extern "C" void sct_host_free(sct_ctx *c, void *p) {
     if (!p) return;
     if (c) (void)hipSetDevice(c->device);
     (void)hipHostFree(p);
+}
+
+extern "C" int sct_get_option(sct_ctx *c, const char *key, int64_t *value) {
+    if (!c || !key || !value) return fail(SCT_E_ARG, "sct_get_option: NULL argument");
+    if (!strcmp(key, "fail_alloc_at")) *value = c->fault.fail_at;
+    else if (!strcmp(key, "alloc_calls")) *value = c->fault.calls;
+    else if (!strcmp(key, "join")) *value = c->join_mode;
+    else if (!strcmp(key, "lanes")) *value = c->stream_lanes;
+    else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
+    else if (!strcmp(key, "zero_copy")) *value = c->zero_copy;
+    else if (!strcmp(key, "force_exhaustive")) *value = c->force_exhaustive;
+    else if (!strcmp(key, "device_free_bytes") || !strcmp(key, "device_total_bytes")) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        *value = (int64_t)(key[7] == 'f' ? fr : tot);
+    } else return fail(SCT_E_ARG, "unknown option '%s'", key);
+    return SCT_OK;
 }
 
 extern "C" int sct_sync(sct_ctx *c) {
@@ -399,7 +443,11 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
         c->chunk_rows = value;
     } else if (!strcmp(key, "zero_copy")) c->zero_copy = value != 0;
     else if (!strcmp(key, "register")) c->auto_register = value != 0;
-    else if (!strcmp(key, "lanes")) {
+    else if (!strcmp(key, "fail_alloc_at")) {   // tests of the error paths: see FaultCounters
+        if (value < 0) return fail(SCT_E_ARG, "fail_alloc_at must be >= 0");
+        c->fault.fail_at = value;
+        c->fault.calls = 0;
+    } else if (!strcmp(key, "lanes")) {
         if (value < 1 || value > STREAM_LANES_MAX) return fail(SCT_E_ARG, "lanes must be in 1 .. %d", STREAM_LANES_MAX);
         c->stream_lanes = (int)value;
     } else return fail(SCT_E_ARG, "unknown option '%s'", key);
@@ -419,6 +467,7 @@ static inline uint8_t comp_byte(uint8_t b) {
 
 extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t bl) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    FaultScope fault_scope(&c->fault);
     if (n < 0 || (n > 0 && !bc)) return fail(SCT_E_ARG, "sct_set_barcodes: bad barcode buffer");
     if (bl < 1) return fail(SCT_E_ARG, "barcode length must be positive (got %d)", bl);
     if (bl > SCT_MAX_BL) return fail(SCT_E_UNSUPPORTED, "barcode length %d exceeds the supported maximum %d", bl, SCT_MAX_BL);
@@ -1025,6 +1074,7 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
 // check_bytes: refuse any byte >= 128 (the two neighbouring stages); the match_trie path checks the rows it reads instead
 static int upload_segments(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n, bool check_bytes) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    FaultScope fault_scope(&c->fault);
     if (n < 0 || !offs) return fail(SCT_E_ARG, "sct_upload_segments: bad offsets");
     if (n >= 0x7FFFFFF0) return fail(SCT_E_ARG, "at most 2^31-16 segments per call (shard the input)");
     if (offs[0] != 0) return fail(SCT_E_ARG, "offs[0] must be 0");
@@ -1065,6 +1115,7 @@ extern "C" int sct_upload_segments(sct_ctx *c, const char *segs, const int64_t *
 
 extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_hits_out) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    FaultScope fault_scope(&c->fault);
     if (!c->have_bc) return fail(SCT_E_STATE, "sct_run before sct_set_barcodes");
     Lane &l = c->lane0();
     if (l.n_seg < 0 || !l.wide) return fail(SCT_E_STATE, "sct_run before sct_upload_segments");
@@ -1087,6 +1138,7 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
 
 extern "C" int sct_download(sct_ctx *c, uint8_t *min_e, int64_t *hit_offs, uint32_t *hits) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    FaultScope fault_scope(&c->fault);
     Lane &l = c->lane0();
     if (!l.have_result) return fail(SCT_E_STATE, "sct_download without a completed sct_run");
     HIPCHK(hipSetDevice(c->device));
@@ -1118,7 +1170,7 @@ static int ensure_host_hits(sct_ctx *c, size_t entries) {
     size_t want = c->h_hits_cap ? c->h_hits_cap : (size_t)1 << 20;
     while (want < entries) want *= 2;
     uint32_t *p = nullptr;
-    hipError_t e = hipHostMalloc((void **)&p, want * sizeof(uint32_t), hipHostMallocDefault);
+    hipError_t e = inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc((void **)&p, want * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail(e == hipErrorOutOfMemory ? SCT_E_NOMEM : SCT_E_HIP, "hipHostMalloc(%zu) for the hit buffer: %s", want * sizeof(uint32_t), hipGetErrorString(e));
@@ -1158,6 +1210,7 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
                                 int32_t max_err, int32_t threads, uint8_t *min_e, void *counts, int32_t count_format, int32_t hits_format,
                                 const void **hits_out, int64_t *n_hits_out) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    FaultScope fault_scope(&c->fault);
     if (!hits_out || !n_hits_out) return fail(SCT_E_ARG, "sct_match_stream: NULL output pointer");
     *hits_out = nullptr;
     *n_hits_out = 0;
@@ -1205,6 +1258,10 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     // the first time, next to nothing when the same pages come again) and then take the zero-copy route too — numpy arrays
     // handed to sct_match cost 20 ms per 10 M rows through staged copies, 9 ms this way.  Whatever cannot be registered
     // (already partly registered, read-only mappings) is copied as before.
+    // Two of the caller's arrays may share a PAGE (numpy's min_e and hit_offs of one sct_match call are neighbours on the heap):
+    // page-locking them one by one registers that page twice, and a kernel's write to it then faulted ("Memory access fault by
+    // GPU", round 4's first run of the pageable bench leg).  So the candidates are merged first: arrays whose page ranges touch or
+    // overlap are locked as ONE range, every page once.
     struct Registered {
         void *p[4] = {nullptr, nullptr, nullptr, nullptr};
         int n = 0;
@@ -1215,16 +1272,33 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     } registered;
     const size_t counts_bytes = count_format == SCT_CNT_OFFS64 ? 8 * (size_t)(n + 1) : count_format == SCT_CNT_U32 ? 4 * (size_t)n : (size_t)n;
     const size_t index_bytes = index_entry_size(index_format) * (size_t)(by_offs ? n + 1 : n);
-    auto lock_pages = [&](const void *p, size_t bytes) {
-        if (!c->zero_copy || !c->auto_register || !p || bytes < ((size_t)1 << 20) || device_view(p)) return;
-        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) registered.p[registered.n++] = const_cast<void *>(p);
-        (void)hipGetLastError();
-    };
-    if ((size_t)seg_bytes >= ((size_t)4 << 20)) {
-        lock_pages(segs, (size_t)seg_bytes);
-        lock_pages(index, index_bytes);
-        lock_pages(min_e, (size_t)n);
-        lock_pages(counts, counts_bytes);  // (64-bit offsets are copied down, faster into locked pages)
+    if (c->zero_copy && c->auto_register && (size_t)seg_bytes >= ((size_t)4 << 20)) {
+        struct Range {
+            uintptr_t lo, hi;   // whole pages
+        } rg[4];
+        int nr = 0;
+        const uintptr_t page = 4096;
+        auto candidate = [&](const void *p, size_t bytes) {
+            if (!p || bytes < ((size_t)1 << 20) || device_view(p)) return;
+            rg[nr].lo = (uintptr_t)p & ~(page - 1);
+            rg[nr].hi = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
+            nr++;
+        };
+        candidate(segs, (size_t)seg_bytes);
+        candidate(index, index_bytes);
+        candidate(min_e, (size_t)n);
+        candidate(counts, counts_bytes);  // (64-bit offsets are copied down, faster into locked pages)
+        std::sort(rg, rg + nr, [](const Range &a, const Range &b) { return a.lo < b.lo; });
+        int k = 0;
+        for (int i = 1; i < nr; i++) {
+            if (rg[i].lo <= rg[k].hi) rg[k].hi = std::max(rg[k].hi, rg[i].hi);
+            else rg[++k] = rg[i];
+        }
+        for (int i = 0; i < (nr ? k + 1 : 0); i++) {
+            if (!inject_alloc_failure() && hipHostRegister((void *)rg[i].lo, (size_t)(rg[i].hi - rg[i].lo), hipHostRegisterDefault) == hipSuccess)
+                registered.p[registered.n++] = (void *)rg[i].lo;
+            (void)hipGetLastError();
+        }
     }
     const uint8_t *zc_segs = (const uint8_t *)device_view(segs);
     const char *zc_index = (const char *)device_view(index);
@@ -1482,6 +1556,7 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
 extern "C" int sct_match(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n, int32_t max_err, int32_t threads,
                          uint8_t *min_e, int64_t *hit_offs, uint32_t **hits, int64_t *n_hits) {
     if (!hits || !n_hits || !min_e || !hit_offs) return fail(SCT_E_ARG, "sct_match: NULL output pointer");
+    FaultScope fault_scope(c ? &c->fault : nullptr);
     *hits = nullptr;
     *n_hits = 0;
     if (n < 0 || !offs) return fail(SCT_E_ARG, "sct_match: bad offsets");
@@ -1489,7 +1564,7 @@ extern "C" int sct_match(sct_ctx *c, const char *segs, const int64_t *offs, int6
     int64_t total = 0;
     int rc = sct_match_stream(c, segs, offs[n], offs, SCT_IDX_OFFS64, n, max_err, threads, min_e, hit_offs, SCT_CNT_OFFS64, SCT_HITS_U32, &h, &total);
     if (rc) return rc;
-    uint32_t *out = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(total ? total : 1));
+    uint32_t *out = inject_alloc_failure() ? nullptr : (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(total ? total : 1));
     if (!out) return fail(SCT_E_NOMEM, "out of host memory for %lld hits", (long long)total);
     if (total) memcpy(out, h, sizeof(uint32_t) * (size_t)total);
     *hits = out;
@@ -1532,6 +1607,7 @@ static void wl_pack(const uint8_t *key, int len, bool rc, uint32_t k[4]) {
 
 extern "C" int sct_wl_set(sct_ctx *c, const char *keys, const int32_t *key_lens, int32_t n) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    FaultScope fault_scope(&c->fault);
     if (n < 0 || (n > 0 && (!keys || !key_lens))) return fail(SCT_E_ARG, "sct_wl_set: bad arguments");
     HIPCHK(hipSetDevice(c->device));
     int64_t total = 0;
@@ -1591,6 +1667,7 @@ extern "C" int sct_wl_set(sct_ctx *c, const char *keys, const int32_t *key_lens,
 extern "C" int sct_wl_count(sct_ctx *c, const char *segs, const int64_t *offs, const uint8_t *skip, int64_t n, int64_t *counts,
                             int64_t *first_seen) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    FaultScope fault_scope(&c->fault);
     if (c->wl_n < 0) return fail(SCT_E_STATE, "sct_wl_count before sct_wl_set");
     if (!counts || !first_seen || (n > 0 && !skip)) return fail(SCT_E_ARG, "sct_wl_count: NULL argument");
     int rc = upload_segments(c, segs, offs, n, true);
@@ -1632,6 +1709,7 @@ extern "C" int sct_wl_count(sct_ctx *c, const char *segs, const int64_t *offs, c
 extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, const char *reads, const int64_t *offs, int64_t n,
                                  int8_t *strand, int32_t *dist, int64_t *loc_offs, int32_t **locs, int64_t *n_locs) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
+    FaultScope fault_scope(&c->fault);
     if (!adapter || !strand || !dist || !loc_offs || !locs || !n_locs) return fail(SCT_E_ARG, "sct_adapter_align: NULL argument");
     *locs = nullptr;
     *n_locs = 0;

@@ -108,6 +108,8 @@ def concat_shards(results):
 
     This is the whole multi-GPU merge: segments are independent, so unlike the reference's per-rid
     min/union over prefix tasks (:705-715) nothing has to be reconciled."""
+    if len(results) == 1:
+        return results[0]         # one shard: nothing to rebase, nothing to copy
     min_e = np.concatenate([r[0] for r in results]) if results else np.empty(0, np.uint8)
     hits = np.concatenate([r[2] for r in results]) if results else np.empty(0, np.uint32)
     total = 1 + sum(r[1].size - 1 for r in results)
@@ -128,12 +130,16 @@ def _barcode_matrix(bl):
     return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), bl)
 
 
-def run_get_matches_prefix_arrays(max_error, threads, devices=(0,), barcode_length=None):
+def run_get_matches_prefix_arrays(max_error, threads, devices=(0,), barcode_length=None, spans=None):
     """The seam, as arrays: -> (min_e uint8[n], hit_offs int64[n+1], hits uint32[total]).
 
     hits are (bid << 1 | strand), strand 1 = forward, ascending per segment == sorted(bids) of the
     reference (:789).  `threads` only sets the reference's prefix length (non-ACGT window rule).
-    With several devices the rids are cut into contiguous ranges, one host thread + context each."""
+    With several devices the rids are cut into contiguous ranges, one host thread + context each
+    (the reference's Pool(threads) fan-out, :703-715, over devices instead of window prefixes).
+    `spans` (a dict, optional) receives where the time went: per device thread the seconds inside the library
+    (context, tables, match: the GIL is released there) and outside it, and the host-side concatenation."""
+    import time
     bl = barcode_length if barcode_length is not None else (len(barcodes[0]) if barcodes else 16)
     bc = _barcode_matrix(bl)
     n = lr_segs_idxs.size - 1
@@ -141,15 +147,25 @@ def run_get_matches_prefix_arrays(max_error, threads, devices=(0,), barcode_leng
     ranges = shard_ranges(n, len(devices))
     results = [None] * len(devices)
     errors = []
+    per_thread = [None] * len(devices)
+    t_call = time.perf_counter()
 
     def work(i):
         try:
+            t0 = time.perf_counter()
             lo, hi = ranges[i]
             offs = lr_segs_idxs[lo:hi + 1] - lr_segs_idxs[lo]
             segs = lr_segs[lr_segs_idxs[lo]:lr_segs_idxs[hi]]
+            t1 = time.perf_counter()
             with _native.Matcher(devices[i]) as m:
+                t2 = time.perf_counter()
                 m.set_barcodes(bc, bl)
+                t3 = time.perf_counter()
                 results[i] = m.match(segs, offs, max_error, threads)
+                t4 = time.perf_counter()
+            t5 = time.perf_counter()
+            per_thread[i] = {"device": devices[i], "rows": int(hi - lo), "start_s": t0 - t_call, "slice_s": t1 - t0, "context_s": t2 - t1,
+                             "set_barcodes_s": t3 - t2, "match_s": t4 - t3, "close_s": t5 - t4, "end_s": t5 - t_call}
         except BaseException as e:  # re-raised on the caller's thread
             errors.append(e)
 
@@ -163,7 +179,13 @@ def run_get_matches_prefix_arrays(max_error, threads, devices=(0,), barcode_leng
             t.join()
     if errors:
         raise errors[0]
-    return concat_shards(results)
+    t_joined = time.perf_counter()
+    out = concat_shards(results)
+    if spans is not None:
+        spans["threads"] = per_thread
+        spans["all_threads_done_s"] = t_joined - t_call
+        spans["concat_s"] = time.perf_counter() - t_joined
+    return out
 
 
 def run_get_matches_prefix(max_error, threads, devices=(0,)):
