@@ -17,34 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define WINDOW 32768
-#define LL_BITS 11
-#define D_BITS 8
-#define PRE_BITS 7
-/* primary table + sub-tables: every sub-table belongs to one primary slot with at least one code longer than the primary
- * width, so there are at most as many as symbols, each of at most 2^(15 - width) entries */
-#define LL_SIZE (2048 + 288 * 16)
-#define D_SIZE (256 + 32 * 128)
-#define PRE_SIZE 128
-
-/* table entries: bits 0..7 = bits to take from the stream for this step, bits 8..11 = extra bits that follow a length / distance
- * code (or the index width of a sub-table), bits 12..15 = kind, bits 16..31 = literal, base value, or sub-table index */
-#define K_LIT 0x1000u
-#define K_EOB 0x2000u
-#define K_SUB 0x4000u
-#define K_BAD 0x8000u          /* unassigned code */
-
-typedef struct {
-    const uint8_t *in, *in_end, *in_next;
-    uint64_t bitbuf;
-    int bitcount;
-    int phase;        /* 0 = at a block header, 1 = inside a Huffman block, 2 = inside a stored block, 3 = stream finished */
-    int final_block;
-    uint32_t stored_left;
-    uint32_t win_fill; /* valid bytes in window[] */
-    uint32_t ll[LL_SIZE], dd[D_SIZE];
-    uint8_t window[WINDOW];
-} sct_inf;
+#include "sct_inflate_impl.h"
 
 static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -155,25 +128,31 @@ void sctio_inflate_set_input(void *p, const uint8_t *in, int64_t len) {
     s->final_block = 0;
     s->stored_left = 0;
     s->win_fill = 0;
+    s->stop_bit = -1;
 }
 
-/* bits: make sure `n` (<= 32) are there; returns 0 if the input ran out */
-static inline int need_bits(sct_inf *s, int n) {
-    while (s->bitcount < n) {
-        if (s->in_next >= s->in_end) return 0;
-        s->bitbuf |= (uint64_t)*s->in_next++ << s->bitcount;
-        s->bitcount += 8;
+/* stop at the first block boundary at or behind bit `stop_bit` of the input (status 2 of sctio_inflate_run); -1 = never */
+void sctio_inflate_set_stop(void *p, int64_t stop_bit) { ((sct_inf *)p)->stop_bit = stop_bit; }
+/* where the decoder stands: bit position of the next unread bit, and its history (window[WINDOW], the last *win_fill bytes valid) */
+void sctio_inflate_get_state(void *p, int64_t *bitpos, uint8_t *window, uint32_t *win_fill) {
+    const sct_inf *s = (const sct_inf *)p;
+    *bitpos = sctinf_bitpos(s);
+    memcpy(window, s->window, WINDOW);
+    *win_fill = s->win_fill;
+}
+
+void sctinf_start_at(sct_inf *s, const uint8_t *in, int64_t len, int64_t bitpos, const uint8_t *window, uint32_t win_fill) {
+    sctio_inflate_set_input(s, in, len);
+    s->in_next = in + (bitpos >> 3);
+    if (s->in_next > s->in_end) s->in_next = s->in_end;
+    if (bitpos & 7) {
+        if (need_bits(s, (int)(bitpos & 7))) take_bits(s, (int)(bitpos & 7));
     }
-    return 1;
-}
-static inline uint32_t take_bits(sct_inf *s, int n) {
-    const uint32_t v = (uint32_t)(s->bitbuf & (((uint64_t)1 << n) - 1));
-    s->bitbuf >>= n;
-    s->bitcount -= n;
-    return v;
+    if (win_fill) memcpy(s->window + WINDOW - win_fill, window + WINDOW - win_fill, win_fill);
+    s->win_fill = win_fill;
 }
 
-static int read_block_header(sct_inf *s) {
+int sctinf_read_block_header(sct_inf *s) {
     if (!need_bits(s, 3)) return -3;
     s->final_block = (int)take_bits(s, 1);
     const uint32_t type = take_bits(s, 2);
@@ -256,12 +235,6 @@ static int read_block_header(sct_inf *s) {
     return 0;
 }
 
-static inline uint64_t load64(const uint8_t *p) {
-    uint64_t v;
-    memcpy(&v, p, 8);
-    return v;
-}
-
 /*
  * Decode into out[WINDOW .. WINDOW + cap): the first WINDOW bytes of `out` receive the previous 32 KiB of output (history for the
  * matches).  Returns the number of bytes produced; *status = 0: the block is full, call again with the next one; 1: the stream
@@ -273,7 +246,7 @@ int64_t sctio_inflate_run(void *p, uint8_t *out, int64_t cap, int32_t *status, i
     uint8_t *const hist = out + WINDOW - s->win_fill;     /* oldest byte a match may reach */
     memcpy(hist, s->window + WINDOW - s->win_fill, s->win_fill);
     uint8_t *o = out + WINDOW, *const o_begin = o, *const o_end = o + cap;
-    int rc = 0;
+    int rc = 0, stopped = 0;
     *status = 0;
     if (cap < 65536) {
         *status = -1;
@@ -281,7 +254,7 @@ int64_t sctio_inflate_run(void *p, uint8_t *out, int64_t cap, int32_t *status, i
     }
     while (s->phase != 3) {
         if (s->phase == 0) {
-            rc = read_block_header(s);
+            rc = sctinf_read_block_header(s);
             if (rc) break;
             continue;
         }
@@ -298,6 +271,10 @@ int64_t sctio_inflate_run(void *p, uint8_t *out, int64_t cap, int32_t *status, i
             s->stored_left -= k;
             if (s->stored_left) break;  /* block full */
             s->phase = s->final_block ? 3 : 0;
+            if (s->phase == 0 && s->stop_bit >= 0 && sctinf_bitpos(s) >= s->stop_bit) {
+                stopped = 1;
+                break;
+            }
             continue;
         }
         /* ---- a Huffman block ---- */
@@ -482,6 +459,10 @@ int64_t sctio_inflate_run(void *p, uint8_t *out, int64_t cap, int32_t *status, i
         if (rc) break;
         if (done == 1) s->phase = s->final_block ? 3 : 0;
         if (done == 2) break;
+        if (s->phase == 0 && s->stop_bit >= 0 && sctinf_bitpos(s) >= s->stop_bit) {
+            stopped = 1;
+            break;
+        }
     }
     /* remember the last 32 KiB for the next block's matches */
     {
@@ -491,6 +472,7 @@ int64_t sctio_inflate_run(void *p, uint8_t *out, int64_t cap, int32_t *status, i
         s->win_fill = keep;
     }
     if (rc) *status = rc;
+    else if (stopped) *status = 2;   /* at a block boundary at or behind stop_bit (sctinf_bitpos says where) */
     else if (s->phase == 3) {
         *status = 1;
         /* whole bytes still in the bit buffer were not consumed */

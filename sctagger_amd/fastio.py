@@ -274,13 +274,16 @@ class GzipChunkWriter:
         self.f = open(path, "wb")
         self.level = level
         self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
-        self.pending = []
+        self.max_pending = 2 * max(1, threads)      # every thread busy and one piece waiting for it (round 3: 32 in all — at 10^8
+        self.pending = []                           # rows the writer, not the device, was what the command waited for)
 
     def write(self, data):
         if not data:
             return
         self.pending.append(self.pool.submit(_gzip_member, self.level, data))
-        while len(self.pending) > 32:
+        while len(self.pending) > self.max_pending:
+            self.f.write(self.pending.pop(0).result())
+        while self.pending and self.pending[0].done():      # whatever is finished goes out now, in order
             self.f.write(self.pending.pop(0).result())
 
     def close(self):

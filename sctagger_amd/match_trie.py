@@ -230,7 +230,7 @@ def _match_trie_streaming(args, devices, level, devs=None):
     if args.outfile.endswith("gz"):
         # (10^7 rows are 420 MB of output: 8 CPU-seconds of deflate at level 4 — the pool, not the device, is what a plain-text
         # input waits for)
-        sink = fastio.GzipChunkWriter(tmp, level, threads=min(64, max(4, (os.cpu_count() or 8) // 2)))
+        sink = fastio.GzipChunkWriter(tmp, level, threads=min(128, max(4, (os.cpu_count() or 8) // 2)))
     else:
         sink = open(tmp, "wb")
     import time

@@ -56,6 +56,25 @@ def _iolib():
         lib.sctio_inflate_set_input.restype = None
         lib.sctio_inflate_run.argtypes = [vp, vp, i64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(i64)]
         lib.sctio_inflate_run.restype = i64
+        lib.sctio_pinflate_new.argtypes = [vp, i64, i32, i64, i64, vp, ctypes.c_uint32]
+        lib.sctio_inflate_set_stop.argtypes = [vp, i64]
+        lib.sctio_inflate_set_stop.restype = None
+        lib.sctio_inflate_get_state.argtypes = [vp, ctypes.POINTER(i64), vp, ctypes.POINTER(ctypes.c_uint32)]
+        lib.sctio_inflate_get_state.restype = None
+        lib.sctio_pinflate_new.restype = vp
+        lib.sctio_pinflate_next.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(i32), ctypes.POINTER(i64)]
+        lib.sctio_pinflate_next.restype = i64
+        lib.sctio_pinflate_free.argtypes = [vp]
+        lib.sctio_pinflate_free.restype = None
+        lib.sctio_pinflate_stats.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        lib.sctio_pinflate_stats.restype = None
+        lib.sctio_piece_free.argtypes = [vp]
+        lib.sctio_piece_free.restype = None
+        lib.sctio_piece_head.restype = i64
+        lib.sctio_crc32_combine.argtypes = [ctypes.c_uint32, ctypes.c_uint32, i64]
+        lib.sctio_crc32_combine.restype = ctypes.c_uint32
+        lib.sctio_crc32.argtypes = [ctypes.c_uint32, vp, i64]
+        lib.sctio_crc32.restype = ctypes.c_uint32
         lib._stream_ready = True
     return lib
 
@@ -83,6 +102,31 @@ def _gzip_header_end(data, at):
 
 
 WINDOW = 32768      # what the decoder of csrc/sct_inflate.c wants in front of its output (the previous 32 KiB, for the matches)
+# One gzip member of at least this many compressed bytes is decoded by several threads (csrc/sct_pinflate.c: block starts found by
+# search, chunks decoded with the unknown 32 KiB before them as markers, resolved in stream order); smaller ones serially.
+PARALLEL_MIN_BYTES = int(os.environ.get("SCT_INFLATE_PARALLEL_MIN", 8 << 20))
+last_inflate_stats = {}     # what the last gzip input was decoded with (for SCT_CLI_TIMING and the tests)
+
+
+def inflate_threads():
+    """Threads of the parallel decoder: SCT_INFLATE_THREADS, or a quarter of the host's cores (at most 32; the parse / render
+    workers and the gzip pool of the writer want the others)."""
+    env = os.environ.get("SCT_INFLATE_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    return max(1, min(32, cores // 4))
+
+
+def _piece_array(lib, piece, nbytes):
+    """A malloc'ed piece of the parallel decoder as a numpy array that owns it: freed when the last view of it is gone."""
+    import weakref
+    raw = (ctypes.c_uint8 * nbytes).from_address(piece)
+    weakref.finalize(raw, lib.sctio_piece_free, piece)
+    return np.frombuffer(raw, dtype=np.uint8)
 
 
 def _cut(region, block_bytes):
@@ -152,16 +196,22 @@ def _inflate_regions(path, piece_bytes):
     st = lib.sctio_inflate_new()
     status, used = ctypes.c_int32(0), ctypes.c_int64(0)
     crc_q = queue.Queue(maxsize=16)
-    crc_state = {"bad": False}
+    crc_state = {"bad": False, "crc": 0, "n": 0}
 
     def crc_worker():
+        # pieces of the serial decoder are summed here, beside the decoding; ("end", crc32, isize) = a member's trailer: compare and
+        # start over; an Event = "publish what you have and start over" (the parallel decoder takes the member from there)
         crc, n = 0, 0
         while True:
             item = crc_q.get()
             if item is None:
                 return
-            if isinstance(item, tuple):           # end of a member: (crc32, isize) of its trailer
-                if item != (crc & 0xFFFFFFFF, n & 0xFFFFFFFF):
+            if isinstance(item, threading.Event):
+                crc_state["crc"], crc_state["n"] = crc, n
+                crc, n = 0, 0
+                item.set()
+            elif isinstance(item, tuple):
+                if item[1:] != (crc & 0xFFFFFFFF, n & 0xFFFFFFFF):
                     crc_state["bad"] = True
                 crc, n = 0, 0
             else:
@@ -170,10 +220,18 @@ def _inflate_regions(path, piece_bytes):
 
     th = threading.Thread(target=crc_worker, daemon=True)
     th.start()
+    threads = inflate_threads()
+    last_inflate_stats.clear()
+    last_inflate_stats.update({"threads": threads, "members": 0, "members_parallel": 0, "pieces_speculative": 0, "pieces_redone": 0})
     try:
         pos = 0
         while True:
+            last_inflate_stats["members"] += 1
             lib.sctio_inflate_set_input(st, base + at, len(data) - at)
+            # A member that is still going after PARALLEL_MIN_BYTES of compressed input, with at least as much of the file left, is
+            # handed to the parallel decoder at the next block boundary (many small members — bgzip — never get there)
+            if threads > 1 and len(data) - at >= 2 * PARALLEL_MIN_BYTES:
+                lib.sctio_inflate_set_stop(st, 8 * PARALLEL_MIN_BYTES)
             while True:
                 pre = yield None                  # how much room the consumer wants in front of the piece (its unfinished line)
                 pre = max(int(pre), WINDOW)
@@ -184,12 +242,59 @@ def _inflate_regions(path, piece_bytes):
                 yield buf, pre, int(n)
                 if status.value != 0:
                     break
+            member_crc = None
+            if status.value == 2:
+                # ---- the rest of the member on several threads (csrc/sct_pinflate.c): pieces in stream order, each with its CRC-32
+                ev = threading.Event()
+                crc_q.put(ev)
+                bitpos, wfill = ctypes.c_int64(), ctypes.c_uint32()
+                window = np.empty(WINDOW, dtype=np.uint8)
+                lib.sctio_inflate_get_state(st, ctypes.byref(bitpos), window.ctypes.data, ctypes.byref(wfill))
+                # chunks of compressed bytes that inflate to about one block of the pipeline (ratio: what the member has shown so far)
+                ev.wait()
+                ratio = max(1.0, crc_state["n"] / max(1.0, bitpos.value / 8.0))
+                chunk = int(os.environ.get("SCT_INFLATE_CHUNK_BYTES", 0)) or int(min(8 << 20, max(256 << 10, piece_bytes / ratio)))
+                h = lib.sctio_pinflate_new(base + at, len(data) - at, threads, chunk, bitpos.value, window.ctypes.data, wfill.value)
+                if not h:
+                    raise MemoryError("parallel inflate: out of memory")
+                head = int(lib.sctio_piece_head())
+                piece, pcrc = ctypes.c_void_p(), ctypes.c_uint32()
+                crc, total = crc_state["crc"], crc_state["n"]
+                last_inflate_stats["chunk_bytes"] = chunk
+                try:
+                    while True:
+                        pre = int((yield None))
+                        n = int(lib.sctio_pinflate_next(h, ctypes.byref(piece), ctypes.byref(pcrc), ctypes.byref(status), ctypes.byref(used)))
+                        if status.value != 0:
+                            yield np.empty(pre, dtype=np.uint8), pre, 0
+                            break
+                        buf = _piece_array(lib, piece.value, head + n)
+                        crc = lib.sctio_crc32_combine(crc, pcrc.value, n)
+                        total += n
+                        if pre > head:          # (an unfinished line of more than a megabyte: make room)
+                            big = np.empty(pre + n, dtype=np.uint8)
+                            big[pre:] = buf[head:head + n]
+                            yield big, pre, n
+                        else:
+                            yield buf, head, n
+                    sp, rd = ctypes.c_int64(), ctypes.c_int64()
+                    lib.sctio_pinflate_stats(h, ctypes.byref(sp), ctypes.byref(rd))
+                    last_inflate_stats["members_parallel"] += 1
+                    last_inflate_stats["pieces_speculative"] += int(sp.value)
+                    last_inflate_stats["pieces_redone"] += int(rd.value)
+                finally:
+                    lib.sctio_pinflate_free(h)
+                member_crc = (crc & 0xFFFFFFFF, total & 0xFFFFFFFF)
             if status.value < 0:
                 raise gzip.BadGzipFile("the compressed stream is corrupt or ends too early")
             pos = at + used.value
             if pos + 8 > len(data):
                 raise EOFError("Compressed file ended before the end-of-stream marker was reached")
-            crc_q.put((int.from_bytes(data[pos:pos + 4], "little"), int.from_bytes(data[pos + 4:pos + 8], "little")))
+            trailer = (int.from_bytes(data[pos:pos + 4], "little"), int.from_bytes(data[pos + 4:pos + 8], "little"))
+            if member_crc is None:
+                crc_q.put(("end",) + trailer)
+            elif member_crc != trailer:
+                crc_state["bad"] = True
             pos += 8
             while pos < len(data) and data[pos] == 0:     # zero padding after a member is ignored, as gzip does
                 pos += 1
@@ -306,20 +411,34 @@ class _Worker(threading.Thread):
         self.error = None
         self.rows = 0
         self.cap_rows = self.cap_bytes = 0
+        self.pinned = False
+        self.ns = None
         self.t = {"parse": 0.0, "wait_device": 0.0, "wait_lock": 0.0, "match": 0.0, "render": 0.0, "idle": 0.0}
 
     def _ensure(self, nbytes):
-        if nbytes <= self.cap_bytes:
+        # Ordinary (pageable) arrays at first, so that parsing does not have to wait for the device context (the library
+        # page-locks them for the duration of each call, option "register"); once the context exists the worker moves to
+        # page-locked arrays of its own (sct_host_alloc), which the kernels read and write in place without any per-call
+        # registration: a call on a 16 MB block took 5.7 ms, 13 ns per row, where the device needs half a nanosecond.
+        want_pinned = self.dev.ready.is_set() and self.dev.error is None and self.dev.m is not None
+        if nbytes <= self.cap_bytes and (self.pinned or not want_pinned):
             return
-        # ordinary (pageable) arrays, so that parsing does not have to wait for the device context; the library page-locks them
-        # for the duration of each call (option "register") and its kernels read and write them in place
-        self.cap_bytes = max(nbytes, BLOCK_BYTES + (1 << 20))
+        self.cap_bytes = max(nbytes, self.cap_bytes, BLOCK_BYTES + (1 << 20))
         self.cap_rows = ROWS_PER_PASS
-        self.segs = np.empty(self.cap_bytes, np.uint8)
-        self.offs = np.empty(self.cap_rows + 1, np.int32)
-        self.lens = np.empty(self.cap_rows, np.uint8)
-        self.min_e = np.empty(self.cap_rows, np.uint8)
-        self.cnt = np.empty(self.cap_rows, np.uint32)     # viewed as uint8 for the one-byte counts
+        if want_pinned:
+            with self.dev.lock:
+                alloc = self.dev.m.host_array
+                self.segs, self.offs, self.lens = alloc(self.cap_bytes, np.uint8), alloc(self.cap_rows + 1, np.int32), alloc(self.cap_rows, np.uint8)
+                self.min_e, self.cnt = alloc(self.cap_rows, np.uint8), alloc(self.cap_rows, np.uint32)
+            self.pinned = True
+        else:
+            self.segs = np.empty(self.cap_bytes, np.uint8)
+            self.offs = np.empty(self.cap_rows + 1, np.int32)
+            self.lens = np.empty(self.cap_rows, np.uint8)
+            self.min_e = np.empty(self.cap_rows, np.uint8)
+            self.cnt = np.empty(self.cap_rows, np.uint32)     # viewed as uint8 for the one-byte counts
+        if getattr(self, "ns", None) is not None and self.ns.size >= self.cap_rows:
+            return
         self.ns = np.empty(self.cap_rows, dtype=np.int64)
         self.ne = np.empty(self.cap_rows, dtype=np.int64)
         self.info = np.zeros(8, dtype=np.int64)

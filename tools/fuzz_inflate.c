@@ -3,8 +3,8 @@
  *
  * Build and run (tools/fuzz_inflate.sh does both and writes the log kept under profiles/):
  *   gcc -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -o /tmp/fuzz_inflate tools/fuzz_inflate.c \
- *       sctagger_amd/csrc/sct_inflate.c -lz
- *   /tmp/fuzz_inflate <iterations> <seed>
+ *       sctagger_amd/csrc/sct_inflate.c sctagger_amd/csrc/sct_pinflate.c -lz -lpthread
+ *   /tmp/fuzz_inflate <iterations> <seed> [0 = without the parallel driver]
  *
  * Every iteration: take a raw DEFLATE stream made by zlib from structured data (level, strategy, window and memory level
  * drawn at random), mutate it (bit flips, byte writes, truncation, slice duplication / removal / swap, splices of two
@@ -26,6 +26,16 @@ void *sctio_inflate_new(void);
 void sctio_inflate_free(void *p);
 void sctio_inflate_set_input(void *p, const uint8_t *in, int64_t len);
 int64_t sctio_inflate_run(void *p, uint8_t *out, int64_t cap, int32_t *status, int64_t *in_used);
+void sctio_inflate_set_stop(void *p, int64_t stop_bit);
+void sctio_inflate_get_state(void *p, int64_t *bitpos, uint8_t *window, uint32_t *win_fill);
+/* the parallel driver (csrc/sct_pinflate.c) */
+void *sctio_pinflate_new(const uint8_t *in, int64_t len, int32_t threads, int64_t chunk_bytes, int64_t start_bit, const uint8_t *window, uint32_t win_fill);
+int64_t sctio_pinflate_next(void *p, uint8_t **piece, uint32_t *crc, int32_t *status, int64_t *in_used);
+void sctio_pinflate_stats(void *p, int64_t *speculative, int64_t *redone);
+void sctio_pinflate_free(void *p);
+void sctio_piece_free(uint8_t *piece);
+int64_t sctio_piece_head(void);
+uint32_t sctio_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2);
 
 static uint64_t rng_state = 88172645463325252ull;
 static uint64_t rnd(void) {
@@ -217,11 +227,90 @@ static int run_ours(const uint8_t *c, size_t n, uint8_t *blk, size_t cap, uint8_
     return verdict;
 }
 
+/* The same stream through the parallel driver: a random number of threads, chunks of a few hundred bytes to a few KB (so that a
+ * stream of some size is cut many times), now and then after the serial decoder has done the beginning (the hand-over the command
+ * makes: stop at a block boundary, pass position and window on).  Also checks the CRC-32 the pieces come with. */
+static long par_pieces_spec = 0, par_pieces_redo = 0, par_handover = 0, par_crc_bad = 0;
+static int run_parallel(const uint8_t *c, size_t n, uint8_t *out, size_t *out_n, size_t *used) {
+    uint8_t *in = (uint8_t *)malloc(n ? n : 1);   /* exactly sized: a read past its end is an ASan report */
+    memcpy(in, c, n);
+    size_t total = 0;
+    int verdict = 3;
+    int64_t start_bit = 0;
+    uint8_t window[32768];
+    uint32_t win_fill = 0;
+    uint32_t crc = 0;
+    int32_t status = 0;
+    int64_t in_used = 0;
+    if (n > 64 && below(3) == 0) {
+        /* the serial decoder first, to the first block boundary behind a random position */
+        void *st = sctio_inflate_new();
+        sctio_inflate_set_input(st, in, (int64_t)n);
+        sctio_inflate_set_stop(st, (int64_t)below((uint32_t)(8 * n)));
+        uint8_t *blk = (uint8_t *)malloc(32768 + 65536);
+        for (;;) {
+            const int64_t k = sctio_inflate_run(st, blk, 65536, &status, &in_used);
+            if (total + (size_t)k > OUT_CAP) { status = 99; break; }
+            memcpy(out + total, blk + 32768, (size_t)k);
+            crc = (uint32_t)crc32(crc, blk + 32768, (uInt)k);
+            total += (size_t)k;
+            if (status != 0) break;
+        }
+        free(blk);
+        if (status == 2) {
+            sctio_inflate_get_state(st, &start_bit, window, &win_fill);
+            par_handover++;
+        }
+        sctio_inflate_free(st);
+        if (status != 2) {   /* the stream ended, broke or overflowed before the hand-over: the serial decoder's verdict */
+            *out_n = total;
+            *used = (size_t)in_used;
+            free(in);
+            return status == 1 ? 0 : status == -3 ? 2 : status == 99 ? 3 : 1;
+        }
+    }
+    static const int64_t chunks[] = {64, 100, 257, 1000, 4096, 20000, 0};
+    void *h = sctio_pinflate_new(in, (int64_t)n, 1 + (int32_t)below(4), chunks[below(7)], start_bit, window, win_fill);
+    if (!h) abort();
+    const int64_t head = sctio_piece_head();
+    for (;;) {
+        uint8_t *piece = NULL;
+        uint32_t pcrc = 0;
+        const int64_t k = sctio_pinflate_next(h, &piece, &pcrc, &status, &in_used);
+        if (status != 0) {
+            verdict = status == 1 ? 0 : status == -3 ? 2 : 1;
+            break;
+        }
+        if (total + (size_t)k > OUT_CAP) {
+            sctio_piece_free(piece);
+            verdict = 3;
+            break;
+        }
+        memcpy(out + total, piece + head, (size_t)k);
+        if ((uint32_t)crc32(0, piece + head, (uInt)k) != pcrc) par_crc_bad++;
+        crc = sctio_crc32_combine(crc, pcrc, k);
+        total += (size_t)k;
+        sctio_piece_free(piece);
+    }
+    if (verdict == 0 && crc != (uint32_t)crc32(0, out, (uInt)total)) par_crc_bad++;
+    int64_t sp = 0, rd = 0;
+    sctio_pinflate_stats(h, &sp, &rd);
+    par_pieces_spec += sp;
+    par_pieces_redo += rd;
+    sctio_pinflate_free(h);
+    *out_n = total;
+    *used = (size_t)in_used;
+    free(in);
+    return verdict;
+}
+
 int main(int argc, char **argv) {
     const long iters = argc > 1 ? atol(argv[1]) : 100000;
     rng_state ^= (uint64_t)(argc > 2 ? atoll(argv[2]) : 1) * 0x9E3779B97F4A7C15ull;
     uint8_t *plain = (uint8_t *)malloc(MAX_PLAIN), *comp = (uint8_t *)malloc(MAX_COMP), *other = (uint8_t *)malloc(MAX_COMP);
-    uint8_t *oz = (uint8_t *)malloc(OUT_CAP), *oo = (uint8_t *)malloc(OUT_CAP + 16);
+    uint8_t *oz = (uint8_t *)malloc(OUT_CAP), *oo = (uint8_t *)malloc(OUT_CAP + 16), *op = (uint8_t *)malloc(OUT_CAP + 16);
+    const int with_parallel = argc > 3 ? atoi(argv[3]) : 1;
+    long par_ok = 0, par_bad = 0, par_vs_serial = 0, par_limit = 0;
     size_t other_n = 0;
     long agree_ok = 0, agree_bad = 0, limit = 0, ours_ok_zlib_bad = 0, ours_bad_zlib_ok = 0, class_differs = 0, valid = 0;
     static const size_t caps[] = {65536, 65537, 70001, 131072, 1 << 20};
@@ -259,6 +348,23 @@ int main(int argc, char **argv) {
             if (ours_bad_zlib_ok < 5) fprintf(stderr, "decoder rejects (%d) what zlib accepts at iteration %ld, %zu bytes in\n", vo, it, cn);
             ours_bad_zlib_ok++;
         }
+        if (with_parallel) {
+            /* the parallel driver: the same verdict as the serial decoder (finished / refused), and on success the same bytes and
+             * the same count of input bytes — which the block above has just compared with zlib's */
+            size_t pn2 = 0, pu = 0;
+            const int vp = run_parallel(comp, cn, op, &pn2, &pu);
+            if (vp == 3 || vo == 3) par_limit++;
+            else if ((vp == 0) != (vo == 0)) {
+                if (par_vs_serial < 20) fprintf(stderr, "parallel verdict %d, serial verdict %d (zlib %d) at iteration %ld, %zu bytes in\n", vp, vo, vz, it, cn);
+                par_vs_serial++;
+            } else if (vp == 0) {
+                if (pn2 != on || memcmp(op, oo, on) != 0 || pu != ou) {
+                    fprintf(stderr, "PARALLEL MISMATCH at iteration %ld: serial %zu bytes out / %zu in, parallel %zu / %zu\n", it, on, ou, pn2, pu);
+                    return 2;
+                }
+                par_ok++;
+            } else par_bad++;
+        }
         /* keep this stream around as splice material */
         if (cn && below(4) == 0) {
             memcpy(other, comp, cn);
@@ -272,7 +378,11 @@ int main(int argc, char **argv) {
     }
     printf("DONE %ld streams (%ld left valid): both finish %ld, both refuse %ld, output limit %ld, decoder ok / zlib not %ld, zlib ok / decoder not %ld\n",
            iters, valid, agree_ok, agree_bad, limit, ours_ok_zlib_bad, ours_bad_zlib_ok);
+    if (with_parallel)
+        printf("PARALLEL %ld streams: finishes like the serial decoder with identical output %ld, refuses like it %ld, verdict differs %ld, output limit %ld; "
+               "pieces accepted from speculative decoding %ld, decoded again serially %ld, hand-overs from the serial decoder %ld, piece CRCs wrong %ld\n",
+               iters, par_ok, par_bad, par_vs_serial, par_limit, par_pieces_spec, par_pieces_redo, par_handover, par_crc_bad);
     fflush(stdout);
-    free(plain); free(comp); free(other); free(oz); free(oo);
-    return (ours_ok_zlib_bad || ours_bad_zlib_ok) ? 3 : 0;
+    free(plain); free(comp); free(other); free(oz); free(oo); free(op);
+    return (ours_ok_zlib_bad || ours_bad_zlib_ok || par_vs_serial || par_crc_bad) ? 3 : 0;
 }
