@@ -227,18 +227,19 @@ def _match_trie_streaming(args, devices, level, devs=None):
     # file behind.  Here blocks are written while later ones are still being read, so the rows go to a temporary file beside the
     # target, which takes its name only when every block has been read, checked (gzip CRC and length included) and written.
     tmp = "%s.tmp.%d" % (args.outfile, os.getpid())
-    if args.outfile.endswith("gz"):
-        # (10^7 rows are 420 MB of output: 8 CPU-seconds of deflate at level 4 — the pool, not the device, is what a plain-text
-        # input waits for)
-        sink = fastio.GzipChunkWriter(tmp, level, threads=min(128, max(4, (os.cpu_count() or 8) // 2)))
-    else:
-        sink = open(tmp, "wb")
+    # gzip output: every worker compresses the rows of its own blocks into gzip members (C threads, csrc/sct_hostio.c); the
+    # main thread only puts them into the file in block order.  (10^7 rows are 420 MB of output: 8 CPU-seconds of deflate at
+    # level 4 — the compressing, not the device, is what a plain-text input waits for.)
+    gz_level = level if args.outfile.endswith("gz") else None
+    sink = open(tmp, "wb")
     import time
     t0 = time.perf_counter()
     try:
         try:
             rows, min_es = streamcli.run_pipeline(args.long_read_segments, bc, args.barcode_length, args.max_error, args.threads, table, sink,
-                                                  devices=tuple(devices), want_min_e=want_plot, devs=devs)
+                                                  devices=tuple(devices), want_min_e=want_plot, devs=devs, gzip_level=gz_level)
+            if gz_level is not None and sink.tell() == 0:      # nothing matched: still a valid (empty) gzip file
+                sink.write(fastio._gzip_member(gz_level, b""))
         finally:
             t1 = time.perf_counter()
             sink.close()

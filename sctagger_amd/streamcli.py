@@ -35,6 +35,7 @@ from . import _native, fastio
 BLOCK_BYTES = int(os.environ.get("SCT_STREAM_BLOCK_BYTES", 4 << 20))
 ROWS_PER_PASS = 1 << 21
 PIECE_BYTES = 4 << 20
+GZ_PIECE_BYTES = 1 << 20      # input bytes per gzip member of the output
 
 
 class NeedPlainReader(Exception):
@@ -75,6 +76,10 @@ def _iolib():
         lib.sctio_crc32_combine.restype = ctypes.c_uint32
         lib.sctio_crc32.argtypes = [ctypes.c_uint32, vp, i64]
         lib.sctio_crc32.restype = ctypes.c_uint32
+        lib.sctio_gzip_bound.argtypes = [i64, i64]
+        lib.sctio_gzip_bound.restype = i64
+        lib.sctio_gzip_members.argtypes = [vp, i64, i32, i64, i32, vp, i64]
+        lib.sctio_gzip_members.restype = i64
         lib._stream_ready = True
     return lib
 
@@ -108,17 +113,52 @@ PARALLEL_MIN_BYTES = int(os.environ.get("SCT_INFLATE_PARALLEL_MIN", 8 << 20))
 last_inflate_stats = {}     # what the last gzip input was decoded with (for SCT_CLI_TIMING and the tests)
 
 
-def inflate_threads():
-    """Threads of the parallel decoder: SCT_INFLATE_THREADS, or a quarter of the host's cores (at most 32; the parse / render
-    workers and the gzip pool of the writer want the others)."""
-    env = os.environ.get("SCT_INFLATE_THREADS")
+def effective_cpus():
+    """CPUs this process may really use: its affinity mask, cut down to the CPU quota of its cgroup (v2 cpu.max, v1 cfs quota) —
+    a container on a 256-thread host may own 16 of them, and a pool sized by the 256 spends its quota in the first milliseconds of
+    every scheduler period and is then suspended, the thread that feeds the device included.  SCT_CPUS overrides."""
+    env = os.environ.get("SCT_CPUS")
     if env:
         return max(1, int(env))
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         cores = os.cpu_count() or 1
-    return max(1, min(32, cores // 4))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(p)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = float(f.read()), float(g.read())
+                if q > 0 and p > 0:
+                    quota = q / p
+        except Exception:
+            pass
+    if quota:
+        cores = min(cores, max(1, int(quota + 0.5)))
+    return max(1, cores)
+
+
+compressing_output = False    # set by run_pipeline: the command also deflates its output (its largest CPU cost by far)
+
+
+def inflate_threads():
+    """Threads of the parallel decoder: SCT_INFLATE_THREADS, or half of the CPUs the process may use (at most 32; the parse / render
+    workers and the compressing pool want the others).  Decoding in two passes costs about a third more CPU than the serial
+    decoder: where the command is short of CPUs anyway — fewer than 32 and a gzip output to produce: 56 CPU-seconds per 10^8 rows,
+    40 of them deflating the output — the serial decoder on one CPU beside the others is the faster arrangement (measured on a
+    16-CPU quota: 3.9 against 4.4 s per 10^8 rows; with a plain-text output 2.3 s on 8 decoding threads)."""
+    env = os.environ.get("SCT_INFLATE_THREADS")
+    if env:
+        return max(1, int(env))
+    cpus = effective_cpus()
+    if compressing_output and cpus < 32:
+        return 1
+    return max(1, min(32, cpus // 2))
 
 
 def _piece_array(lib, piece, nbytes):
@@ -403,17 +443,18 @@ class _Worker(threading.Thread):
     reader (scTagger.py:602-628) and writer loop (:777-789) are serial Python; here as many workers as the host has cores to
     spare parse and render side by side, whatever the number of devices."""
 
-    def __init__(self, dev, inq, max_err, threads, table, want_min_e):
+    def __init__(self, dev, inq, max_err, threads, table, want_min_e, gz=None):
         super().__init__(daemon=True)
         self.dev, self.inq, self.max_err, self.threads = dev, inq, max_err, threads
         self.table, self.want_min_e = table, want_min_e
+        self.gz = gz              # (gzip level, threads of one call): the worker hands on gzip members instead of text
         self.outq = None          # set by run_pipeline
         self.error = None
         self.rows = 0
         self.cap_rows = self.cap_bytes = 0
         self.pinned = False
         self.ns = None
-        self.t = {"parse": 0.0, "wait_device": 0.0, "wait_lock": 0.0, "match": 0.0, "render": 0.0, "idle": 0.0}
+        self.t = {"parse": 0.0, "wait_device": 0.0, "wait_lock": 0.0, "match": 0.0, "render": 0.0, "gzip": 0.0, "idle": 0.0}
 
     def _ensure(self, nbytes):
         # Ordinary (pageable) arrays at first, so that parsing does not have to wait for the device context (the library
@@ -496,11 +537,23 @@ class _Worker(threading.Thread):
             o = np.empty(size, dtype=np.uint8)
             got = lib.sctio_render_block(*args, o.ctypes.data)
             assert got == size
-            out.append(o)
             if self.want_min_e:
                 keep.append(me.copy())
             t5 = clk()
-            for k, v in (("parse", t1 - t0), ("wait_device", t2 - t1), ("wait_lock", t3 - t2), ("match", t4 - t3), ("render", t5 - t4)):
+            if self.gz is not None and size:
+                # the block's rows as gzip members of GZ_PIECE_BYTES each, compressed side by side inside ONE call (no Python
+                # thread, no interpreter lock: csrc/sct_hostio.c sctio_gzip_members)
+                level, inner = self.gz
+                cap = int(lib.sctio_gzip_bound(size, GZ_PIECE_BYTES))
+                z = np.empty(cap, dtype=np.uint8)
+                zn = int(lib.sctio_gzip_members(o.ctypes.data, size, level, GZ_PIECE_BYTES, inner, z.ctypes.data, cap))
+                if zn < 0:
+                    raise RuntimeError("gzip compression of a block failed")
+                o = z[:zn]
+            if size:
+                out.append(o)
+            t6 = clk()
+            for k, v in (("parse", t1 - t0), ("wait_device", t2 - t1), ("wait_lock", t3 - t2), ("match", t4 - t3), ("render", t5 - t4), ("gzip", t6 - t5)):
                 self.t[k] += v
             n_rows += n
             at += used
@@ -526,15 +579,11 @@ class _Worker(threading.Thread):
 
 def cpu_workers_for(n_devices):
     """CPU workers of the command: SCT_CLI_WORKERS, or by the host's cores — at least one per device, at most 8 (parse + render
-    of 10^7 rows is 0.6 s of one core; the gzip pool of the writer wants the other cores)."""
+    of 10^7 rows is 0.6 s of one core, compressing their output 8 s: every worker compresses its own blocks, on several threads)."""
     env = os.environ.get("SCT_CLI_WORKERS")
     if env:
         return max(n_devices, int(env))
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
-    return max(n_devices, min(8, max(1, cores // 4)))
+    return max(n_devices, min(16, max(1, effective_cpus() // 4)))
 
 
 def start_devices(devices):
@@ -546,19 +595,32 @@ def start_devices(devices):
     return devs
 
 
-def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), want_min_e=False, block_bytes=BLOCK_BYTES, cpu_workers=None,
-                 devs=None):
+def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), want_min_e=False, block_bytes=None, cpu_workers=None,
+                 devs=None, gzip_level=None):
     """Stream `lr_path` through the devices into `sink` (an object with write(bytes-like)); -> (rows read, list of min_e
     arrays in row order if want_min_e).  Raises NeedPlainReader / IndexError like the whole-file readers.  `devs`: contexts already
-    being created by start_devices (they are closed here)."""
+    being created by start_devices (they are closed here).  gzip_level: the workers compress their rows themselves and `sink` gets
+    consecutive gzip members (a plain binary file); None: `sink` gets the text."""
     t_start = time.perf_counter()
+    if block_bytes is None:
+        # large inputs in larger blocks: fewer calls into the device library, more pieces per block for the compressing threads
+        try:
+            big = os.path.getsize(lr_path) >= (256 << 20)
+        except OSError:
+            big = False
+        block_bytes = BLOCK_BYTES if "SCT_STREAM_BLOCK_BYTES" in os.environ or not big else 2 * BLOCK_BYTES
     if devs is None:
         devs = start_devices(devices)
     for d in devs:
         d.set_barcodes(bc, bl)
     n_workers = cpu_workers or cpu_workers_for(len(devs))
     inq = queue.Queue(maxsize=2 * n_workers)
-    workers = [_Worker(devs[i % len(devs)], inq, max_err, threads, table, want_min_e) for i in range(n_workers)]
+    global compressing_output
+    compressing_output = gzip_level is not None
+    gz = None
+    if gzip_level is not None:
+        gz = (int(gzip_level), max(1, min(128, effective_cpus() - 1)))      # (level, threads of the process-wide compressing pool)
+    workers = [_Worker(devs[i % len(devs)], inq, max_err, threads, table, want_min_e, gz) for i in range(n_workers)]
     outq = queue.Queue()
     for w in workers:
         w.outq = outq

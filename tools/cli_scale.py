@@ -3,7 +3,7 @@
 producer writes, /root/reference/scTagger.py:377), inflate threads (1 = the serial decoder of round 3), workers, block size and
 --devices.  The input files are written once per size and level; every variant runs the command twice (best reported).
   gpurun -- 'python tools/cli_scale.py 10000000 100000000 > gpurun_out/r04/cli_scale.jsonl'"""
-import gzip, json, os, subprocess, sys, time
+import gzip, json, os, resource, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import bench, cli_e2e
@@ -30,22 +30,24 @@ for n in sizes:
                       "raw_MB": round(files[9][1] / 1e6), "gz_MB": {l: round(files[l][2] / 1e6, 1) for l in files}}), flush=True)
     del segs
     B8, B16 = {"SCT_STREAM_BLOCK_BYTES": str(8 << 20)}, {"SCT_STREAM_BLOCK_BYTES": str(16 << 20)}
-    variants = [(9, {"SCT_INFLATE_THREADS": "1"}, []), (9, {}, []), (9, B8, []), (9, B16, []), (9, dict(B16, SCT_CLI_WORKERS="16"), []),
-                (9, dict(B8, SCT_CLI_WORKERS="16"), ["--devices", "0", "0"]), (1, {}, []), (9, dict(B16, SCT_CLI_WORKERS="16", SCT_INFLATE_THREADS="16"), []),
-                (9, dict(B16, SCT_CLI_WORKERS="16"), ["--gzip-level", "1"]), (9, dict(B16, SCT_CLI_WORKERS="16"), ["--gzip-level", "9"])]
+    variants = [(9, {"SCT_INFLATE_THREADS": "1"}, []), (9, {}, []), (9, {"SCT_CLI_WORKERS": "8"}, []), (9, {"SCT_INFLATE_THREADS": "12"}, []), (9, {"SCT_INFLATE_THREADS": "4"}, []),
+                (9, {}, ["--devices", "0", "0"]), (1, {}, []), (9, {}, ["--gzip-level", "1"]), (9, {}, ["-o", os.path.join(work, "out.tsv")])]
     if quick:
-        variants = variants[:5]
+        variants = variants[:4]
     out = os.path.join(work, "out.tsv.gz")
     rows_out = None
     for level, env, extra in variants:
         e = {k: v for k, v in os.environ.items() if k not in ENVS}
         e.update(env, SCT_CLI_TIMING="1")
-        walls = []
+        walls, cpu = [], []
         for _ in range(2):
+            r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
             t0 = time.time()
-            rc = subprocess.call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", files[level][0], "-sr", sr, "-mr", "2", "-t", "16", "-o", out] + extra,
+            rc = subprocess.call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", files[level][0], "-sr", sr, "-mr", "2", "-t", "16"] + (extra if "-o" in extra else ["-o", out] + extra),
                                  stderr=open(os.path.join(work, "cli.err"), "w"), env=e)
             walls.append(round(time.time() - t0, 3))
+            r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+            cpu.append([round(r1.ru_utime - r0.ru_utime, 2), round(r1.ru_stime - r0.ru_stime, 2)])
             if rc != 0:
                 break
         timing = [l.strip() for l in open(os.path.join(work, "cli.err")) if "timing" in l]
@@ -57,7 +59,7 @@ for n in sizes:
                     if not piece:
                         break
                     rows_out += piece.count(b"\n")
-        print(json.dumps({"rows": n, "in_gzip_level": level, "in_gz_MB": round(files[level][2] / 1e6, 1), "env": env, "extra": extra, "rc": rc, "wall_s": walls,
+        print(json.dumps({"rows": n, "in_gzip_level": level, "in_gz_MB": round(files[level][2] / 1e6, 1), "env": env, "extra": extra, "rc": rc, "wall_s": walls, "cpu_user_sys_s": cpu,
                           "segments_per_s": n / min(walls), "out_gz_MB": round(os.path.getsize(out) / 1e6, 1) if rc == 0 else None, "rows_out": rows_out,
                           "timing": timing[-3:]}), flush=True)
     for l in files:
