@@ -1246,13 +1246,29 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     // Page-locked host memory (sct_host_alloc, hipHostMalloc, hipHostRegister) is mapped into the device's address space: the
     // kernels read the rows and their index from it directly ("zero copy"), at the rate of the PCIe link (57 GB/s measured,
     // profiles/r02_pcie_probe.json), every byte once — there is no upload step to wait for.  Pageable memory is copied.
-    auto device_view = [&](const void *p, bool always = false) -> const void * {
-        if (!p || !(c->zero_copy || always)) return nullptr;
+    // ... but only if the WHOLE array is: its first and its last byte must both lie in mapped host memory, the same distance apart on
+    // the device.  (The caller's arrays are page-locked below in whole pages: an array that merely BEGINS in the last page of a
+    // neighbour's locked range, too small to be locked itself, looked "mapped" by its first byte, and a kernel's write behind
+    // that page was a GPU memory fault — now and then, as the allocator happened to place the arrays.)
+    struct OwnRange {
+        uintptr_t lo, hi;
+    } own[4];          // what THIS call page-locked
+    int n_own = 0;
+    auto device_view = [&](const void *p, size_t bytes) -> const void * {
+        if (!p || !c->zero_copy) return nullptr;
+        for (int i = 0; i < n_own; i++) {   // an array that begins inside a range of ours must lie inside it altogether
+            const uintptr_t a = (uintptr_t)p;
+            if (a >= own[i].lo && a < own[i].hi && a + bytes > own[i].hi) return nullptr;
+        }
         hipPointerAttribute_t at;
-        const void *d = nullptr;
-        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) d = at.devicePointer;
+        const char *d0 = nullptr, *d1 = nullptr;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) d0 = (const char *)at.devicePointer;
         (void)hipGetLastError();
-        return d;
+        if (!d0) return nullptr;
+        if (bytes <= 1) return d0;
+        if (hipPointerGetAttributes(&at, (const char *)p + (bytes - 1)) == hipSuccess && at.type == hipMemoryTypeHost) d1 = (const char *)at.devicePointer;
+        (void)hipGetLastError();
+        return (d1 && d1 - d0 == (ptrdiff_t)(bytes - 1)) ? d0 : nullptr;
     };
     // Pageable caller buffers of some size are page-locked for the duration of the call (hipHostRegister: 3.5 ms for 230 MB
     // the first time, next to nothing when the same pages come again) and then take the zero-copy route too — numpy arrays
@@ -1260,8 +1276,10 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     // (already partly registered, read-only mappings) is copied as before.
     // Two of the caller's arrays may share a PAGE (numpy's min_e and hit_offs of one sct_match call are neighbours on the heap):
     // page-locking them one by one registers that page twice, and a kernel's write to it then faulted ("Memory access fault by
-    // GPU", round 4's first run of the pageable bench leg).  So the candidates are merged first: arrays whose page ranges touch or
-    // overlap are locked as ONE range, every page once.
+    // GPU", round 4's first run of the pageable bench leg).  So the candidates are merged first: arrays whose PAGES touch or
+    // overlap are locked as ONE range — from the first byte of the first to the last byte of the last, not rounded to pages: the
+    // runtime takes any other array that begins inside a registered range for registered as a whole, and refuses a copy into it
+    // (or, through the zero-copy path, lets a kernel write behind the locked pages) if it reaches beyond.
     struct Registered {
         void *p[4] = {nullptr, nullptr, nullptr, nullptr};
         int n = 0;
@@ -1274,14 +1292,14 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     const size_t index_bytes = index_entry_size(index_format) * (size_t)(by_offs ? n + 1 : n);
     if (c->zero_copy && c->auto_register && (size_t)seg_bytes >= ((size_t)4 << 20)) {
         struct Range {
-            uintptr_t lo, hi;   // whole pages
+            uintptr_t lo, hi;   // first byte, one past the last byte
         } rg[4];
         int nr = 0;
         const uintptr_t page = 4096;
         auto candidate = [&](const void *p, size_t bytes) {
-            if (!p || bytes < ((size_t)1 << 20) || device_view(p)) return;
-            rg[nr].lo = (uintptr_t)p & ~(page - 1);
-            rg[nr].hi = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
+            if (!p || bytes < ((size_t)1 << 20) || device_view(p, bytes)) return;
+            rg[nr].lo = (uintptr_t)p;
+            rg[nr].hi = (uintptr_t)p + bytes;
             nr++;
         };
         candidate(segs, (size_t)seg_bytes);
@@ -1291,21 +1309,25 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
         std::sort(rg, rg + nr, [](const Range &a, const Range &b) { return a.lo < b.lo; });
         int k = 0;
         for (int i = 1; i < nr; i++) {
-            if (rg[i].lo <= rg[k].hi) rg[k].hi = std::max(rg[k].hi, rg[i].hi);
+            if ((rg[i].lo & ~(page - 1)) <= ((rg[k].hi + page - 1) & ~(page - 1))) rg[k].hi = std::max(rg[k].hi, rg[i].hi);   // a page in common
             else rg[++k] = rg[i];
         }
         for (int i = 0; i < (nr ? k + 1 : 0); i++) {
-            if (!inject_alloc_failure() && hipHostRegister((void *)rg[i].lo, (size_t)(rg[i].hi - rg[i].lo), hipHostRegisterDefault) == hipSuccess)
+            if (!inject_alloc_failure() && hipHostRegister((void *)rg[i].lo, (size_t)(rg[i].hi - rg[i].lo), hipHostRegisterDefault) == hipSuccess) {
                 registered.p[registered.n++] = (void *)rg[i].lo;
+                own[n_own].lo = rg[i].lo;
+                own[n_own].hi = rg[i].hi;
+                n_own++;
+            }
             (void)hipGetLastError();
         }
     }
-    const uint8_t *zc_segs = (const uint8_t *)device_view(segs);
-    const char *zc_index = (const char *)device_view(index);
+    const uint8_t *zc_segs = (const uint8_t *)device_view(segs, (size_t)seg_bytes);
+    const char *zc_index = (const char *)device_view(index, index_bytes);
     // outputs the kernels can write in place (page-locked arrays): min_e and the compact counts; the 64-bit offsets need the
     // hits of the earlier chunks added and stay on the copy path
-    uint8_t *zc_min_e = (uint8_t *)device_view(min_e);
-    void *zc_counts = count_format == SCT_CNT_OFFS64 ? nullptr : (void *)device_view(counts);
+    uint8_t *zc_min_e = (uint8_t *)device_view(min_e, (size_t)n);
+    void *zc_counts = count_format == SCT_CNT_OFFS64 ? nullptr : (void *)device_view(counts, counts_bytes);
     int64_t chunk = c->chunk_rows;
     if (chunk <= 0) {
         // Zero copy: ONE launch over as many rows as possible — a launch begins with every resident wave asking for its rows at

@@ -306,3 +306,37 @@ def test_bad_input_leaves_no_output_file(tmp_path):
                            os.path.join(g, "g2.sr.tsv"), "-mr", "2", "-t", "1", "-o", str(o)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
     with open(os.path.join(g, "g2.e2.t1.expected.tsv"), "rb") as f:
         assert gzip.open(o, "rb").read() == f.read()
+
+
+def test_pageable_arrays_that_share_pages(m):
+    """Caller arrays as a heap places them: neighbours that share pages.  The library page-locks large pageable arrays for the
+    call in WHOLE pages; a small array that only begins in such a page must not be taken for mapped (round 4: a GPU memory fault,
+    now and then), and two large neighbours must not lock their shared page twice."""
+    bc = synth.make_barcodes(800, seed=23)
+    n = 250_000
+    segs, offs = synth.make_segments(n, bc, seed=23)
+    m.set_barcodes(bc)
+    want = m.match(segs, offs, 2, 16)
+    lens = np.diff(offs).astype(np.uint8)
+    for pad in (0, 3, 4093):
+        for order in (0, 1):
+            # one buffer, the arrays back to back: [segs (locked: > 4 MB)] [min_e (small)] [lens (small)] [counts u32 (1 MB: locked)] [offs64]
+            sizes = [("segs", segs.size), ("min_e", n), ("lens", n), ("cnt", 4 * n), ("offs", 8 * (n + 1))]
+            if order:
+                sizes = [sizes[1], sizes[0], sizes[3], sizes[2], sizes[4]]
+            buf = np.empty(sum(s for _, s in sizes) + 8 * len(sizes) + pad + 64, np.uint8)
+            at, view = pad, {}
+            for name, sz in sizes:
+                at += (-(buf.ctypes.data + at)) % (8 if name in ("cnt", "offs") else 1)
+                view[name] = buf[at:at + sz]
+                at += sz
+            view["segs"][:] = segs
+            view["lens"][:] = lens
+            view["offs"].view(np.int64)[:] = offs
+            view["min_e"][:] = 7
+            me, cnt, hits = m.match_stream(view["segs"], view["lens"], 2, 16, index_format=_native.IDX_LEN8, count_format=_native.CNT_U32,
+                                           min_e=view["min_e"], counts=view["cnt"].view(np.uint32))
+            util.assert_same((me, counts_to_offsets(cnt, _native.CNT_U32), hits), want, "carved arrays, pad %d order %d" % (pad, order))
+            me, ho, hits = m.match_stream(view["segs"], view["offs"].view(np.int64), 2, 16, index_format=_native.IDX_OFFS64, count_format=_native.CNT_OFFS64,
+                                          min_e=view["min_e"])
+            util.assert_same((me, ho, hits), want, "carved arrays, offsets, pad %d order %d" % (pad, order))
