@@ -336,8 +336,21 @@ static struct {
     int n_threads;
 } gz_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, NULL, 0};
 
+int64_t sctfd_gzip_member(const uint8_t *in, int64_t n, uint8_t *out, void *scratch_mem);   /* sct_fdeflate.c */
+int64_t sctfd_scratch_bytes(void);
+static __thread void *gz_fast_scratch = NULL;   /* per thread, kept */
+
 static void gz_piece(gz_job *j, int k) {
     const int64_t a = (int64_t)k * j->piece, len = j->n - a < j->piece ? j->n - a : j->piece;
+    if (j->level < 0) {   /* the command's own fast compressor (sct_fdeflate.c) */
+        if (!gz_fast_scratch) gz_fast_scratch = malloc((size_t)sctfd_scratch_bytes());
+        if (!gz_fast_scratch) {
+            __atomic_store_n(&j->failed, 1, __ATOMIC_RELAXED);
+            return;
+        }
+        j->sizes[k] = sctfd_gzip_member(j->in + a, len, j->out + (int64_t)k * j->slot, gz_fast_scratch);
+        return;
+    }
     z_stream z;
     memset(&z, 0, sizeof(z));
     int ok = deflateInit2(&z, j->level, Z_DEFLATED, 31, 8, Z_DEFAULT_STRATEGY) == Z_OK;
@@ -405,7 +418,8 @@ int32_t sctio_gzip_pool(int32_t threads) {
 
 /*
  * in[0 .. n) -> consecutive gzip members of `piece` input bytes each (the last one shorter; n = 0: one empty member), written to
- * out[0 .. return value); out must hold sctio_gzip_bound(n, piece) bytes.  The pieces are compressed by the process-wide pool
+ * out[0 .. return value); out must hold sctio_gzip_bound(n, piece) bytes.  level 1..9: zlib; level < 0: the fast compressor of
+ * sct_fdeflate.c.  The pieces are compressed by the process-wide pool
  * (sctio_gzip_pool; `threads` = how many threads it should have at least) and by the calling thread.  -1 on failure.
  */
 int64_t sctio_gzip_members(const uint8_t *in, int64_t n, int32_t level, int64_t piece, int32_t threads, uint8_t *out, int64_t out_cap) {

@@ -260,8 +260,30 @@ def render_matches_numpy(names, segs, offs, min_e, hit_offs, hits, pattern_text,
 
 
 def _gzip_member(level, data):
+    if level < 0:       # the command's own fast compressor (csrc/sct_fdeflate.c)
+        return gzip_members(data, level, max(len(data), 4096), 1)
     c = zlib.compressobj(level, zlib.DEFLATED, 31)
     return c.compress(data) + c.flush()
+
+
+def gzip_members(data, level=-1, piece=1 << 20, threads=1):
+    """`data` as consecutive gzip members of `piece` input bytes each, compressed side by side on `threads` C threads
+    (csrc/sct_hostio.c sctio_gzip_members): level 1..9 = zlib, level < 0 = the fast compressor of csrc/sct_fdeflate.c.  -> bytes"""
+    lib = _iolib()
+    if not getattr(lib, "_gz_ready", False):
+        vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+        lib.sctio_gzip_bound.argtypes = [i64, i64]
+        lib.sctio_gzip_bound.restype = i64
+        lib.sctio_gzip_members.argtypes = [vp, i64, i32, i64, i32, vp, i64]
+        lib.sctio_gzip_members.restype = i64
+        lib._gz_ready = True
+    src = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+    cap = int(lib.sctio_gzip_bound(len(data), piece))
+    out = np.empty(cap, dtype=np.uint8)
+    n = int(lib.sctio_gzip_members(src.ctypes.data, len(data), level, piece, threads, out.ctypes.data, cap))
+    if n < 0:
+        raise RuntimeError("gzip compression failed")
+    return out[:n].tobytes()
 
 
 class GzipChunkWriter:

@@ -263,7 +263,7 @@ def match_trie(args):
     """reference :758-790. args: long_read_segments, short_read_barcodes, max_error, barcode_length,
     threads, outfile; mem is accepted and unused as in the reference; plotfile draws the distance histogram."""
     devices = getattr(args, "devices", None) or (0,)
-    level = getattr(args, "gzip_level", 4)
+    level = getattr(args, "gzip_level", -1)      # 1..9 = zlib; -1 = the fast compressor of csrc/sct_fdeflate.c
     streaming = bool(args.outfile) and not getattr(args, "no_stream", False)
     devs = None
     if streaming:
@@ -298,7 +298,7 @@ def match_trie(args):
         return
     if args.outfile:
         if args.outfile.endswith("gz"):
-            outfile = gzip.open(args.outfile, "wt", compresslevel=level)
+            outfile = gzip.open(args.outfile, "wt", compresslevel=level if level > 0 else 6)
         else:
             outfile = open(args.outfile, "w")
     else:

@@ -143,7 +143,7 @@ def effective_cpus():
     return max(1, cores)
 
 
-compressing_output = False    # set by run_pipeline: the command also deflates its output (its largest CPU cost by far)
+compressing_output = False    # set by run_pipeline: the command also deflates its output with zlib (then its largest CPU cost by far)
 
 
 def inflate_threads():
@@ -583,7 +583,7 @@ def cpu_workers_for(n_devices):
     env = os.environ.get("SCT_CLI_WORKERS")
     if env:
         return max(n_devices, int(env))
-    return max(n_devices, min(16, max(1, effective_cpus() // 4)))
+    return max(n_devices, min(16, max(1, effective_cpus() // 2)))
 
 
 def start_devices(devices):
@@ -616,7 +616,7 @@ def run_pipeline(lr_path, bc, bl, max_err, threads, table, sink, devices=(0,), w
     n_workers = cpu_workers or cpu_workers_for(len(devs))
     inq = queue.Queue(maxsize=2 * n_workers)
     global compressing_output
-    compressing_output = gzip_level is not None
+    compressing_output = gzip_level is not None and gzip_level > 0     # (zlib: the fast compressor leaves CPUs for the decoder)
     gz = None
     if gzip_level is not None:
         gz = (int(gzip_level), max(1, min(128, effective_cpus() - 1)))      # (level, threads of the process-wide compressing pool)

@@ -1,5 +1,6 @@
 """The vectorised reader / writer (sctagger_amd/fastio.py) against the plain line-by-line implementations
 and the reference's golden bytes.  CPU only; result arrays come from the oracle."""
+import ctypes
 import gzip
 import os
 
@@ -186,3 +187,72 @@ def test_block_parser_and_renderer_reproduce_reference_bytes(name, e, t):
         lib.sctio_parse_block(ctypes.cast(ctypes.c_char_p(bad), ctypes.c_void_p).value, len(bad), 1, 7, 64, ns.ctypes.data, ne.ctypes.data,
                               segs.ctypes.data, offs.ctypes.data, lens.ctypes.data, info.ctypes.data)
         assert (info[3] == 1) if slot == 3 else (info[4] == 1)
+
+
+# ---- the fast DEFLATE compressor of the streaming command's output (csrc/sct_fdeflate.c) ---------------------------------------
+def _compress_corpus():
+    import random
+    rng = random.Random(11)
+    yield b""
+    yield b"a"
+    yield b"abcabcabcabc"
+    yield b"A" * 300000                                                         # one long run: maximal lengths at distance 1
+    yield bytes(rng.getrandbits(8) for _ in range(200000))                      # incompressible: stored blocks
+    yield bytes(range(256)) * 400                                               # every literal
+    yield bytes(rng.choice(b"ab") for _ in range(200000))
+    yield ("\n".join("r%09d\t%d\t%d\t%s\t%s" % (i, rng.randrange(3), 1 + rng.randrange(3), "".join(rng.choice("ACGT") for _ in range(22)),
+                                              ",".join("".join(rng.choice("ACGT") for _ in range(16)) for _ in range(1 + rng.randrange(2)))) for i in range(60000))).encode()
+    x = bytearray()
+    for _ in range(4000):                                                       # copies at every distance up to the window
+        if x and rng.random() < 0.6:
+            st = rng.randrange(len(x))
+            x += x[st:st + rng.randint(3, 600)]
+        else:
+            x += bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 60)))
+    yield bytes(x)
+    # skewed frequencies: Huffman codes that want to be longer than 15 bits (Fibonacci-like counts)
+    fib, out = [1, 1], bytearray()
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    for sym, k in enumerate(fib[:30]):
+        out += bytes([sym]) * min(k, 400000)
+    rng.shuffle(out)
+    yield bytes(out)
+
+
+def test_fast_compressor_round_trips():
+    import gzip as _gzip
+    import zlib as _zlib
+    from sctagger_amd import streamcli
+    lib = streamcli._iolib()
+    for ci, data in enumerate(_compress_corpus()):
+        for piece, threads in ((1 << 20, 1), (4096, 3), (70001, 2), (max(len(data), 4096), 1)):
+            z = fastio.gzip_members(data, -1, piece, threads)
+            assert _gzip.decompress(z) == data, (ci, piece)
+            assert len(z) <= len(data) + len(data) // 1000 + 64 * (len(data) // piece + 1) + 64
+            # ... and through the command's own decoder (every member)
+            buf = np.frombuffer(z, dtype=np.uint8)
+            at, got = 0, []
+            st = lib.sctio_inflate_new()
+            out = np.empty(32768 + (1 << 20), np.uint8)
+            while at < len(z):
+                hdr = streamcli._gzip_header_end(z, at)
+                assert hdr is not None
+                lib.sctio_inflate_set_input(st, buf.ctypes.data + hdr, len(z) - hdr)
+                status, used = ctypes.c_int32(0), ctypes.c_int64(0)
+                member = []
+                while True:
+                    n = lib.sctio_inflate_run(st, out.ctypes.data, 1 << 20, ctypes.byref(status), ctypes.byref(used))
+                    member.append(out[32768:32768 + n].tobytes())
+                    if status.value != 0:
+                        break
+                assert status.value == 1
+                m = b"".join(member)
+                at = hdr + used.value
+                assert int.from_bytes(z[at:at + 4], "little") == _zlib.crc32(m) and int.from_bytes(z[at + 4:at + 8], "little") == len(m) & 0xFFFFFFFF
+                at += 8
+                got.append(m)
+            lib.sctio_inflate_free(st)
+            assert b"".join(got) == data
+        for level in (1, 6):
+            assert _gzip.decompress(fastio.gzip_members(data, level, 1 << 18, 2)) == data

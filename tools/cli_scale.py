@@ -30,8 +30,8 @@ for n in sizes:
                       "raw_MB": round(files[9][1] / 1e6), "gz_MB": {l: round(files[l][2] / 1e6, 1) for l in files}}), flush=True)
     del segs
     B8, B16 = {"SCT_STREAM_BLOCK_BYTES": str(8 << 20)}, {"SCT_STREAM_BLOCK_BYTES": str(16 << 20)}
-    variants = [(9, {"SCT_INFLATE_THREADS": "1"}, []), (9, {}, []), (9, {"SCT_CLI_WORKERS": "8"}, []), (9, {"SCT_INFLATE_THREADS": "12"}, []), (9, {"SCT_INFLATE_THREADS": "4"}, []),
-                (9, {}, ["--devices", "0", "0"]), (1, {}, []), (9, {}, ["--gzip-level", "1"]), (9, {}, ["-o", os.path.join(work, "out.tsv")])]
+    variants = [(9, {}, []), (9, {"SCT_INFLATE_THREADS": "1"}, []), (9, {"SCT_INFLATE_THREADS": "12"}, []), (9, {"SCT_CLI_WORKERS": "8"}, []), (9, {}, ["--gzip-level", "4"]),
+                (9, {}, ["--gzip-level", "1"]), (1, {}, []), (9, {}, ["--devices", "0", "0"]), (9, {}, ["-o", os.path.join(work, "out.tsv")])]
     if quick:
         variants = variants[:4]
     out = os.path.join(work, "out.tsv.gz")

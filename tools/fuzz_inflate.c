@@ -36,6 +36,9 @@ void sctio_pinflate_free(void *p);
 void sctio_piece_free(uint8_t *piece);
 int64_t sctio_piece_head(void);
 uint32_t sctio_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2);
+/* the fast compressor of the command's output (csrc/sct_fdeflate.c) */
+int64_t sctfd_gzip_member(const uint8_t *in, int64_t n, uint8_t *out, void *scratch_mem);
+int64_t sctfd_scratch_bytes(void);
 
 static uint64_t rng_state = 88172645463325252ull;
 static uint64_t rnd(void) {
@@ -304,6 +307,37 @@ static int run_parallel(const uint8_t *c, size_t n, uint8_t *out, size_t *out_n,
     return verdict;
 }
 
+/* The other direction: the structured data through the fast compressor (one gzip member, output buffer exactly as large as the
+ * contract says: a write past it is an ASan report), decoded by zlib: must be the data, CRC and length included. */
+static long fd_ok = 0, fd_stored_like = 0;
+static int check_fast_compressor(const uint8_t *plain, size_t pn, uint8_t *back) {
+    static void *scratch = NULL;
+    if (!scratch) scratch = malloc((size_t)sctfd_scratch_bytes());
+    uint8_t *in = (uint8_t *)malloc(pn ? pn : 1);
+    memcpy(in, plain, pn);
+    const size_t cap = pn + pn / 1000 + 64;
+    uint8_t *z = (uint8_t *)malloc(cap);
+    const int64_t zn = sctfd_gzip_member(in, (int64_t)pn, z, scratch);
+    int ok = zn > 0 && (size_t)zn <= cap;
+    if (ok) {
+        z_stream s;
+        memset(&s, 0, sizeof(s));
+        if (inflateInit2(&s, 31) != Z_OK) abort();
+        s.next_in = z;
+        s.avail_in = (uInt)zn;
+        s.next_out = back;
+        s.avail_out = OUT_CAP;
+        const int rc = inflate(&s, Z_FINISH);
+        ok = rc == Z_STREAM_END && s.total_out == pn && s.avail_in == 0 && memcmp(back, plain, pn) == 0;
+        inflateEnd(&s);
+        if ((size_t)zn > pn) fd_stored_like++;
+    }
+    free(z);
+    free(in);
+    if (ok) fd_ok++;
+    return ok;
+}
+
 int main(int argc, char **argv) {
     const long iters = argc > 1 ? atol(argv[1]) : 100000;
     rng_state ^= (uint64_t)(argc > 2 ? atoll(argv[2]) : 1) * 0x9E3779B97F4A7C15ull;
@@ -316,6 +350,10 @@ int main(int argc, char **argv) {
     static const size_t caps[] = {65536, 65537, 70001, 131072, 1 << 20};
     for (long it = 0; it < iters; it++) {
         const size_t pn = make_plain(plain);
+        if (!check_fast_compressor(plain, pn, op)) {
+            fprintf(stderr, "FAST COMPRESSOR: zlib does not get the data back at iteration %ld (%zu bytes)\n", it, pn);
+            return 2;
+        }
         size_t cn = deflate_raw(plain, pn, comp);
         const int keep_valid = below(8) == 0;
         if (!keep_valid) cn = mutate(comp, cn, other, other_n);
@@ -382,6 +420,7 @@ int main(int argc, char **argv) {
         printf("PARALLEL %ld streams: finishes like the serial decoder with identical output %ld, refuses like it %ld, verdict differs %ld, output limit %ld; "
                "pieces accepted from speculative decoding %ld, decoded again serially %ld, hand-overs from the serial decoder %ld, piece CRCs wrong %ld\n",
                iters, par_ok, par_bad, par_vs_serial, par_limit, par_pieces_spec, par_pieces_redo, par_handover, par_crc_bad);
+    printf("COMPRESSOR %ld inputs through csrc/sct_fdeflate.c and back through zlib: identical %ld (%ld of them not smaller than the input: stored blocks)\n", iters, fd_ok, fd_stored_like);
     fflush(stdout);
     free(plain); free(comp); free(other); free(oz); free(oo); free(op);
     return (ours_ok_zlib_bad || ours_bad_zlib_ok || par_vs_serial || par_crc_bad) ? 3 : 0;
