@@ -88,7 +88,7 @@ def pmc_quote(workload_desc, fname="k_filter_counters.json"):
 
 def valu_mix(kernel_name):
     """The committed instruction-mix estimate of the dominant kernel (tools/valu_mix.py), if it is about this kernel."""
-    path = os.path.join(ROOT, "profiles", "r03_valu_mix.json")
+    path = os.path.join(ROOT, "profiles", "r04_valu_mix.json")
     if not kernel_name or not os.path.exists(path):
         return None
     m = json.load(open(path))
@@ -307,11 +307,11 @@ def hbm_roofline(loops, avg, desc, quote_file, exhaustive=False):
             mix = valu_mix(q.get("kernel"))
             if mix:
                 # ceiling of THIS kernel's instruction mix: 1024 SIMDs x 2.4 GHz / (mean cycles per wave-instruction of the mix,
-                # every opcode priced at its measured issue cost: profiles/r03_valu_mix.json)
+                # every opcode priced at its measured issue cost: profiles/r04_valu_mix.json)
                 peak = 1024 * 2.4e9 / mix["mean_cycles_per_instruction"]
                 v.update({"full_rate_share": mix["valu_full_rate_share"], "mean_cycles_per_instruction": mix["mean_cycles_per_instruction"],
                           "peak_wave_insts_per_s": peak, "frac": round(min(w / peak, 1.0), 3), "frac_uncapped": round(w / peak, 3),
-                          "mix_source": "profiles/r03_valu_mix.json (tools/valu_mix.py: disassembly weighted by loop depth; issue costs tools/valu_peak.hip)"})
+                          "mix_source": "profiles/r04_valu_mix.json (tools/valu_mix.py: disassembly weighted by loop depth; issue costs tools/valu_peak.hip)"})
             else:
                 v.update({"peak_wave_insts_per_s": VALU_PEAK_WINST_S, "frac": round(min(w / VALU_PEAK_WINST_S, 1.0), 3),
                           "frac_uncapped": round(w / VALU_PEAK_WINST_S, 3)})

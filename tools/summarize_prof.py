@@ -53,6 +53,11 @@ def main():
             out[k]["lds_bank_conflict_share_of_lds_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]
         if c.get("SQ_LEVEL_WAVES") and c.get("SQ_BUSY_CU_CYCLES"):
             out[k]["mean_waves_per_cu_while_busy"] = c["SQ_LEVEL_WAVES"] / c["SQ_BUSY_CU_CYCLES"]
+        elif c.get("SQ_WAVE_CYCLES") and c.get("SQ_BUSY_CU_CYCLES"):
+            # SQ_LEVEL_WAVES reads 0 on this stack.  SQ_WAVE_CYCLES counts quad-cycles of resident waves (MI355X_MICROARCH.md: SQ PMC
+            # units), SQ_BUSY_CU_CYCLES cycles of busy CUs (k_filter: 1.44e9 = 256 CUs x 2.6 ms x 2.2 GHz): waves per busy CU = 4 x ratio
+            out[k]["mean_waves_per_cu_while_busy"] = 4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CU_CYCLES"]
+            out[k]["mean_waves_per_cu_note"] = "4 x SQ_WAVE_CYCLES (quad-cycles) / SQ_BUSY_CU_CYCLES (cycles), counters of two separate passes"
     with open("profiles/%s_pmc_summary.json" % tag, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     if dom and os.path.exists(bench):

@@ -19,7 +19,7 @@ import re
 import sys
 
 MAX_DEPTH = 4   # family passes > bucket entries / batches > automaton steps > (inner bookkeeping); deeper nesting is layout, not loops
-KERNEL = "_Z8k_filterILi2EjLi0ELi6ELi6ELi64ELb0ELb1ElEv10FilterArgsIT7_E"   # k_filter<2, unsigned int, 0, 6, 6, 64, false, true, long>
+KERNEL = "_Z8k_filterILi2EjLi0ELi6ELi6ELi64ELb0ELb1ElLb0EEv10FilterArgsIT7_E"   # k_filter<2, unsigned int, 0, 6, 6, 64, false, true, long, false>
 
 
 def kernel_lines(path, sym):
@@ -83,7 +83,7 @@ def main():
             return rates.get("v_lshrrev_b32_sdwa", 4.2), False
         return 4.2, False                   # unmeasured: priced as half rate (pessimistic for the ceiling = optimistic for nobody)
 
-    out = {"kernel": "k_filter<2, unsigned int, 0, 6, 6, 64, false, true, long>", "static_valu_instructions": len(ops),
+    out = {"kernel": "k_filter<2, unsigned int, 0, 6, 6, 64, false, true, long, false>", "static_valu_instructions": len(ops),
            "loops_found": len(loops), "max_loop_depth": max(depth) if depth else 0, "by_weight": {}}
     measured_share = sum(c for o, c in static.items() if cls(o)[1]) / float(len(ops))
     out["static_share_of_instructions_whose_opcode_was_measured"] = round(measured_share, 3)
