@@ -18,6 +18,13 @@ void sct_launch_filter_e1(SctFilterVariant v, const FilterArgs<int64_t> &fa, uns
 void sct_launch_filter_e1(SctFilterVariant v, const FilterArgs<uint32_t> &fa, unsigned grid, unsigned grid64, hipStream_t st);
 void sct_launch_filter_e2(SctFilterVariant v, const FilterArgs<int64_t> &fa, unsigned grid, unsigned grid64, hipStream_t st);
 void sct_launch_filter_e2(SctFilterVariant v, const FilterArgs<uint32_t> &fa, unsigned grid, unsigned grid64, hipStream_t st);
+// the special launch's instantiations (v.special), translation units filter_sp_e0/1/2.hip
+void sct_launch_filter_sp_e0(SctFilterVariant v, const FilterArgs<int64_t> &fa, unsigned grid, unsigned grid64, hipStream_t st);
+void sct_launch_filter_sp_e0(SctFilterVariant v, const FilterArgs<uint32_t> &fa, unsigned grid, unsigned grid64, hipStream_t st);
+void sct_launch_filter_sp_e1(SctFilterVariant v, const FilterArgs<int64_t> &fa, unsigned grid, unsigned grid64, hipStream_t st);
+void sct_launch_filter_sp_e1(SctFilterVariant v, const FilterArgs<uint32_t> &fa, unsigned grid, unsigned grid64, hipStream_t st);
+void sct_launch_filter_sp_e2(SctFilterVariant v, const FilterArgs<int64_t> &fa, unsigned grid, unsigned grid64, hipStream_t st);
+void sct_launch_filter_sp_e2(SctFilterVariant v, const FilterArgs<uint32_t> &fa, unsigned grid, unsigned grid64, hipStream_t st);
 
 // the partitioned join of the thirds scheme at max_err = 1 (k_join.hip.h, translation unit join_e1.hip): the passes for rows
 // [row0, row1) — tuples, probes —, and the finish over all rows

@@ -656,6 +656,12 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
 
 template <typename OffT>
 static void launch_filter(int max_err, SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, unsigned g64, hipStream_t st) {
+    if (v.special) {
+        if (max_err == 0) sct_launch_filter_sp_e0(v, fa, g, g64, st);
+        else if (max_err == 1) sct_launch_filter_sp_e1(v, fa, g, g64, st);
+        else sct_launch_filter_sp_e2(v, fa, g, g64, st);
+        return;
+    }
     if (max_err == 0) sct_launch_filter_e0(v, fa, g, g64, st);
     else if (max_err == 1) sct_launch_filter_e1(v, fa, g, g64, st);
     else sct_launch_filter_e2(v, fa, g, g64, st);

@@ -28,7 +28,7 @@ import numpy as np
 
 from . import _native, fastio
 
-# Blocks of 4 MB (105 k rows of the usual shape).  Measured on the GPU box, 10 M rows (tools/cli_workers_sweep.sh): the reader
+# Blocks of 4 MB (105 k rows of the usual shape).  Measured on the GPU box, 10 M rows (tools/history/cli_workers_sweep.sh): the reader
 # finishes a gzip input in 0.67 s with 32 MB blocks and in 0.52 s with 4 or 8 MB ones — a piece that has just been inflated is still
 # in the cache when it is copied out, CRC-summed and cut at its last line end —, a plain-text input in 0.36 / 0.19 s; and the last
 # block's parse + match + render + compress, which nothing overlaps, shrinks with the block.  (The environment variable is for tests.)

@@ -48,15 +48,18 @@ def test_core_header_and_table_builder_under_asan_ubsan():
 
 
 def test_inflate_differential_fuzz_short_run():
-    """tools/fuzz_inflate.c for 4 000 mutated streams under ASan + UBSan: the decoder of csrc/sct_inflate.c and zlib must agree on
-    which streams are valid and on every byte of the valid ones (the recorded long run — 1.2 M streams — is
-    profiles/r03_inflate_fuzz.log)."""
+    """tools/fuzz_inflate.c for 2 000 mutated streams under ASan + UBSan: the serial decoder (csrc/sct_inflate.c), the parallel driver
+    (csrc/sct_pinflate.c: threads, chunking, hand-over) and zlib must agree on which streams are valid and on every byte of the valid
+    ones; every structured input also goes through the fast compressor (csrc/sct_fdeflate.c) and back through zlib.  The recorded long
+    run — 1.02 M streams — is profiles/r04_inflate_fuzz.log."""
     build = os.path.join(util.HERE, "_build")
     os.makedirs(build, exist_ok=True)
     exe = os.path.join(build, "fuzz_inflate_asan")
     subprocess.check_call(["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
-                           os.path.join(ROOT, "tools", "fuzz_inflate.c"), os.path.join(ROOT, "sctagger_amd", "csrc", "sct_inflate.c"), "-lz"])
-    r = subprocess.run([exe, "4000", "77"], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"), timeout=900)
+                           os.path.join(ROOT, "tools", "fuzz_inflate.c"), os.path.join(ROOT, "sctagger_amd", "csrc", "sct_inflate.c"),
+                           os.path.join(ROOT, "sctagger_amd", "csrc", "sct_pinflate.c"), os.path.join(ROOT, "sctagger_amd", "csrc", "sct_fdeflate.c"), "-lz", "-lpthread"])
+    r = subprocess.run([exe, "2000", "77"], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"), timeout=900)
     out = r.stdout.decode() + r.stderr.decode()
-    assert r.returncode == 0 and "DONE 4000 streams" in out and "decoder ok / zlib not 0, zlib ok / decoder not 0" in out, out[-3000:]
+    assert r.returncode == 0 and "DONE 2000 streams" in out and "decoder ok / zlib not 0, zlib ok / decoder not 0" in out, out[-3000:]
+    assert "verdict differs 0" in out and "piece CRCs wrong 0" in out and "COMPRESSOR 2000 inputs" in out and "identical 2000" in out, out[-3000:]
     assert "runtime error" not in out and "AddressSanitizer" not in out
