@@ -187,6 +187,9 @@ int sct_sync(sct_ctx *ctx);
  *   "lanes"            1..8  chunks of a stream call in flight at once, each on a stream of its own (default 5)
  *   "zero_copy"        0|1   1 (default): sct_match_stream's kernels read page-locked segs / index buffers in place over the
  *                            host link; 0: they are uploaded first
+ *   "gather"           0|1   1 (default): in a zero-copy batch the rows of more than 63 characters are copied to the device
+ *                            (one coalesced pass, k_special_gather) before the special launch cuts them into windows; 0: its
+ *                            window lanes read them over the link.  Same results.
  *   "register"         0|1   1 (default): pageable segs / index / min_e / counts buffers of a stream call of at least 4 MB of
  *                            segments are page-locked for the duration of the call (hipHostRegister) and then read and
  *                            written in place as well; 0: they go through staged copies

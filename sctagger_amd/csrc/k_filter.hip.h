@@ -1010,6 +1010,9 @@ struct FilterWave {
 struct __attribute__((aligned(32))) SctSpecialRec {
     uint64_t lo, hi, bad, len;
 };
+// len = SCT_REC_NONE: nothing is known about the row (read its bytes where the caller has them); SCT_REC_GATHERED: the row has more
+// than PLANE_MAX characters and k_special_gather copied it to the device: its first byte is at gather[lo]
+static constexpr uint64_t SCT_REC_NONE = ~0ull, SCT_REC_GATHERED = ~1ull;
 
 template <typename OffT>
 struct FilterArgs {
@@ -1041,6 +1044,9 @@ struct FilterArgs {
                                   // first stage: the same for the rows it hands to the second (beside list_defer)
     const SctSpecialRec *rec_in;  // special launch: the records of its listed rows
     uint32_t rec_cap;
+    const uint8_t *gather;        // special launch: where the long rows of a zero-copy batch were copied (SCT_REC_GATHERED records), or NULL
+    uint8_t *gather_out;          // main launch of a zero-copy batch: copy the long rows there while the block's bytes are in LDS
+    uint64_t gather_cap;          //   (bytes; cursor = ctr[CTR_GATHER]); what it cannot take is left to k_special_gather
     uint32_t *ctr;                // the batch's counter record (CTR_*)
     unsigned long long *slot_cursor;
     unsigned long long *arena_cursors;   // main launch of a large batch: SLOT_ARENAS cursors, 64 bytes apart (NULL: the one slot_cursor)
@@ -1061,6 +1067,40 @@ __device__ __forceinline__ unsigned long long *sct_slot_arena(const FilterArgs<O
     base_off = (unsigned long long)k * a.arena_cap;
     cap_end = base_off + a.arena_cap;
     return a.arena_cursors + 8u * k;
+}
+
+// k_special_gather: the listed rows of more than PLANE_MAX characters that the main launch did not copy itself (filter_rows, COOP:
+// it copies them from its LDS stage; not the rows of blocks that staged per wave), copied from where the caller has them (page-locked
+// host memory of a zero-copy batch) into the gather buffer on the device, one wave per row, whole 16-byte pieces.  The special
+// launch's window lanes read 4-byte words of their own: over the link that took four times the filtering itself (1 % rows of 80
+// characters: 2.1 of 7.1 ms per 10 M rows).  This kernel's row-sized reads are bound by the link's outstanding requests — 12 ns a
+// row whatever its length —, which is why the main launch takes the rows from its own streaming pass where it can.  A row that
+// finds no room keeps SCT_REC_NONE.
+template <typename OffT>
+__global__ void __launch_bounds__(256) k_special_gather(const uint8_t *__restrict__ segs, const OffT *__restrict__ offs, int64_t seg_bytes,
+                                                        const int32_t *__restrict__ rows, const uint32_t *__restrict__ n_dev, SctSpecialRec *__restrict__ rec,
+                                                        uint32_t rec_cap, uint8_t *__restrict__ gather, uint64_t gather_cap, uint32_t *__restrict__ ctr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    int64_t n = (int64_t)*n_dev;
+    if (n > (int64_t)rec_cap) n = rec_cap;
+    for (int64_t k = wave; k < n; k += n_waves) {
+        const int64_t r = rows[k];
+        int64_t start, len;
+        sct_row_span(offs, r, seg_bytes, start, len);
+        if (len <= PLANE_MAX) continue;   // (a row of one window: the listing launch left its planes)
+        if (rec[k].len == SCT_REC_GATHERED) continue;   // (the listing launch copied the row while it had it in LDS)
+        const uint64_t a0 = ((uint64_t)(uintptr_t)segs + (uint64_t)start) & ~15ull, a1 = (uint64_t)(uintptr_t)segs + (uint64_t)(start + len);
+        const uint64_t bytes = (a1 - a0 + 15) & ~15ull;
+        unsigned long long off = 0;
+        if (lane == 0) off = atomicAdd(reinterpret_cast<unsigned long long *>(ctr + CTR_GATHER), (unsigned long long)bytes);
+        off = __shfl(off, 0, 64);
+        if (off + bytes > gather_cap) continue;
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const __attribute__((address_space(1))) u4 *src = (const __attribute__((address_space(1))) u4 *)(uintptr_t)a0;
+        for (uint64_t i = (uint64_t)lane; i < bytes / 16; i += 64) *reinterpret_cast<u4 *>(gather + off + 16 * i) = __builtin_nontemporal_load(src + i);
+        if (lane == 0) rec[k] = SctSpecialRec{off + (((uint64_t)(uintptr_t)segs + (uint64_t)start) - a0), 0, 0, SCT_REC_GATHERED};
+    }
 }
 
 // One wave's RPW rows, starting at row (or list position) `first`.
@@ -1117,6 +1157,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     const bool anyrow = __ballot(inrange) != 0;
     W lo, hi, badmask = 0;
     bool decoded = false, high_checked = false;
+    [[maybe_unused]] uint64_t gathered_at = ~0ull;   // COOP: where this lane's long row went in the gather buffer
     if constexpr (COOP) {
         static_assert(RPW == 64, "the cooperative stage belongs to the main launch");
         const int widx = (int)(threadIdx.x >> 6);
@@ -1142,6 +1183,31 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
                     if (badmask != 0) sct_report_high_bytes(reinterpret_cast<const uint8_t *>(block_lds) + so, dl, (uint64_t)badmask, start, bl, E, a.prefix_len, a.ctr);
                 }
                 high_checked = true;
+                // a zero-copy batch: rows of more than PLANE_MAX characters go to the special launch, whose window lanes would fetch
+                // them over the link once more, row by row — 12 ns a row whatever its length (the link's outstanding reads), 1.2 ms
+                // for 1 % of 10 M rows.  Their bytes are in LDS now: the wave copies them to the device's gather buffer, word by word.
+                if (a.gather_out != nullptr) {
+                    const bool lg = inrange && len_all > PLANE_MAX && start >= A && start + (int64_t)len_all <= B;
+                    uint64_t todo = __ballot(lg);
+                    const uint64_t base = ((uint64_t)(uintptr_t)a.segs + (uint64_t)A) & ~127ull;
+                    const uint32_t so_mine = lg ? (uint32_t)((uint64_t)(uintptr_t)a.segs + (uint64_t)start - base) : 0u;
+                    while (todo != 0) {
+                        const int src = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const uint32_t so_r = (uint32_t)__shfl((int)so_mine, src, 64);
+                        const int ln = __shfl(len_all, src, 64);
+                        const int nw = (int)(((so_r & 3u) + (uint32_t)ln + 3u) >> 2);
+                        const uint64_t pad = ((uint64_t)nw * 4 + 15) & ~15ull;
+                        unsigned long long off = 0;
+                        if (lane == 0) off = atomicAdd(reinterpret_cast<unsigned long long *>(a.ctr + CTR_GATHER), (unsigned long long)pad);
+                        off = __shfl(off, 0, 64);
+                        if (off + pad > a.gather_cap) continue;
+                        uint32_t *dst = reinterpret_cast<uint32_t *>(a.gather_out + off);
+                        const uint32_t *wp = block_lds + (so_r >> 2);
+                        for (int i = lane; i < nw; i += 64) dst[i] = wp[i];
+                        if (lane == src) gathered_at = off + (so_r & 3u);
+                    }
+                }
                 __syncthreads();   // the stage is every wave's working LDS from here on
                 decoded = true;
             }
@@ -1150,17 +1216,23 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     if (!mykind) return;
     if (!anyrow) return;
     [[maybe_unused]] bool has_rec = false;
+    [[maybe_unused]] SctSpecialRec rec{0, 0, 0, SCT_REC_NONE};
+    [[maybe_unused]] const uint8_t *row_bytes = a.segs + row_start;
     if constexpr (SP) {
-        if (toolong && win == 0) {   // more windows than the row has lanes: the scan kernels (via k_route_long).  (Such a row adds
-            const uint32_t k = atomicAdd(a.defer_count, 1u);            // nothing to the wave's longest text, so exactly one of the
-            a.list_defer[k] = (int32_t)r;                               // two mask widths gets here with it.)
+        if (toolong && win == 0) {   // more windows than the row has lanes: the next stage, or the scan kernels (via k_route_long).
+            const uint32_t k = atomicAdd(a.defer_count, 1u);            // (Such a row adds nothing to the wave's longest text, so
+            a.list_defer[k] = (int32_t)r;                               // exactly one of the two mask widths gets here with it.)
+            if (a.rec_out != nullptr && k < a.rec_cap)                  // its record (where its bytes were gathered) goes along
+                a.rec_out[k] = (a.rec_in != nullptr && (uint64_t)gid < (uint64_t)a.rec_cap) ? a.rec_in[gid] : SctSpecialRec{0, 0, 0, SCT_REC_NONE};
             a.cnt[r] = CNT_DEFER;
         }
         // a row of one window: the listing launch left its planes; longer rows are decoded from their bytes
-        SctSpecialRec rec{0, 0, 0, ~0ull};
-        if (a.rec_in != nullptr && inrange && win == 0 && (uint64_t)gid < (uint64_t)a.rec_cap && len_all <= PLANE_MAX) rec = a.rec_in[gid];
-        has_rec = rec.len != ~0ull;   // (the first stage marks the rows it hands on without planes)
-        sct_decode_row_mask<W>(a.segs, start, has_rec ? 0 : len, lo, hi, badmask);
+        // what the listing launch left about the row: its planes (one window), or where its bytes were gathered (longer rows)
+        if (a.rec_in != nullptr && inrange && (uint64_t)gid < (uint64_t)a.rec_cap) rec = a.rec_in[gid];
+        const bool gathered = rec.len == SCT_REC_GATHERED && a.gather != nullptr && len_all > PLANE_MAX;
+        has_rec = rec.len <= (uint64_t)PLANE_MAX && win == 0 && len_all <= PLANE_MAX;
+        row_bytes = gathered ? a.gather + rec.lo : a.segs + row_start;
+        sct_decode_row_mask<W>(row_bytes, (int64_t)win * sp_step, has_rec ? 0 : len, lo, hi, badmask);
         if (has_rec) {
             lo = len > 0 ? (W)rec.lo : (W)0;
             hi = len > 0 ? (W)rec.hi : (W)0;
@@ -1191,7 +1263,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
                 while (bad != 0) {
                     const int i = __builtin_ctzll(bad);
                     bad &= bad - 1;
-                    if (a.segs[start + i] >= 128 && sct_byte_is_read(a.segs + row_start, len_all, (int64_t)win * sp_step + i, bl, E, a.prefix_len)) {
+                    if (row_bytes[(int64_t)win * sp_step + i] >= 128 && sct_byte_is_read(row_bytes, len_all, (int64_t)win * sp_step + i, bl, E, a.prefix_len)) {
                         atomicMin(reinterpret_cast<unsigned long long *>(a.ctr + CTR_BAD_BYTE), (unsigned long long)(start + i));
                         break;
                     }
@@ -1210,7 +1282,10 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
         if (!line && a.cnt8 && (!fits || (nonacgt && a.prefix_len > 0))) a.cnt8[r] = 0;  // with `line` the wave's store covers them
         if (!fits) {
             if (len_all > PLANE_MAX) {  // more characters than one lane's planes hold: the special launch cuts the row into windows
-                a.list_special[atomicAdd(&a.ctr[CTR_SPECIAL], 1u)] = (int32_t)r;
+                const uint32_t k = atomicAdd(&a.ctr[CTR_SPECIAL], 1u);
+                a.list_special[k] = (int32_t)r;
+                if (a.rec_out != nullptr && k < a.rec_cap)
+                    a.rec_out[k] = gathered_at != ~0ull ? SctSpecialRec{gathered_at, 0, 0, SCT_REC_GATHERED} : SctSpecialRec{0, 0, 0, SCT_REC_NONE};
                 a.cnt[r] = CNT_DEFER;
             } else {
                 if (!line) a.min_e[r] = SCT_NO_HIT;
@@ -1466,7 +1541,8 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
             a.list_defer[k] = (int32_t)r;
             if constexpr (SP) {   // first stage of the special launch: the planes go along with the row
                 if (a.rec_out != nullptr && k < a.rec_cap)
-                    a.rec_out[k] = has_rec ? SctSpecialRec{(uint64_t)lo0, (uint64_t)hi0, (uint64_t)bad0, (uint64_t)len_all} : SctSpecialRec{0, 0, 0, ~0ull};
+                    a.rec_out[k] = has_rec ? SctSpecialRec{(uint64_t)lo0, (uint64_t)hi0, (uint64_t)bad0, (uint64_t)len_all}
+                                           : (rec.len == SCT_REC_GATHERED ? rec : SctSpecialRec{0, 0, 0, SCT_REC_NONE});
             }
             a.cnt[r] = CNT_DEFER;
         }

@@ -122,7 +122,9 @@ __global__ void __launch_bounds__(256) k_join_part0(const JoinArgs<OffT> ja) {
             if (!line && a.cnt8 && (!fits || (nonacgt && a.prefix_len > 0))) a.cnt8[r] = 0;
             if (!fits) {
                 if (len_all > PLANE_MAX) {
-                    a.list_special[atomicAdd(&a.ctr[CTR_SPECIAL], 1u)] = (int32_t)r;
+                    const uint32_t k = atomicAdd(&a.ctr[CTR_SPECIAL], 1u);
+                    a.list_special[k] = (int32_t)r;
+                    if (a.rec_out != nullptr && k < a.rec_cap) a.rec_out[k] = SctSpecialRec{0, 0, 0, SCT_REC_NONE};
                     a.cnt[r] = CNT_DEFER;
                 } else {
                     if (!line) a.min_e[r] = SCT_NO_HIT;

@@ -39,6 +39,7 @@ enum {
     CTR_TOTAL = 14,     // (64-bit, words 14-15) total number of hits of the batch
     CTR_SPECIAL = 16,   // rows the main launch lists for the special launch (list_special): restricted starts, more than PLANE_MAX characters
     CTR_SPECIAL2 = 17,  // rows the special launch's first stage (16 rows per wave, bucket slots) hands to its second (list_special2)
+    CTR_GATHER = 18,    // (64-bit, words 18-19) bytes used in the gather buffer (k_special_gather: long listed rows copied to the device)
     CTR_WORDS = 32
 };
 

@@ -169,6 +169,7 @@ struct Lane {
     // work / results
     DevBuf min_e, cnt, route, slots, slots_retry, list_retry, list_special, list_special2, rec_special, rec_special2, slot_off, wave_base, list_long, list_scan, list_dp, counters, hit_offs, sums, hits,
         part_best, part_cnt, cnt_out;
+    DevBuf gather;      // zero-copy batches: the listed rows of more than PLANE_MAX characters, copied to the device (k_special_gather)
     DevBuf arena_cur;   // SLOT_ARENAS cursors of the main launch's slot array, 64 bytes apart (sct_slot_arena)
     DevBuf j_planes, j_len, j_wave, j_cnt, j_slots, j_tup0, j_cnt0, j_tup1, j_cnt1;   // the partitioned join (k_join.hip.h)
     uint64_t slots_cap = 0, retry_cap = 0;
@@ -203,7 +204,7 @@ struct Lane {
     void release() {
         DevBuf *bufs[] = {&segs, &offs64, &offs32, &index_in, &min_e, &cnt, &route, &slots, &slots_retry, &list_retry, &list_special, &list_special2, &rec_special, &rec_special2, &slot_off, &wave_base, &list_long,
                           &list_scan, &list_dp, &counters, &hit_offs, &sums, &hits, &part_best, &part_cnt, &cnt_out,
-                          &arena_cur, &j_planes, &j_len, &j_wave, &j_cnt, &j_slots, &j_tup0, &j_cnt0, &j_tup1, &j_cnt1};
+                          &gather, &arena_cur, &j_planes, &j_len, &j_wave, &j_cnt, &j_slots, &j_tup0, &j_cnt0, &j_tup1, &j_cnt1};
         for (DevBuf *b : bufs) b->release();
         for (hipEvent_t e : pool) (void)hipEventDestroy(e);
         pool.clear();
@@ -239,7 +240,7 @@ struct sct_ctx {
     uint32_t wl_mask = 0, wl_len_set = 0;
     int32_t wl_n = -1;
     // options
-    bool force_exhaustive = false, timing = true, no_thirds = false;
+    bool force_exhaustive = false, timing = true, no_thirds = false, no_gather = false;
     int thirds_mode = -1;  // -1 = thirds tables by the size of the set, 1 = built whatever the size (next sct_set_barcodes)
     int fb_mode = -1;      // thirds families: -1 / 1 = lookups read the fixed buckets, 0 = offsets + codes
     int wide_mode = -1;    // -1 = by the size of the barcode set, 0 = never, 1 = build and use the wide families whatever the size
@@ -442,6 +443,7 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
         if (value < 0 || value > 0x7FFFFFF0) return fail(SCT_E_ARG, "chunk_rows must be in 0 .. 2^31-16");
         c->chunk_rows = value;
     } else if (!strcmp(key, "zero_copy")) c->zero_copy = value != 0;
+    else if (!strcmp(key, "gather")) c->no_gather = value == 0;
     else if (!strcmp(key, "register")) c->auto_register = value != 0;
     else if (!strcmp(key, "fail_alloc_at")) {   // tests of the error paths: see FaultCounters
         if (value < 0) return fail(SCT_E_ARG, "fail_alloc_at must be >= 0");
@@ -633,6 +635,10 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
         const uint64_t rc = n1 / 8 < 65536 ? 65536 : n1 / 8;
         l.rec_cap = (uint32_t)(rc < 0x7FFFFFFFull ? rc : 0x7FFFFFFFull);
         if (l.rec_special.ensure(sizeof(SctSpecialRec) * (size_t)l.rec_cap) || l.rec_special2.ensure(sizeof(SctSpecialRec) * (size_t)l.rec_cap)) return g_code;
+        // the long rows of a zero-copy batch, gathered before the special launch reads them: 16 bytes per row of the batch (a tenth
+        // of the rows at 150 characters), between 4 MB and 256 MB; rows that find no room are read where the caller has them
+        const size_t gc = 16 * n1 < ((size_t)4 << 20) ? ((size_t)4 << 20) : (16 * n1 < ((size_t)256 << 20) ? 16 * n1 : ((size_t)256 << 20));
+        if (l.gather.ensure(gc)) return g_code;
     }
     if (l.hits.ensure(4 * (size_t)(l.slots_cap + l.retry_cap + 1))) return g_code;
     if (bp.use_join && n < ((int64_t)1 << 30)) {
@@ -700,6 +706,10 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.rec_out = l.rec_special.as<SctSpecialRec>();
     fa.rec_in = nullptr;
     fa.rec_cap = l.rec_cap;
+    const bool gather = l.host_segs != nullptr && l.gather.p != nullptr && !c->no_gather;   // a zero-copy batch (see k_special_gather)
+    fa.gather = nullptr;
+    fa.gather_out = gather ? l.gather.as<uint8_t>() : nullptr;
+    fa.gather_cap = (uint64_t)l.gather.cap;
     fa.ctr = ctr;
     fa.bl = c->bl;
     fa.prefix_len = bp.prefix_len;
@@ -754,6 +764,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         Timer t(c, l, "k_filter_retry");
         v.retry = true;
         fa.rec_out = nullptr;
+        fa.gather_out = nullptr;
         fa.n = 0;
         fa.n_dev = ctr + CTR_RETRY;
         fa.rows = l.list_retry.as<int32_t>();
@@ -783,6 +794,14 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.rows = l.list_special.as<int32_t>();
         fa.rec_in = l.rec_special.as<SctSpecialRec>();
         fa.rec_out = nullptr;
+        if (gather) {
+            // a zero-copy batch: every window lane of a long row would read its words over the link.  The main launch copied the rows
+            // it had in LDS; one wave per other listed row copies that row to the device first (striding, as the launch itself: how
+            // many rows there are is only known on the device).
+            k_special_gather<OffT><<<capped((n + 63) / 64), 256, 0, st>>>(fa.segs, offs, l.seg_bytes, fa.rows, fa.n_dev, l.rec_special.as<SctSpecialRec>(), l.rec_cap,
+                                                                      l.gather.as<uint8_t>(), (uint64_t)l.gather.cap, ctr);
+            fa.gather = l.gather.as<uint8_t>();
+        }
         if (v.slots) {
             v.special16 = true;
             fa.list_defer = l.list_special2.as<int32_t>();

@@ -196,3 +196,37 @@ def test_cfg3_with_noise_equals_exhaustive(m, n, frac_n, frac_long):
     lens = np.diff(offs).astype(np.uint8)
     me, cnt, hits = m.match_stream(segs, lens, 2, 16, index_format=_native.IDX_LEN8, count_format=_native.CNT_U8, hits_format=_native.HITS_U16)
     assert np.array_equal(me, got[0]) and np.array_equal(cnt, np.diff(got[1]).astype(np.uint8)) and np.array_equal(hits.astype(np.uint32), got[2])
+
+
+def test_long_rows_of_a_zero_copy_batch_are_gathered(m):
+    """Zero-copy batches: k_special_gather copies the listed rows of more than 63 characters to the device before the special
+    launch cuts them into windows.  Same results with the copy switched off, and when the rows outgrow the buffer (4 MB at this
+    batch size: 60 000 rows of 100 .. 139 characters are 7 MB — the rows that find no room are read over the link)."""
+    bc = synth.make_barcodes(500, seed=91)
+    rng = np.random.default_rng(92)
+    lengths = list(rng.integers(100, 140, size=60_000)) + [22, 63, 64, 0, 700] * 40
+    rng.shuffle(lengths)
+    segs, offs = rows_of_lengths(bc, lengths, 93, junk=0.01)
+    want = trie_oracle.match(bc, segs, offs, 2, threads=16, workers=8)
+    m.set_barcodes(bc)
+    m.set_option("force_exhaustive", 0)
+    n = offs.size - 1
+    try:
+        for skew in (0, 5):
+            buf = m.host_array(segs.size + skew, np.uint8)
+            psegs = buf[skew:]
+            psegs[:] = segs
+            poffs = m.host_array(offs.size, np.int64)
+            poffs[:] = offs
+            for gather in (1, 0):
+                m.set_option("gather", gather)
+                me, ho, hits = m.match_stream(psegs, poffs, 2, 16, index_format=_native.IDX_OFFS64, count_format=_native.CNT_OFFS64,
+                                              min_e=m.host_array(n, np.uint8), counts=m.host_array(n + 1, np.int64))
+                util.assert_same((me, ho, hits), want, "gather=%d skew=%d" % (gather, skew))
+                st = m.last_stats()
+                assert st["special"] >= int((np.diff(offs) > 63).sum())
+                assert st["exhaustive"] + st["restricted_start"] == 0, st
+    finally:
+        m.set_option("gather", 1)
+        m.sync()
+        m.release_host_arrays()
