@@ -102,8 +102,8 @@ void sct_free_hits(sct_ctx *ctx, uint32_t *hits);
  *   k-1 overlap.
  *   Limits: row counts, seg_bytes, hit offsets and the hit total are 64-bit throughout (the reference's own c_int index,
  *   scTagger.py:618, ends at 2^31 segment bytes); sct_upload_segments takes at most 2^31 - 16 rows per call.  Tested: 20 M rows
- *   in one call at the default chunking and 4.5 GB of segment bytes in one call (tests/test_gpu_limits.py).  NOT tested: more
- *   than 2^32 hits in one call (that is more than 16 GiB of page-locked result buffer).
+ *   in one call at the default chunking, 4.5 GB of segment bytes in one call, and 4.43 x 10^9 hits (> 2^32; a 17.7 GB
+ *   page-locked hit array) out of one call (tests/test_gpu_limits.py).
  *   Bytes >= 128: the reference raises (UnicodeDecodeError / IndexError, scTagger.py:682, :555, :512-516) when it inserts a
  *   window that contains one, and never looks at a byte no inserted window covers (:677-682: windows shorter than
  *   bl - max_err, and with -t > 1 windows whose first k raw bytes are not all in ACGT, are not inserted).  This library fails

@@ -206,3 +206,70 @@ def test_one_chunk_of_few_long_rows_is_cut_by_bytes(m):
     assert np.array_equal(me, np.tile(bme, reps)) and np.array_equal(cnt, np.tile(np.diff(bho).astype(np.uint32), reps))
     assert np.array_equal(hits, np.tile(bhits, reps))
     m.release_host_arrays()
+
+
+def _host_memory_available():
+    """bytes this process may still take: MemAvailable, capped by the cgroup's limit"""
+    avail = None
+    with open("/proc/meminfo") as f:
+        for line in f:
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    for p, q in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                 ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            lim = open(p).read().strip()
+            if lim != "max":
+                left = int(lim) - int(open(q).read().strip())
+                avail = left if avail is None else min(avail, left)
+        except (OSError, ValueError):
+            pass
+    return avail or 0
+
+
+def test_more_than_2_32_hits_in_one_call(m):
+    """Every row ties with ~1 000 barcodes (the barcode set = all 16-mers two substitutions away from A x 16, the rows =
+    A x 22): 4.4 M rows give more than 2^32 hits in ONE call — hit offsets and the hit total are 64-bit, the hit array is
+    more than 16 GiB.  Every row's list must be the oracle's list of one row.  (include/sctagger_hip.h "Limits")"""
+    if _host_memory_available() < (72 << 30):
+        pytest.skip("needs 72 GB of host memory for a 17.6 GB page-locked hit array and its checks")
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    centre = np.full(16, ord("A"), dtype=np.uint8)   # (a homopolymer: no shifted alignment gets below two edits)
+    rows = []
+    for i in range(16):
+        for j in range(i + 1, 16):
+            for a in acgt[1:]:
+                for b in acgt[1:]:
+                    s = centre.copy()
+                    s[i], s[j] = a, b
+                    rows.append(s)
+    bc = np.array(rows, dtype=np.uint8)
+    assert bc.shape == (1080, 16)
+    row = np.full(22, ord("A"), dtype=np.uint8)
+    one = trie_oracle.match(bc, row, np.array([0, row.size], dtype=np.int64), 2, threads=1, workers=1)
+    per_row = int(one[2].size)
+    assert one[0][0] == 2 and per_row == 1080, (one[0], per_row)
+    n = ((1 << 32) + (1 << 27)) // per_row + 1
+    total = n * per_row
+    assert total > (1 << 32)
+    m.set_barcodes(bc)
+    m.set_option("force_exhaustive", 0)
+    m.set_option("chunk_rows", 0)
+    psegs = m.host_array(n * row.size, np.uint8)
+    psegs.reshape(n, row.size)[:] = row
+    plens = m.host_array(n, np.uint8)
+    plens[:] = row.size
+    try:
+        me, cnt, hits = m.match_stream(psegs, plens, 2, 1, index_format=_native.IDX_LEN8, count_format=_native.CNT_U32,
+                                       min_e=m.host_array(n, np.uint8), counts=m.host_array(n, np.uint32), copy_hits=False)
+        assert hits.size == total and hits.dtype == np.uint32
+        assert (me[:n] == 2).all() and (cnt[:n] == per_row).all()
+        h2 = hits.reshape(n, per_row)
+        for r0 in range(0, n, 200_000):         # block by block: a whole-array comparison would take another 4 GB
+            assert (h2[r0:r0 + 200_000] == one[2]).all(), "rows %d.. differ from the oracle's list" % r0
+        del h2, hits
+        # 64-bit offsets out of the three-step API (the hits stay on the device: the total and the last offsets are what matters)
+        m.upload_segments(psegs, np.arange(n + 1, dtype=np.int64) * row.size)
+        assert m.run(2, threads=1) == total
+    finally:
+        m.release_host_arrays()
