@@ -19,11 +19,12 @@
 
 uint32_t sctio_crc32(uint32_t crc, const uint8_t *p, int64_t n);   /* sct_pinflate.c */
 
+#ifndef FD_HASH_BITS
 #define FD_HASH_BITS 15
+#endif
 #define FD_HASH_SIZE (1 << FD_HASH_BITS)
 #define FD_WINDOW 32768
 #define FD_BLOCK_SYMS 65536
-#define FD_MIN_MATCH 4
 #define FD_MAX_MATCH 258
 
 static const uint16_t fd_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -278,28 +279,58 @@ static void fd_write_block(fd_bw *w, const uint32_t *sym, int ns, const fd_freqs
         else if (rl_sym[i] == 17) fd_put(w, rl_extra[i], 3);
         else if (rl_sym[i] == 18) fd_put(w, rl_extra[i], 7);
     }
-    for (int i = 0; i < ns; i++) {
-        const uint32_t s = sym[i];
-        if (!(s & 0x80000000u)) {
-            fd_put(w, lc[s], ll[s]);
-        } else {
-            const uint32_t l3 = (s >> 15) & 0xFFu, d1 = s & 0x7FFFu;
-            const int c = fd_len_code[l3];
-            fd_put(w, lc[257 + c], ll[257 + c]);
-            fd_put(w, l3 + 3 - fd_len_base[c], fd_len_extra[c]);
-            const int d = fd_dcode(d1);
-            fd_put(w, dc[d], dl[d]);
-            fd_put(w, d1 + 1 - fd_dist_base[d], fd_dist_extra[d]);
-        }
+    /* The symbols.  More than half of the compressor's time was here with one fd_put per code (two table reads and a conditional
+     * flush each); the rows are mostly literals (DNA), so: code and length of a literal in one table word, those of a match length
+     * with its extra bits folded in, up to three literals (45 bits) or one match (48) between two unconditional 8-byte stores. */
+    uint32_t lit_e[256], len_e[256];   /* bits 0..23 the code (+ extra bits), 24..31 its width */
+    for (int i = 0; i < 256; i++) lit_e[i] = (uint32_t)lc[i] | ((uint32_t)ll[i] << 24);
+    for (int l3 = 0; l3 < 256; l3++) {
+        const int c = fd_len_code[l3];
+        len_e[l3] = ((uint32_t)lc[257 + c] | ((uint32_t)(l3 + 3 - fd_len_base[c]) << ll[257 + c])) | ((uint32_t)(ll[257 + c] + fd_len_extra[c]) << 24);
     }
-    fd_put(w, lc[256], ll[256]);
+    while (w->n >= 8) {   /* whole bytes out; up to 7 bits stay */
+        *w->p++ = (uint8_t)w->bits;
+        w->bits >>= 8;
+        w->n -= 8;
+    }
+    uint64_t acc = w->bits;
+    int nb = w->n;
+    uint8_t *p = w->p;
+#define FD_ADD(v, l) (acc |= (uint64_t)(v) << nb, nb += (int)(l))
+#define FD_STORE() (memcpy(p, &acc, 8), p += nb >> 3, acc >>= (nb & ~7), nb &= 7)
+    for (int i = 0; i < ns;) {
+        uint32_t s = sym[i++];
+        if (!(s & 0x80000000u)) {
+            uint32_t e = lit_e[s];
+            FD_ADD(e & 0xFFFFFFu, e >> 24);
+            if (i < ns && !((s = sym[i]) & 0x80000000u)) {
+                e = lit_e[s];
+                FD_ADD(e & 0xFFFFFFu, e >> 24);
+                i++;
+                if (i < ns && !((s = sym[i]) & 0x80000000u)) {
+                    e = lit_e[s];
+                    FD_ADD(e & 0xFFFFFFu, e >> 24);
+                    i++;
+                }
+            }
+        } else {
+            const uint32_t d1 = s & 0x7FFFu, e = len_e[(s >> 15) & 0xFFu];
+            const int d = fd_dcode(d1);
+            FD_ADD(e & 0xFFFFFFu, e >> 24);
+            FD_ADD(dc[d], dl[d]);
+            FD_ADD(d1 + 1 - fd_dist_base[d], fd_dist_extra[d]);
+        }
+        FD_STORE();
+    }
+    FD_ADD(lc[256], ll[256]);
+    FD_STORE();
+#undef FD_ADD
+#undef FD_STORE
+    w->bits = acc;
+    w->n = nb;
+    w->p = p;
 }
 
-static inline uint32_t fd_load32(const uint8_t *p) {
-    uint32_t v;
-    memcpy(&v, p, 4);
-    return v;
-}
 static inline uint64_t fd_load64(const uint8_t *p) {
     uint64_t v;
     memcpy(&v, p, 8);
@@ -310,7 +341,25 @@ static inline uint64_t fd_load64(const uint8_t *p) {
  * short match costs more bits than the literals it replaces.  Measured on the command's output text (ratio; speed is the same):
  * accept from 4: 3.43, from 6: 3.79, from 7: 3.75, from 8: 3.65; hashing 5 / 6 bytes instead: 3.58 / 3.46; zlib level 1 / 4: 3.28 / 3.61. */
 #define FD_MIN_ACCEPT 6
-static inline uint32_t fd_hash(uint32_t v) { return (v * 2654435761u) >> (32 - FD_HASH_BITS); }
+/* ... and only if it is cheaper than its bytes as literals (fd_worth): a match costs about FD_MATCH_BASE_BITS (length code + distance
+ * code) + the distance's extra bits, a letter of a segment 2.25 bits, another character about 5.  Ratio 3.80 -> 3.90 (base 10; 9: 3.89,
+ * 11: 3.88, 12: 3.89) at the same speed.  Hashing more bytes finds a candidate of six letters at almost every position of a segment
+ * (4^6 six-grams, 16 K of them in the window) and spends its time rejecting them: 5 bytes 140 MB/s, 6 bytes 112 against 226. */
+#ifndef FD_MATCH_BASE_BITS
+#define FD_MATCH_BASE_BITS 10
+#endif
+#ifndef FD_HASH_BYTES
+#define FD_HASH_BYTES 4
+#endif
+static inline uint32_t fd_hash64(uint64_t v) { return (uint32_t)(((v << (64 - 8 * FD_HASH_BYTES)) * 0x9E3779B185EBCA87ull) >> (64 - FD_HASH_BITS)); }
+static inline int fd_worth(uint64_t v8, int64_t len, int64_t dist) {
+    /* literal cost of the matched bytes, in eighths of a bit: 18 for a letter, 40 for the other characters of a row (digits, tabs,
+     * commas, line ends: bit 6 clear), counted among the first eight bytes — the rest are priced as letters */
+    const uint64_t m = ~v8 & 0x4040404040404040ull & (len >= 8 ? ~0ull : ((1ull << (8 * len)) - 1));
+    const int cost = 18 * (int)len + 22 * __builtin_popcountll(m);
+    const int dbits = dist < 5 ? 0 : (63 - __builtin_clzll((uint64_t)dist - 1)) - 1;   /* extra bits of the distance code */
+    return cost > 8 * (FD_MATCH_BASE_BITS + dbits);
+}
 
 /* scratch of one compression (per thread): the hash table and a block's symbols */
 typedef struct {
@@ -336,25 +385,35 @@ int64_t sctfd_gzip_member(const uint8_t *in, int64_t n, uint8_t *out, void *scra
     for (int i = 0; i < FD_HASH_SIZE; i++) S->head[i] = -FD_WINDOW - 1;
     fd_freqs f;
     memset(&f, 0, sizeof(f));
+    uint32_t lit2[2][256];   /* literal counts by the parity of the symbol's index: neighbours never wait for each other's increment */
+    memset(lit2, 0, sizeof(lit2));
     int ns = 0;
     int64_t i = 0, block_start = 0;
     const int64_t last_hash = n - 8;   /* positions from which 8 bytes can be loaded */
     while (i < n) {
         if (ns >= FD_BLOCK_SYMS - 1) {
+            for (int c = 0; c < 256; c++) f.lit[c] = lit2[0][c] + lit2[1][c];
             fd_write_block(&w, S->sym, ns, &f, in + block_start, i - block_start, 0);
             memset(&f, 0, sizeof(f));
+            memset(lit2, 0, sizeof(lit2));
             ns = 0;
             block_start = i;
         }
         if (i <= last_hash) {
-            const uint32_t v = fd_load32(in + i);
-            const uint32_t h = fd_hash(v);
+            const uint64_t v8 = fd_load64(in + i);
+            const uint32_t h = fd_hash64(v8);
             const int64_t cand = S->head[h];
             S->head[h] = (int32_t)i;
-            if (i - cand <= FD_WINDOW && fd_load32(in + cand) == v) {
+            uint64_t x0;
+            if (i - cand <= FD_WINDOW && (((x0 = fd_load64(in + cand) ^ v8) << (64 - 8 * FD_HASH_BYTES)) == 0)) {
                 /* extend, eight bytes at a time */
-                int64_t len = FD_MIN_MATCH;
+                int64_t len;
                 const int64_t max = n - i < FD_MAX_MATCH ? n - i : FD_MAX_MATCH;
+                if (x0) {
+                    len = __builtin_ctzll(x0) >> 3;
+                    goto matched;
+                }
+                len = 8;
                 while (len + 8 <= max) {
                     const uint64_t x = fd_load64(in + i + len) ^ fd_load64(in + cand + len);
                     if (x) {
@@ -365,25 +424,26 @@ int64_t sctfd_gzip_member(const uint8_t *in, int64_t n, uint8_t *out, void *scra
                 }
                 while (len < max && in[i + len] == in[cand + len]) len++;
             matched:
-                if (len < FD_MIN_ACCEPT) goto literal;
+                if (len < FD_MIN_ACCEPT || !fd_worth(v8, len, i - cand)) goto literal;
                 S->sym[ns++] = 0x80000000u | ((uint32_t)(len - 3) << 15) | (uint32_t)(i - cand - 1);
                 f.lit[257 + fd_len_code[len - 3]]++;
                 f.dist[fd_dcode((uint32_t)(i - cand - 1))]++;
                 /* a few positions of the match go into the table too (the ends: where the next match is likeliest to start) */
                 if (i + len <= last_hash) {
-                    S->head[fd_hash(fd_load32(in + i + 1))] = (int32_t)(i + 1);
-                    S->head[fd_hash(fd_load32(in + i + len - 2))] = (int32_t)(i + len - 2);
-                    S->head[fd_hash(fd_load32(in + i + len - 1))] = (int32_t)(i + len - 1);
+                    S->head[fd_hash64(fd_load64(in + i + 1))] = (int32_t)(i + 1);
+                    S->head[fd_hash64(fd_load64(in + i + len - 2))] = (int32_t)(i + len - 2);
+                    S->head[fd_hash64(fd_load64(in + i + len - 1))] = (int32_t)(i + len - 1);
                 }
                 i += len;
                 continue;
             }
         }
     literal:
+        lit2[ns & 1][in[i]]++;
         S->sym[ns++] = in[i];
-        f.lit[in[i]]++;
         i++;
     }
+    for (int c = 0; c < 256; c++) f.lit[c] = lit2[0][c] + lit2[1][c];
     fd_write_block(&w, S->sym, ns, &f, in + block_start, n - block_start, 1);
     fd_flush_bytes(&w);
     const uint32_t crc = sctio_crc32(0, in, n), isize = (uint32_t)n;

@@ -12,6 +12,9 @@
  */
 #include <stdint.h>
 #include <string.h>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 
 /* Number of lines (a last line without '\n' counts). */
 int64_t sctio_count_lines(const uint8_t *buf, int64_t len) {
@@ -219,16 +222,45 @@ void sctio_parse_block(const uint8_t *buf, int64_t len, int32_t final, int64_t m
     info[3] = -1;
     info[4] = 0;
     for (; i < max_rows && p < len; i++) {
-        const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', (size_t)(len - p));
-        if (!nl && !final) break;
-        const int64_t q = nl ? (int64_t)(nl - buf) : len;
         int64_t tab[4] = {-1, -1, -1, -1};
         int nt = 0;
         uint8_t hi = 0;
-        for (int64_t k = p; k < q; k++) {
-            const uint8_t c = buf[k];
-            hi |= (uint8_t)(c & 0x80) | (uint8_t)(c == '\r' ? 0x80 : 0);
-            if (c == '\t' && nt < 4) tab[nt++] = k;
+        int64_t q = -1, k = p;
+#if defined(__x86_64__)
+        /* sixteen bytes at a time: where the tabs and the line end are, and whether a byte needs the text-mode reader (>= 128, '\r');
+         * a row of the usual shape is three loads instead of forty turns of the byte loop below (2.9 of the command's 27 CPU-seconds
+         * per 10^8 rows were spent there) */
+        {
+            const __m128i vt = _mm_set1_epi8('\t'), vn = _mm_set1_epi8('\n'), vr = _mm_set1_epi8('\r');
+            while (k + 16 <= len) {
+                const __m128i c = _mm_loadu_si128((const __m128i *)(buf + k));
+                uint32_t mt = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(c, vt));
+                const uint32_t mn = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(c, vn));
+                uint32_t mb = (uint32_t)_mm_movemask_epi8(_mm_or_si128(c, _mm_cmpeq_epi8(c, vr)));   /* (bit 7 of a byte = its movemask bit) */
+                const uint32_t below = mn ? ((mn & (0u - mn)) - 1u) : 0xFFFFu;   /* the bytes in front of the first line end */
+                mt &= below;
+                mb &= below;
+                if (mb) hi = 0x80;
+                while (mt && nt < 4) {
+                    tab[nt++] = k + __builtin_ctz(mt);
+                    mt &= mt - 1;
+                }
+                if (mn) {
+                    q = k + __builtin_ctz(mn);
+                    break;
+                }
+                k += 16;
+            }
+        }
+#endif
+        if (q < 0) {   /* the last bytes of the buffer (or no SSE2): byte by byte */
+            for (; k < len && buf[k] != '\n'; k++) {
+                const uint8_t c = buf[k];
+                hi |= (uint8_t)(c & 0x80) | (uint8_t)(c == '\r' ? 0x80 : 0);
+                if (c == '\t' && nt < 4) tab[nt++] = k;
+            }
+            if (k >= len && !final) break;   /* an unfinished line: the caller brings it again with the next block */
+            q = k;
         }
         if (hi) info[4] = 1;
         if (nt < 3) {
@@ -255,14 +287,17 @@ void sctio_parse_block(const uint8_t *buf, int64_t len, int32_t final, int64_t m
 /*
  * sctio_render for a block whose hits come as per-row COUNTS (uint8 if cnt_bytes == 1, else uint32) and int32 segment offsets:
  * the hit list of row r starts where the counts of the rows before it end; the hits are uint16 or uint32 entries.  With
- * out == NULL only the size is returned.
+ * out == NULL only the size is returned.  out_cap = the bytes `out` can take: the exact size will do; with 64 bytes more every row
+ * can be written with copies of fixed size (a name or a barcode as 16 bytes, a segment as 32, whatever their length: the next field
+ * overwrites the surplus) — 10^8 rows are 5 x 10^8 calls of memcpy otherwise.
  */
 int64_t sctio_render_block(const uint8_t *namebuf, const int64_t *name_start, const int64_t *name_end, const uint8_t *segs,
                            const int32_t *offs, const uint8_t *min_e, const void *cnt, int32_t cnt_bytes, const void *hits,
                            int32_t hit_bytes /* 2 = uint16 entries, else uint32 */, const uint8_t *pattern_text, int32_t bl, int64_t n,
-                           uint8_t *out) {
+                           uint8_t *out, int64_t out_cap) {
     int64_t size = 0, pos = 0;
     uint8_t *o = out;
+    const int64_t seg_total = n > 0 ? (int64_t)offs[n] : 0;
     for (int64_t r = 0; r < n; r++) {
         const int64_t c = cnt_bytes == 1 ? (int64_t)((const uint8_t *)cnt)[r] : (int64_t)((const uint32_t *)cnt)[r];
         if (min_e[r] == 0xFF) {
@@ -272,6 +307,40 @@ int64_t sctio_render_block(const uint8_t *namebuf, const int64_t *name_start, co
         const int64_t ln = name_end[r] - name_start[r], ls = (int64_t)offs[r + 1] - offs[r];
         if (!out) {
             size += ln + ndigits(min_e[r]) + ndigits((uint64_t)c) + ls + c * bl + (c > 0 ? c - 1 : 0) + 5;
+            pos += c;
+            continue;
+        }
+        /* the fast form: the usual shape of a row, and room for its surplus.  (A name is followed in its line by three more fields
+         * and the segment: ln + 3 + ls bytes can be read from its start; a segment by the other segments up to seg_total.) */
+        if (bl == 16 && ln <= 16 && ls <= 32 && ln + 3 + ls >= 16 && (int64_t)offs[r] + 32 <= seg_total &&
+            (o - out) + 16 + 8 + 24 + 32 + 1 + c * 17 + 16 <= out_cap) {
+            memcpy(o, namebuf + name_start[r], 16);
+            o += ln;
+            *o++ = '\t';
+            o = put_num(o, min_e[r]);
+            *o++ = '\t';
+            o = put_num(o, (uint64_t)c);
+            *o++ = '\t';
+            memcpy(o, segs + offs[r], 32);
+            o += ls;
+            *o++ = '\t';
+            if (hit_bytes == 2) {
+                const uint16_t *h = (const uint16_t *)hits + pos;
+                for (int64_t k = 0; k < c; k++) {
+                    memcpy(o, pattern_text + (int64_t)h[k] * 16, 16);
+                    o[16] = ',';
+                    o += 17;
+                }
+            } else {
+                const uint32_t *h = (const uint32_t *)hits + pos;
+                for (int64_t k = 0; k < c; k++) {
+                    memcpy(o, pattern_text + (int64_t)h[k] * 16, 16);
+                    o[16] = ',';
+                    o += 17;
+                }
+            }
+            if (c > 0) o--;   /* the last comma becomes the line end */
+            *o++ = '\n';
             pos += c;
             continue;
         }

@@ -55,9 +55,7 @@ static void crc_init(void) {
     for (uint32_t i = 0; i < 256; i++)
         for (int t = 1; t < 8; t++) crc_tab[t][i] = (crc_tab[t - 1][i] >> 8) ^ crc_tab[0][crc_tab[t - 1][i] & 0xFF];
 }
-uint32_t sctio_crc32(uint32_t crc, const uint8_t *p, int64_t n) {
-    pthread_once(&crc_once, crc_init);
-    uint32_t c = ~crc;
+static uint32_t crc_tables(uint32_t c, const uint8_t *p, int64_t n) {   /* c = the running (inverted) state */
     while (n > 0 && ((uintptr_t)p & 7)) {
         c = (c >> 8) ^ crc_tab[0][(c ^ *p++) & 0xFF];
         n--;
@@ -72,7 +70,83 @@ uint32_t sctio_crc32(uint32_t crc, const uint8_t *p, int64_t n) {
         n -= 8;
     }
     while (n-- > 0) c = (c >> 8) ^ crc_tab[0][(c ^ *p++) & 0xFF];
-    return ~c;
+    return c;
+}
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+/* Folding with carry-less multiplications (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ", Intel 2009):
+ * four 128-bit accumulators are each multiplied by x^512 mod P (k1, k2: the two 64-bit halves) and added to the next 64 bytes; the
+ * four are then folded into one (x^128: k3, k4), that into 64 bits (k5) and reduced to 32 by Barrett's method (P and its inverse).
+ * Bit-reflected constants for the gzip polynomial.  n >= 64 and a multiple of 16; the command sums 3.8 + 3.0 GB per 10^8 rows (the
+ * decoded input, the members of its output): 1.9 GB/s with the tables, 4 of its 31 CPU-seconds. */
+__attribute__((target("pclmul,sse4.1"))) static uint32_t crc_fold(uint32_t c, const uint8_t *p, int64_t n) {
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll), k3k4 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll);
+    const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124ll), poly = _mm_set_epi64x(0x01f7011641ll, 0x01db710641ll);
+    __m128i x1 = _mm_loadu_si128((const __m128i *)(p + 0)), x2 = _mm_loadu_si128((const __m128i *)(p + 16));
+    __m128i x3 = _mm_loadu_si128((const __m128i *)(p + 32)), x4 = _mm_loadu_si128((const __m128i *)(p + 48));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)c));
+    p += 64;
+    n -= 64;
+    while (n >= 64) {
+        const __m128i a1 = _mm_clmulepi64_si128(x1, k1k2, 0x00), a2 = _mm_clmulepi64_si128(x2, k1k2, 0x00);
+        const __m128i a3 = _mm_clmulepi64_si128(x3, k1k2, 0x00), a4 = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, k1k2, 0x11);
+        x2 = _mm_clmulepi64_si128(x2, k1k2, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, k1k2, 0x11);
+        x4 = _mm_clmulepi64_si128(x4, k1k2, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, a1), _mm_loadu_si128((const __m128i *)(p + 0)));
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, a2), _mm_loadu_si128((const __m128i *)(p + 16)));
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, a3), _mm_loadu_si128((const __m128i *)(p + 32)));
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, a4), _mm_loadu_si128((const __m128i *)(p + 48)));
+        p += 64;
+        n -= 64;
+    }
+    __m128i a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+    x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), a), x2);
+    a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+    x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), a), x3);
+    a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+    x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), a), x4);
+    while (n >= 16) {
+        a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+        x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), a), _mm_loadu_si128((const __m128i *)p));
+        p += 16;
+        n -= 16;
+    }
+    const __m128i lo32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x2 = _mm_clmulepi64_si128(x1, k3k4, 0x10);          /* 128 -> 96 bits */
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), x2);
+    x2 = _mm_srli_si128(x1, 4);                         /* -> 64 */
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, lo32), k5, 0x00), x2);
+    x2 = _mm_clmulepi64_si128(_mm_and_si128(x1, lo32), poly, 0x10);   /* Barrett */
+    x2 = _mm_clmulepi64_si128(_mm_and_si128(x2, lo32), poly, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+static int crc_can_fold = -1;
+#endif
+
+uint32_t sctio_crc32(uint32_t crc, const uint8_t *p, int64_t n) {
+    pthread_once(&crc_once, crc_init);
+    uint32_t c = ~crc;
+#if defined(__x86_64__)
+    if (n >= 256) {
+        if (crc_can_fold < 0) crc_can_fold = (__builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1")) ? 1 : 0;
+        if (crc_can_fold) {
+            const int64_t m = n & ~(int64_t)15;
+            c = crc_fold(c, p, m);
+            p += m;
+            n -= m;
+        }
+    }
+#endif
+    return ~crc_tables(c, p, n);
+}
+/* the table version alone (tests compare the two) */
+uint32_t sctio_crc32_tables(uint32_t crc, const uint8_t *p, int64_t n) {
+    pthread_once(&crc_once, crc_init);
+    return ~crc_tables(~crc, p, n);
 }
 /* GF(2) 32 x 32 matrices as 32 words: mat[i] = image of bit i */
 static uint32_t gf2_times(const uint32_t *mat, uint32_t vec) {
@@ -504,15 +578,40 @@ static int resolve_item(item_t *it) {
     uint8_t *o = buf + SCTIO_PIECE_HEAD;
     const uint16_t *v = it->sym.v;
     const uint8_t *w = it->win;
-    uint32_t lowest = WINDOW;
-    for (int64_t i = 0; i < it->n; i++) {
-        const uint16_t x = v[i];
-        if (x & MARK) {
-            const uint32_t k = x & (MARK - 1);
-            if (k < lowest) lowest = k;
-            o[i] = w[k];
-        } else o[i] = (uint8_t)x;
+    /* Two thirds of the symbols of a -lr file are markers (every row copies its first columns from the row before, and so on back
+     * to the unknown window), in runs the branch predictor cannot follow: with a branch per symbol this pass cost as much as decoding
+     * the bytes directly does.  Without one: the window byte is always loaded (a literal's low bits index it harmlessly) and selected. */
+    const int64_t n = it->n;
+    int64_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const uint32_t x0 = v[i], x1 = v[i + 1], x2 = v[i + 2], x3 = v[i + 3];
+        const uint8_t w0 = w[x0 & (MARK - 1)], w1 = w[x1 & (MARK - 1)], w2 = w[x2 & (MARK - 1)], w3 = w[x3 & (MARK - 1)];
+        const uint32_t m0 = 0u - (x0 >> 15), m1 = 0u - (x1 >> 15), m2 = 0u - (x2 >> 15), m3 = 0u - (x3 >> 15);
+        o[i] = (uint8_t)((w0 & m0) | (x0 & ~m0));
+        o[i + 1] = (uint8_t)((w1 & m1) | (x1 & ~m1));
+        o[i + 2] = (uint8_t)((w2 & m2) | (x2 & ~m2));
+        o[i + 3] = (uint8_t)((w3 & m3) | (x3 & ~m3));
     }
+    for (; i < n; i++) {
+        const uint32_t x = v[i];
+        o[i] = (x & MARK) ? w[x & (MARK - 1)] : (uint8_t)x;
+    }
+    /* the marker that reaches back furthest: as signed 16-bit numbers the markers are the negative ones, the smallest the furthest */
+    int lowest16 = 0;
+    i = 0;
+#if defined(__x86_64__)
+    if (n >= 8) {
+        __m128i mn = _mm_setzero_si128();
+        for (; i + 8 <= n; i += 8) mn = _mm_min_epi16(mn, _mm_loadu_si128((const __m128i *)(v + i)));
+        int16_t t[8];
+        _mm_storeu_si128((__m128i *)t, mn);
+        for (int k = 0; k < 8; k++)
+            if (t[k] < lowest16) lowest16 = t[k];
+    }
+#endif
+    for (; i < n; i++)
+        if ((int16_t)v[i] < lowest16) lowest16 = (int16_t)v[i];
+    const uint32_t lowest = lowest16 < 0 ? (uint32_t)(lowest16 & (MARK - 1)) : WINDOW;
     it->buf = buf;
     it->crc = sctio_crc32(0, o, it->n);
     free(it->win);

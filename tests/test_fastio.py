@@ -176,10 +176,15 @@ def test_block_parser_and_renderer_reproduce_reference_bytes(name, e, t):
             hits = np.ascontiguousarray(hits, dtype=np.uint16 if hbytes == 2 else np.uint32)
             args = [base + at, ns.ctypes.data, ne.ctypes.data, segs.ctypes.data, offs.ctypes.data, me.ctypes.data, cnt.ctypes.data, cbytes,
                     hits.ctypes.data if hits.size else None, hbytes, table.ctypes.data, bl, n]
-            size = lib.sctio_render_block(*args, None)
-            o = np.empty(size, np.uint8)
-            assert lib.sctio_render_block(*args, o.ctypes.data) == size
-            out.append(o.tobytes())
+            size = lib.sctio_render_block(*args, None, 0)
+            for slack in (0, 64):           # exactly sized (the last rows byte by byte) and with room for fixed-size copies throughout
+                o = np.full(size + slack + 32, 0xEE, np.uint8)
+                assert lib.sctio_render_block(*args, o.ctypes.data, size + slack) == size
+                assert (o[size + slack:] == 0xEE).all(), "wrote past the room it was given"
+                if slack:
+                    assert o[:size].tobytes() == out[-1]
+                else:
+                    out.append(o[:size].tobytes())
             at += used
         assert b"".join(out) == want
     # a line with fewer than four fields, a non-ASCII byte and a carriage return are reported, not parsed
@@ -187,6 +192,67 @@ def test_block_parser_and_renderer_reproduce_reference_bytes(name, e, t):
         lib.sctio_parse_block(ctypes.cast(ctypes.c_char_p(bad), ctypes.c_void_p).value, len(bad), 1, 7, 64, ns.ctypes.data, ne.ctypes.data,
                               segs.ctypes.data, offs.ctypes.data, lens.ctypes.data, info.ctypes.data)
         assert (info[3] == 1) if slot == 3 else (info[4] == 1)
+
+
+def test_block_parser_line_scanner_against_python():
+    """sctio_parse_block's 16-bytes-at-a-time line scanner against a plain Python parse: lines of every length around the 16-byte
+    steps, empty fields, more than four fields, bytes >= 128 and carriage returns at every offset, unfinished last lines with and
+    without `final`, row and segment-byte limits."""
+    import ctypes
+    import random
+    from sctagger_amd import streamcli
+    lib = streamcli._iolib()
+    rng = random.Random(5)
+
+    def field(n, alphabet=b"ACGTN0123456789r_"):
+        return bytes(rng.choice(alphabet) for _ in range(n))
+    for trial in range(400):
+        lines = []
+        for _ in range(rng.randrange(1, 12)):
+            nf = rng.choice((4, 4, 4, 4, 5, 6, 3, 2, 1)) if trial % 5 == 0 else rng.choice((4, 4, 4, 5))
+            fs = [field(rng.choice((0, 1, 5, 10, 15, 16, 17, 22, 31, 32, 33, 60, 300))) for _ in range(nf)]
+            lines.append(b"\t".join(fs))
+        buf = b"\n".join(lines) + (b"\n" if rng.random() < 0.7 else b"")
+        if trial % 3 == 0 and buf:
+            k = rng.randrange(len(buf))
+            buf = buf[:k] + rng.choice((b"\r", b"\x80", b"\xff")) + buf[k + 1:]
+        final = rng.randrange(2)
+        max_rows, seg_cap = rng.choice((1, 3, 100)), rng.choice((40, 100000))
+        # the plain parse
+        want_rows, p, first_short, odd, out_bytes, used = [], 0, -1, 0, 0, 0
+        i = 0
+        while i < max_rows and p < len(buf):
+            q = buf.find(b"\n", p)
+            if q < 0:
+                if not final:
+                    break
+                q = len(buf)
+            line = buf[p:q]
+            fs = line.split(b"\t")
+            if any(c >= 128 or c == 13 for c in line):
+                odd = 1
+            if len(fs) < 4:
+                first_short = i
+                break
+            if out_bytes + len(fs[3]) > seg_cap:
+                break
+            want_rows.append((fs[0], fs[3]))
+            out_bytes += len(fs[3])
+            p = q + 1
+            i += 1
+        used = min(p, len(buf))
+        ns, ne = np.empty(max_rows, np.int64), np.empty(max_rows, np.int64)
+        segs, offs, lens, info = np.empty(seg_cap + 1, np.uint8), np.empty(max_rows + 1, np.int32), np.empty(max_rows, np.uint8), np.zeros(8, np.int64)
+        holder = np.frombuffer(buf, dtype=np.uint8).copy() if buf else np.empty(1, np.uint8)   # (exactly sized: the scanner must not need bytes behind it)
+        lib.sctio_parse_block(holder.ctypes.data, len(buf), final, max_rows, seg_cap, ns.ctypes.data, ne.ctypes.data, segs.ctypes.data,
+                              offs.ctypes.data, lens.ctypes.data, info.ctypes.data)
+        n = int(info[0])
+        assert n == len(want_rows), (trial, buf)
+        assert int(info[3]) == first_short and int(info[4]) == odd, (trial, buf, info[:5])
+        if first_short < 0:
+            assert int(info[1]) == used, (trial, buf)
+        for r, (name, seg) in enumerate(want_rows):
+            assert buf[ns[r]:ne[r]] == name and segs[offs[r]:offs[r + 1]].tobytes() == seg and lens[r] == min(len(seg), 255)
 
 
 # ---- the fast DEFLATE compressor of the streaming command's output (csrc/sct_fdeflate.c) ---------------------------------------

@@ -252,3 +252,26 @@ def test_gzip_container_through_the_parallel_decoder(tmp_path, monkeypatch):
     p.write_bytes(bytes(bad))
     with pytest.raises(gzip.BadGzipFile):
         read(p)
+
+
+def test_crc32_by_folding_equals_zlib():
+    """sctio_crc32 (carry-less multiplications where the CPU has them, csrc/sct_pinflate.c) against zlib's and against the table
+    version, at every length around the 16- and 64-byte steps of the folding loop, odd addresses, running values carried over."""
+    import ctypes
+    lib = streamcli._iolib()
+    lib.sctio_crc32_tables.argtypes = lib.sctio_crc32.argtypes
+    lib.sctio_crc32_tables.restype = ctypes.c_uint32
+    rng = np.random.default_rng(77)
+    buf = rng.integers(0, 256, size=70_000, dtype=np.uint8)
+    lengths = list(range(0, 700)) + [4095, 4096, 4097, 65535, 65536, 69_000]
+    for k, n in enumerate(lengths):
+        off = k % 17
+        init = 0 if k % 3 == 0 else int(rng.integers(0, 1 << 32))
+        want = zlib.crc32(buf[off:off + n].tobytes(), init)
+        assert lib.sctio_crc32(init, buf[off:].ctypes.data, n) == want, (n, off)
+        assert lib.sctio_crc32_tables(init, buf[off:].ctypes.data, n) == want, (n, off)
+    # in pieces, and combined
+    a, b = buf[:33_333], buf[33_333:]
+    ca, cb = lib.sctio_crc32(0, a.ctypes.data, a.size), lib.sctio_crc32(0, b.ctypes.data, b.size)
+    assert lib.sctio_crc32(ca, b.ctypes.data, b.size) == zlib.crc32(buf.tobytes())
+    assert lib.sctio_crc32_combine(ca, cb, b.size) == zlib.crc32(buf.tobytes())

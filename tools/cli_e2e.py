@@ -93,6 +93,10 @@ def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_
     out = os.path.join(work, "out.tsv.gz")
     walls = []
     for _ in range(runs):          # the second run has the input file and the libraries in the page cache
+        try:
+            os.remove(out)         # (a fresh output file, as in a first run)
+        except OSError:
+            pass
         t0 = time.time()
         subprocess.check_call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", lr, "-sr", sr, "-mr", "2", "-t", "16", "-o", out] + list(extra),
                               stderr=open(os.path.join(work, "cli.err"), "w"), env=dict(os.environ, SCT_CLI_TIMING="1"))

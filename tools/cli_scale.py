@@ -41,6 +41,11 @@ for n in sizes:
         e.update(env, SCT_CLI_TIMING="1")
         walls, cpu = [], []
         for _ in range(2):
+            for stale in (out, os.path.join(work, "out.tsv")):     # a fresh output file, as in a first run (renaming over last run's
+                try:                                               # 1.1 GB file costs 0.2 s of freeing it inside the rename)
+                    os.remove(stale)
+                except OSError:
+                    pass
             r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
             t0 = time.time()
             rc = subprocess.call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", files[level][0], "-sr", sr, "-mr", "2", "-t", "16"] + (extra if "-o" in extra else ["-o", out] + extra),
@@ -51,7 +56,7 @@ for n in sizes:
             if rc != 0:
                 break
         timing = [l.strip() for l in open(os.path.join(work, "cli.err")) if "timing" in l]
-        if rows_out is None and rc == 0:        # once per size: every row came out (counted in pieces)
+        if rows_out is None and rc == 0 and "-o" not in extra:        # once per size: every row came out (counted in pieces)
             rows_out = 0
             with gzip.open(out, "rb") as f:
                 while True:
@@ -60,7 +65,7 @@ for n in sizes:
                         break
                     rows_out += piece.count(b"\n")
         print(json.dumps({"rows": n, "in_gzip_level": level, "in_gz_MB": round(files[level][2] / 1e6, 1), "env": env, "extra": extra, "rc": rc, "wall_s": walls, "cpu_user_sys_s": cpu,
-                          "segments_per_s": n / min(walls), "out_gz_MB": round(os.path.getsize(out) / 1e6, 1) if rc == 0 else None, "rows_out": rows_out,
+                          "segments_per_s": n / min(walls), "out_MB": round(os.path.getsize(extra[extra.index("-o") + 1] if "-o" in extra else out) / 1e6, 1) if rc == 0 else None, "rows_out": rows_out,
                           "timing": timing[-3:]}), flush=True)
     for l in files:
         os.remove(files[l][0])
