@@ -31,6 +31,42 @@ def _keep_freed_memory():
         pass
 
 
+def _relaunch_with_huge_pages():
+    """Large inputs (match_trie, an -lr file of 200 MB or more): run the command in a child process whose allocator asks for
+    transparent huge pages (GLIBC_TUNABLES=glibc.malloc.hugetlb=1 — glibc reads its tunables at process start only, and offers no
+    call that does the same later).  The command touches 4 GB of heap per 10^8 rows: a million page faults, and a TLB entry per 4 KB
+    for the decoders' and the compressor's windows; with huge pages 10^8 rows take 1.75 instead of 2.07 s on the GPU box (10^7 rows:
+    no difference, so small inputs are not relaunched — the second interpreter costs 0.02 s).  Nothing has touched the GPU yet: this
+    process only waits and passes the child's exit status on."""
+    import sys
+    if "glibc.malloc.hugetlb" in os.environ.get("GLIBC_TUNABLES", "") or os.environ.get("SCT_NO_RELAUNCH") or "match_trie" not in sys.argv[1:2]:
+        return
+    try:
+        at = [i for i, a in enumerate(sys.argv) if a in ("-lr", "--long-read-segments")][-1]
+        if os.path.getsize(sys.argv[at + 1]) < int(os.environ.get("SCT_RELAUNCH_MIN_BYTES", 200 << 20)):
+            return
+    except (IndexError, OSError, ValueError):
+        return
+    import signal
+    env = dict(os.environ)
+    env["GLIBC_TUNABLES"] = ":".join(x for x in (env.get("GLIBC_TUNABLES"), "glibc.malloc.hugetlb=1") if x)
+    if os.environ.get("SCT_CLI_TIMING"):
+        sys.stderr.write("cli timing: relaunching with GLIBC_TUNABLES=%s\n" % env["GLIBC_TUNABLES"])
+        sys.stderr.flush()
+    pid = os.posix_spawn(sys.executable, [sys.executable] + sys.argv, env)
+    for sig in (signal.SIGINT, signal.SIGTERM, signal.SIGHUP):
+        signal.signal(sig, lambda s, frame: os.kill(pid, s))
+    while True:
+        try:
+            _, status = os.waitpid(pid, 0)
+            break
+        except InterruptedError:
+            continue
+    code = os.waitstatus_to_exitcode(status)
+    os._exit(code if code >= 0 else 128 - code)
+
+
+_relaunch_with_huge_pages()
 _keep_freed_memory()
 threading.Thread(target=_wake_the_device, daemon=True).start()
 

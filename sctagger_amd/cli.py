@@ -100,6 +100,15 @@ def main(argv=None):
     finally:
         if timing:
             sys.stderr.write("cli timing: sub-command returned %.3f s after process start\n" % since_process_start())
+            if os.environ.get("SCT_CLI_TIMING") == "2":      # where the memory is: the kernel's view and the allocator's
+                try:
+                    with open("/proc/self/status") as f:
+                        sys.stderr.write("cli memory: " + " ".join(l.strip().replace("\t", "") for l in f if l.startswith(("VmHWM", "VmRSS", "RssAnon", "RssFile", "RssShmem"))) + "\n")
+                    import ctypes
+                    sys.stderr.flush()
+                    ctypes.CDLL(None).malloc_stats()
+                except Exception:
+                    pass
 
 
 def _dispatch(args):

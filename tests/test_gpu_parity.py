@@ -670,6 +670,27 @@ def test_resident_three_step_api(m):
     assert "k_filter" in names and all(ms >= 0 for _, ms in m.last_timing())
 
 
+def test_cli_relaunch_for_large_inputs(tmp_path):
+    """-lr files of 200 MB or more run in a child process with GLIBC_TUNABLES=glibc.malloc.hugetlb=1 (scTagger.py,
+    _relaunch_with_huge_pages); forced on a golden case here: same bytes out, the child's exit status passed on, and no second
+    relaunch from inside the child."""
+    g = util.GOLDEN
+    env = dict(os.environ, SCT_RELAUNCH_MIN_BYTES="1", SCT_CLI_TIMING="1")
+    env.pop("GLIBC_TUNABLES", None)
+    o = tmp_path / "o.tsv.gz"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", os.path.join(g, "g3.lr.tsv"), "-sr", os.path.join(g, "g3.sr.tsv"),
+                        "-mr", "2", "-t", "16", "-o", str(o)], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count(b"cli timing: relaunching with GLIBC_TUNABLES=glibc.malloc.hugetlb=1") == 1
+    with open(os.path.join(g, "g3.e2.t16.expected.tsv"), "rb") as f:
+        assert gzip.open(o, "rb").read() == f.read()
+    bad = tmp_path / "bad.tsv"
+    bad.write_bytes(b"r0\t1\t2\tACGTACGTACGTACGTAC\nr1\t1\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", str(bad), "-sr", os.path.join(g, "g1.sr.tsv"),
+                        "-o", str(tmp_path / "bad.out.tsv")], capture_output=True, env=env)
+    assert r.returncode == 1 and b"IndexError" in r.stderr and not (tmp_path / "bad.out.tsv").exists()
+
+
 def test_cli_end_to_end(tmp_path):
     """`scTagger.py match_trie ...` writes the reference's bytes (gz and plain), with the reference's flags."""
     g = util.GOLDEN

@@ -109,3 +109,25 @@ def test_plots(tmp_path):
     plots.plot_match_trie(np.array([0, 0, 1, 2, 255, 1], dtype=np.uint8), str(a))
     plots.plot_extract_lr_bc(np.array([0, 0, 1, -1, 3, 7], dtype=np.int32), str(b))
     assert a.stat().st_size > 1000 and b.stat().st_size > 1000
+
+
+def test_cli_relaunch_mechanics(tmp_path):
+    """scTagger.py runs match_trie on a large -lr file in a child process with GLIBC_TUNABLES=glibc.malloc.hugetlb=1 and passes its
+    exit status on (here: whatever the child ends with — without a GPU it fails loudly, with one it succeeds); small inputs and
+    processes that already carry the tunable are not relaunched."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lr, sr = tmp_path / "lr.tsv", tmp_path / "sr.tsv"
+    lr.write_bytes(b"r0\t1\t2\tACGTACGTACGTACGTAC\n")
+    sr.write_bytes(b"ACGTACGTACGTACGT\t3\n")
+    cmd = [sys.executable, os.path.join(root, "scTagger.py"), "match_trie", "-lr", str(lr), "-sr", str(sr), "-o", str(tmp_path / "o.tsv")]
+    env = dict(os.environ, SCT_CLI_TIMING="1")
+    env.pop("GLIBC_TUNABLES", None)
+    note = b"cli timing: relaunching with GLIBC_TUNABLES=glibc.malloc.hugetlb=1"
+    small = subprocess.run(cmd, capture_output=True, env=env)
+    forced = subprocess.run(cmd, capture_output=True, env=dict(env, SCT_RELAUNCH_MIN_BYTES="1"))
+    already = subprocess.run(cmd, capture_output=True, env=dict(env, SCT_RELAUNCH_MIN_BYTES="1", GLIBC_TUNABLES="glibc.malloc.hugetlb=1"))
+    assert note not in small.stderr and note not in already.stderr and forced.stderr.count(note) == 1
+    assert forced.returncode == small.returncode == already.returncode
+    assert (b"no CPU fallback" in forced.stderr) == (forced.returncode != 0)

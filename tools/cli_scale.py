@@ -34,6 +34,9 @@ for n in sizes:
                 (9, {}, ["--gzip-level", "1"]), (1, {}, []), (9, {}, ["--devices", "0", "0"]), (9, {}, ["-o", os.path.join(work, "out.tsv")])]
     if quick:
         variants = variants[:4]
+    if "--thp" in sys.argv:      # malloc'ed memory in transparent huge pages (fewer faults on first touch, fewer pages to free at exit)
+        T = {"GLIBC_TUNABLES": "glibc.malloc.hugetlb=1"}
+        variants = [(9, {}, []), (9, T, []), (9, {"SCT_INFLATE_THREADS": "12"}, []), (9, dict(T, SCT_INFLATE_THREADS="12"), [])]
     out = os.path.join(work, "out.tsv.gz")
     rows_out = None
     for level, env, extra in variants:
@@ -53,6 +56,7 @@ for n in sizes:
             walls.append(round(time.time() - t0, 3))
             r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
             cpu.append([round(r1.ru_utime - r0.ru_utime, 2), round(r1.ru_stime - r0.ru_stime, 2)])
+            maxrss_MB = round(r1.ru_maxrss / 1024)      # (largest child so far)
             if rc != 0:
                 break
         timing = [l.strip() for l in open(os.path.join(work, "cli.err")) if "timing" in l]
@@ -64,7 +68,7 @@ for n in sizes:
                     if not piece:
                         break
                     rows_out += piece.count(b"\n")
-        print(json.dumps({"rows": n, "in_gzip_level": level, "in_gz_MB": round(files[level][2] / 1e6, 1), "env": env, "extra": extra, "rc": rc, "wall_s": walls, "cpu_user_sys_s": cpu,
+        print(json.dumps({"rows": n, "in_gzip_level": level, "in_gz_MB": round(files[level][2] / 1e6, 1), "env": env, "extra": extra, "rc": rc, "wall_s": walls, "cpu_user_sys_s": cpu, "maxrss_MB_so_far": maxrss_MB,
                           "segments_per_s": n / min(walls), "out_MB": round(os.path.getsize(extra[extra.index("-o") + 1] if "-o" in extra else out) / 1e6, 1) if rc == 0 else None, "rows_out": rows_out,
                           "timing": timing[-3:]}), flush=True)
     for l in files:
