@@ -848,7 +848,9 @@ static void *worker(void *arg) {
             continue;
         }
         /* 3. pass 1 of the next chunk, not too far ahead of the chain */
-        if (!h->chain_done && h->next_p1 < h->n_chunks && h->next_p1 < h->chain_k + h->lookahead) {
+        /* (... nor of the consumer: the pieces nobody has fetched yet are whole buffers; without this bound a reader that waits for
+         * its own consumers let the decoders run through the file, 3.8 GB of pieces for 10^8 rows) */
+        if (!h->chain_done && h->next_p1 < h->n_chunks && h->next_p1 < h->chain_k + h->lookahead && h->n_items - h->cons < h->lookahead + 8) {
             const int k = h->next_p1++;
             h->chunks[k].state = C_RUNNING;
             symbuf b = {0, 0, 0};

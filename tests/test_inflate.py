@@ -275,3 +275,39 @@ def test_crc32_by_folding_equals_zlib():
     ca, cb = lib.sctio_crc32(0, a.ctypes.data, a.size), lib.sctio_crc32(0, b.ctypes.data, b.size)
     assert lib.sctio_crc32(ca, b.ctypes.data, b.size) == zlib.crc32(buf.tobytes())
     assert lib.sctio_crc32_combine(ca, cb, b.size) == zlib.crc32(buf.tobytes())
+
+
+def test_parallel_decoder_waits_for_its_consumer():
+    """Nobody fetching: the decoders stop a bounded number of pieces ahead (lookahead = 2 x threads + 2 chunks of pass 1 in front of
+    the chain, lookahead + 8 finished pieces in front of the consumer) instead of decoding the whole stream into memory; fetching
+    then gets every byte."""
+    import time
+    rng = random.Random(17)
+    data = ("\n".join("r%09d\t%d\t30\t%s" % (i, rng.randrange(4), "".join(rng.choice("ACGT") for _ in range(22))) for i in range(400000))).encode()
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw = c.compress(data) + c.flush()
+    lib = streamcli._iolib()
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    threads, chunk = 3, 20000
+    assert len(raw) // chunk > 150
+    h = lib.sctio_pinflate_new(buf.ctypes.data, len(raw), threads, chunk, 0, None, 0)
+    sp, rd = ctypes.c_int64(), ctypes.c_int64()
+    seen = -1
+    for _ in range(100):            # until the decoders have come to rest
+        time.sleep(0.05)
+        lib.sctio_pinflate_stats(h, ctypes.byref(sp), ctypes.byref(rd))
+        if sp.value + rd.value == seen:
+            break
+        seen = sp.value + rd.value
+    assert 0 < seen <= 2 * (2 * threads + 2) + 8 + 2, seen
+    head = lib.sctio_piece_head()
+    out = []
+    piece, cc, st, used = ctypes.c_void_p(), ctypes.c_uint32(), ctypes.c_int32(), ctypes.c_int64()
+    while True:
+        n = lib.sctio_pinflate_next(h, ctypes.byref(piece), ctypes.byref(cc), ctypes.byref(st), ctypes.byref(used))
+        if st.value != 0:
+            break
+        out.append(ctypes.string_at(piece.value + head, n))
+        lib.sctio_piece_free(piece)
+    lib.sctio_pinflate_free(h)
+    assert st.value == 1 and b"".join(out) == data

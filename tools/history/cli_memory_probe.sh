@@ -14,6 +14,6 @@ segs, offs = bench.make_batch($n, bc, 3)
 print(cli_e2e.write_lr_file("/tmp/sct_mem/lr.tsv.gz", segs, offs, level=9))
 PY
 for i in 1 2; do
-  SCT_CLI_TIMING=2 python scTagger.py match_trie -lr /tmp/sct_mem/lr.tsv.gz -sr /tmp/sct_mem/sr.tsv -mr 2 -t 16 -o /tmp/sct_mem/out.tsv.gz 2>&1 | grep -E "cli memory|cli timing|streamcli timing|match_trie timing|^Total|^system bytes|max mmap" | tail -n 20
+  SCT_CLI_TIMING=2 python scTagger.py match_trie -lr /tmp/sct_mem/lr.tsv.gz -sr /tmp/sct_mem/sr.tsv -mr 2 -t 16 -o /tmp/sct_mem/out.tsv.gz 2>&1 | grep -E "cli memory|cli timing: sub|streamcli timing|^Total|max mmap bytes" | cut -c1-260
   rm -f /tmp/sct_mem/out.tsv.gz
 done
