@@ -56,7 +56,6 @@ for n in sizes:
             walls.append(round(time.time() - t0, 3))
             r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
             cpu.append([round(r1.ru_utime - r0.ru_utime, 2), round(r1.ru_stime - r0.ru_stime, 2)])
-            maxrss_MB = round(r1.ru_maxrss / 1024)      # (largest child so far)
             if rc != 0:
                 break
         timing = [l.strip() for l in open(os.path.join(work, "cli.err")) if "timing" in l]
@@ -68,7 +67,7 @@ for n in sizes:
                     if not piece:
                         break
                     rows_out += piece.count(b"\n")
-        print(json.dumps({"rows": n, "in_gzip_level": level, "in_gz_MB": round(files[level][2] / 1e6, 1), "env": env, "extra": extra, "rc": rc, "wall_s": walls, "cpu_user_sys_s": cpu, "maxrss_MB_so_far": maxrss_MB,
+        print(json.dumps({"rows": n, "in_gzip_level": level, "in_gz_MB": round(files[level][2] / 1e6, 1), "env": env, "extra": extra, "rc": rc, "wall_s": walls, "cpu_user_sys_s": cpu,
                           "segments_per_s": n / min(walls), "out_MB": round(os.path.getsize(extra[extra.index("-o") + 1] if "-o" in extra else out) / 1e6, 1) if rc == 0 else None, "rows_out": rows_out,
                           "timing": timing[-3:]}), flush=True)
     for l in files:
