@@ -207,8 +207,14 @@ def _inflate_regions(path, piece_bytes):
     of the piece before.  CRC-32 and length of every member are checked, the CRC on a thread of its own; a file the decoder does
     not take from its first byte on is read through zlib instead."""
     import gzip
+    import mmap
     with open(path, "rb") as f:
-        data = f.read()
+        # mapped, not read: the decoders' threads fault the pages in as they get to them (reading 1 GB first was 0.15 s of the
+        # 1.7 s the 10^8-row command takes, with every other stage waiting for the first block)
+        try:
+            data = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        except (ValueError, OSError):           # an empty file, or one that cannot be mapped
+            data = f.read()
     at = _gzip_header_end(data, 0)
     if at is None:                                # not a plain gzip member at offset 0: let zlib judge
         # bounded output per call (a small input can expand a thousandfold) and, like gzip.open in the reference (:605-606),
@@ -232,7 +238,8 @@ def _inflate_regions(path, piece_bytes):
             raise EOFError("Compressed file ended before the end-of-stream marker was reached")
         return
     lib = _iolib()
-    base = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value
+    data_view = np.frombuffer(data, dtype=np.uint8)      # (kept: the address below is only good while the mapping lives)
+    base = data_view.ctypes.data
     st = lib.sctio_inflate_new()
     status, used = ctypes.c_int32(0), ctypes.c_int64(0)
     crc_q = queue.Queue(maxsize=16)

@@ -42,13 +42,13 @@ def test_core_header_and_table_builder_under_asan_ubsan():
     exe = os.path.join(build, "host_core_check_asan")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-o", exe, os.path.join(util.HERE, "host_core_check.cpp")])
-    r = subprocess.run([exe, "4"], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"), timeout=1200)
+    r = subprocess.run([exe, "8"], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"), timeout=1200)
     out = r.stdout.decode() + r.stderr.decode()
     assert r.returncode == 0 and out.startswith("OK") and "runtime error" not in out, out[-4000:]
 
 
 def test_inflate_differential_fuzz_short_run():
-    """tools/fuzz_inflate.c for 2 000 mutated streams under ASan + UBSan: the serial decoder (csrc/sct_inflate.c), the parallel driver
+    """tools/fuzz_inflate.c for 1 000 mutated streams under ASan + UBSan: the serial decoder (csrc/sct_inflate.c), the parallel driver
     (csrc/sct_pinflate.c: threads, chunking, hand-over) and zlib must agree on which streams are valid and on every byte of the valid
     ones; every structured input also goes through the fast compressor (csrc/sct_fdeflate.c) and back through zlib.  The recorded long
     run — 1.02 M streams — is profiles/r04_inflate_fuzz.log."""
@@ -58,8 +58,8 @@ def test_inflate_differential_fuzz_short_run():
     subprocess.check_call(["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
                            os.path.join(ROOT, "tools", "fuzz_inflate.c"), os.path.join(ROOT, "sctagger_amd", "csrc", "sct_inflate.c"),
                            os.path.join(ROOT, "sctagger_amd", "csrc", "sct_pinflate.c"), os.path.join(ROOT, "sctagger_amd", "csrc", "sct_fdeflate.c"), "-lz", "-lpthread"])
-    r = subprocess.run([exe, "2000", "77"], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"), timeout=900)
+    r = subprocess.run([exe, "1000", "77"], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"), timeout=900)
     out = r.stdout.decode() + r.stderr.decode()
-    assert r.returncode == 0 and "DONE 2000 streams" in out and "decoder ok / zlib not 0, zlib ok / decoder not 0" in out, out[-3000:]
-    assert "verdict differs 0" in out and "piece CRCs wrong 0" in out and "COMPRESSOR 2000 inputs" in out and "identical 2000" in out, out[-3000:]
+    assert r.returncode == 0 and "DONE 1000 streams" in out and "decoder ok / zlib not 0, zlib ok / decoder not 0" in out, out[-3000:]
+    assert "verdict differs 0" in out and "piece CRCs wrong 0" in out and "COMPRESSOR 1000 inputs" in out and "identical 1000" in out, out[-3000:]
     assert "runtime error" not in out and "AddressSanitizer" not in out
