@@ -129,7 +129,7 @@ def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_
             pass
     return {"rows_in": n, "rows_out": rows, "wall_s": round(wall, 3), "wall_s_runs": [round(w, 3) for w in walls],
             "segments_per_s": n / wall, "in_raw_MB": round(raw / 1e6), "in_gz_MB": round(gz / 1e6, 1) if not plain else None, "in_gzip_level": None if plain else level,
-            "out_gz_MB": round(out_bytes / 1e6, 1), "sample_checked_rows": k, "extra_args": list(extra), "timing_lines": timing[-3:],
+            "out_gz_MB": round(out_bytes / 1e6, 1), "sample_checked_rows": k, "extra_args": list(extra), "timing_lines": timing[-5:],
             "what": "scTagger.py match_trie -lr lr.tsv%s -sr sr.tsv -mr 2 -t 16 -o out.tsv.gz in a child process (python start-up, "
                     "gunzip + parse, match, render + gzip), best of %d runs" % ("" if plain else ".gz", runs)}
 

@@ -69,6 +69,6 @@ for n in sizes:
                     rows_out += piece.count(b"\n")
         print(json.dumps({"rows": n, "in_gzip_level": level, "in_gz_MB": round(files[level][2] / 1e6, 1), "env": env, "extra": extra, "rc": rc, "wall_s": walls, "cpu_user_sys_s": cpu,
                           "segments_per_s": n / min(walls), "out_MB": round(os.path.getsize(extra[extra.index("-o") + 1] if "-o" in extra else out) / 1e6, 1) if rc == 0 else None, "rows_out": rows_out,
-                          "timing": timing[-3:]}), flush=True)
+                          "timing": timing[-5:]}), flush=True)
     for l in files:
         os.remove(files[l][0])
