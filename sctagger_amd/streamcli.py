@@ -473,19 +473,24 @@ class _Worker(threading.Thread):
         if nbytes <= self.cap_bytes and (self.pinned or not want_pinned):
             return
         self.cap_bytes = max(nbytes, self.cap_bytes, BLOCK_BYTES + (1 << 20))
-        self.cap_rows = ROWS_PER_PASS
+        # Rows per pass: a block of the usual shape has one row per 40 bytes; one per 16 is room enough for a pass to take nearly
+        # every block whole, and what has more rows goes in several passes (the loop in _block).  Page-locking costs 2.4 ms per
+        # MB (tools/history/close_cost.py): sized for 2^21 rows, as these arrays were, the eight workers of a 10^7-row run locked
+        # 220 MB — half a second of kernel work, one worker after the other — for blocks of 105 000 rows.
+        self.cap_rows = min(ROWS_PER_PASS, max(65536, self.cap_bytes // 16))
         if want_pinned:
             with self.dev.lock:
                 alloc = self.dev.m.host_array
                 self.segs, self.offs, self.lens = alloc(self.cap_bytes, np.uint8), alloc(self.cap_rows + 1, np.int32), alloc(self.cap_rows, np.uint8)
-                self.min_e, self.cnt = alloc(self.cap_rows, np.uint8), alloc(self.cap_rows, np.uint32)
+                self.min_e, self.cnt8 = alloc(self.cap_rows, np.uint8), alloc(self.cap_rows, np.uint8)
             self.pinned = True
         else:
             self.segs = np.empty(self.cap_bytes, np.uint8)
             self.offs = np.empty(self.cap_rows + 1, np.int32)
             self.lens = np.empty(self.cap_rows, np.uint8)
             self.min_e = np.empty(self.cap_rows, np.uint8)
-            self.cnt = np.empty(self.cap_rows, np.uint32)     # viewed as uint8 for the one-byte counts
+            self.cnt8 = np.empty(self.cap_rows, np.uint8)
+        self.cnt = None      # four-byte counts: only for a block with a row of more than 255 hits (an ordinary array, made then)
         if getattr(self, "ns", None) is not None and self.ns.size >= self.cap_rows:
             return
         self.ns = np.empty(self.cap_rows, dtype=np.int64)
@@ -497,7 +502,7 @@ class _Worker(threading.Thread):
         self._ensure(len(buf))
         base = buf.ctypes.data          # (a uint8 array: a view of the buffer the reader decoded into)
         at, n_rows, out, keep = 0, 0, [], []
-        cnt8 = self.cnt.view(np.uint8)
+        cnt8 = self.cnt8
         n_bc = self.dev.bc.shape[0]
         # 16-bit hits while the pattern ids fit (2 per barcode): half the bytes back over the link
         hfmt, hbytes = (_native.HITS_U16, 2) if 2 * n_bc <= 65536 else (_native.HITS_U32, 4)
@@ -532,6 +537,8 @@ class _Worker(threading.Thread):
                 except _native.SctError as e:
                     if e.code != _native.E_RANGE:
                         raise
+                    if self.cnt is None or self.cnt.size < self.cap_rows:
+                        self.cnt = np.empty(self.cap_rows, np.uint32)
                     me, cnt, hits = m.match_stream(self.segs[:nbytes], index, self.max_err, self.threads, index_format=ifmt,
                                                    count_format=_native.CNT_U32, min_e=self.min_e, counts=self.cnt, copy_hits=True, hits_format=hfmt)
                     cbytes = 4

@@ -340,3 +340,50 @@ def test_pageable_arrays_that_share_pages(m):
             me, ho, hits = m.match_stream(view["segs"], view["offs"].view(np.int64), 2, 16, index_format=_native.IDX_OFFS64, count_format=_native.CNT_OFFS64,
                                           min_e=view["min_e"])
             util.assert_same((me, ho, hits), want, "carved arrays, offsets, pad %d order %d" % (pad, order))
+
+
+def test_streaming_command_many_ties_and_many_short_rows(tmp_path):
+    """Two shapes the command's per-worker arrays are not sized for at first: a block with a row of more than 255 hits (one-byte
+    counts give SCT_E_RANGE: the worker repeats the call with four-byte counts) and a block with more rows than one pass holds
+    (rows of 7 bytes where the arrays allow one row per 16 bytes of the block).  Against the oracle's rendering."""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    centre = np.full(16, ord("A"), dtype=np.uint8)
+    rows = []
+    for i in range(16):
+        for j in range(i + 1, 16):
+            for a in acgt[1:]:
+                s = centre.copy()
+                s[i], s[j] = a, a
+                rows.append(s)
+    bc = np.array(rows, dtype=np.uint8)                       # 360 barcodes two substitutions away from A x 16
+    bcs = [b.tobytes().decode() for b in bc]
+    lines, names, segl = [], [], []
+    for k in range(520_000):
+        if k < 400_000:
+            seg = ""                                          # a stretch of seven-byte rows "x\t1\t2\t\n": 150 000 of them per MB
+        elif k % 1000 == 0:
+            seg = "A" * 22                                    # 360 ties at distance 2
+        elif k % 3 == 0:
+            seg = ""                                          # five-byte rows: "x\t1\t2\t\n" and the like
+        else:
+            seg = "".join("ACGT"[c] for c in rng.integers(0, 4, size=int(rng.integers(0, 30))))
+        nm = "r%d" % k if seg else "x"
+        names.append(nm)
+        segl.append(seg)
+        lines.append("%s\t1\t2\t%s" % (nm, seg))
+    lr = tmp_path / "lr.tsv"
+    lr.write_text("\n".join(lines) + "\n")
+    sr = tmp_path / "sr.tsv"
+    sr.write_text("".join("%s\t1\n" % b for b in bcs))
+    segs = np.frombuffer("".join(segl).encode(), dtype=np.uint8)
+    offs = np.zeros(len(segl) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in segl], out=offs[1:])
+    want = trie_oracle.match(bc, segs, offs, 2, threads=16, workers=8)
+    assert int(np.diff(want[1]).max()) == 360
+    exp = util.render(bcs, names, segs, offs, *want).encode()
+    for env in (dict(os.environ), dict(os.environ, SCT_STREAM_BLOCK_BYTES=str(1 << 20), SCT_CLI_WORKERS="3")):
+        o = tmp_path / "o.tsv"
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", str(lr), "-sr", str(sr), "-mr", "2", "-t", "16",
+                               "-o", str(o)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+        assert o.read_bytes() == exp
