@@ -479,10 +479,11 @@ class _Worker(threading.Thread):
         # 220 MB — half a second of kernel work, one worker after the other — for blocks of 105 000 rows.
         self.cap_rows = min(ROWS_PER_PASS, max(65536, self.cap_bytes // 16))
         if want_pinned:
-            with self.dev.lock:
-                alloc = self.dev.m.host_array
-                self.segs, self.offs, self.lens = alloc(self.cap_bytes, np.uint8), alloc(self.cap_rows + 1, np.int32), alloc(self.cap_rows, np.uint8)
-                self.min_e, self.cnt8 = alloc(self.cap_rows, np.uint8), alloc(self.cap_rows, np.uint8)
+            # (not under the device's lock: sct_host_alloc keeps no state in the context, and the workers' allocations — 15-25 ms
+            # each, all of them at the moment the context becomes ready — would otherwise stand in line with the first calls)
+            alloc = self.dev.m.host_array
+            self.segs, self.offs, self.lens = alloc(self.cap_bytes, np.uint8), alloc(self.cap_rows + 1, np.int32), alloc(self.cap_rows, np.uint8)
+            self.min_e, self.cnt8 = alloc(self.cap_rows, np.uint8), alloc(self.cap_rows, np.uint8)
             self.pinned = True
         else:
             self.segs = np.empty(self.cap_bytes, np.uint8)
