@@ -656,7 +656,7 @@ def main():
                 # (the -lr file at gzip level 9: what the reference's producer writes, gzip.open's default, scTagger.py:377)
                 out["cli_e2e"] = cli_e2e.run(k, work=os.environ.get("SCT_BENCH_TMP", "/tmp/sct_bench_cli"), bc=bc,
                                              segs=segs[:offs[k]], offs=offs[:k + 1], quiet=True, level=9)
-                out["cli_e2e"]["at_100M_rows"] = "profiles/r04_cli_scale.jsonl: gz -> gz 1.86 / 2.08 s (4.8-5.4e7 rows/s), gz -> tsv 1.42 s (7.0e7 rows/s) on the box's 16-CPU quota"
+                out["cli_e2e"]["at_100M_rows"] = "profiles/r04_cli_scale.jsonl: gz -> gz 1.72 / 1.78 s (5.6-5.8e7 rows/s; other boxes 1.54-1.77), gz -> tsv 1.15 / 1.21 s (8.5e7 rows/s) on the box's 16-CPU quota"
             except Exception as e:   # the figure is informative; the bench line must come out
                 out["cli_e2e"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
