@@ -1045,6 +1045,8 @@ struct FilterArgs {
     const SctSpecialRec *rec_in;  // special launch: the records of its listed rows
     uint32_t rec_cap;
     const uint8_t *gather;        // special launch: where the long rows of a zero-copy batch were copied (SCT_REC_GATHERED records), or NULL
+    bool skip64_unless_needed;    // main launch, both instantiations over all rows: the 32-bit one marks ctr[CTR_NEED64] when it meets a
+                                  //   wave of the other kind, the 64-bit one (launched behind it) leaves at once if nobody did
     uint8_t *gather_out;          // main launch of a zero-copy batch: copy the long rows there while the block's bytes are in LDS
     uint64_t gather_cap;          //   (bytes; cursor = ctr[CTR_GATHER]); what it cannot take is left to k_special_gather
     uint32_t *ctr;                // the batch's counter record (CTR_*)
@@ -1212,6 +1214,9 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
                 decoded = true;
             }
         }
+    }
+    if constexpr (COOP) {
+        if (anyrow && !mykind && lane == 0 && a.skip64_unless_needed) a.ctr[CTR_NEED64] = 1u;
     }
     if (!mykind) return;
     if (!anyrow) return;
@@ -1611,6 +1616,11 @@ k_filter(const FilterArgs<OffT> a) {
         filter_rows<E, W, SCHEME, KS, HM, RPW, RT, SL, OffT, true>(a, lds[threadIdx.x >> 6], first, n, reinterpret_cast<uint32_t *>(&lds[0]),
                                                                    (int)sizeof(lds), reinterpret_cast<uint8_t *>(&block_flags));
     } else {
+        if constexpr (RPW == 64 && sizeof(W) == 8 && !SP) {
+            // the main launch's 64-bit instantiation behind its 32-bit one: 42 us for a pass over every row's length that finds
+            // nothing to do when all rows have at most 31 characters (the BASELINE shapes)
+            if (a.skip64_unless_needed && a.ctr[CTR_NEED64] == 0u) return;
+        }
         const int64_t step = (int64_t)gridDim.x * WPB * RPW;
         for (int64_t f = first; f < n; f += step) {
             filter_rows<E, W, SCHEME, KS, HM, RPW, RT, SL, OffT, false, SP>(a, lds[0], f, n);

@@ -40,6 +40,7 @@ enum {
     CTR_SPECIAL = 16,   // rows the main launch lists for the special launch (list_special): restricted starts, more than PLANE_MAX characters
     CTR_SPECIAL2 = 17,  // rows the special launch's first stage (16 rows per wave, bucket slots) hands to its second (list_special2)
     CTR_GATHER = 18,    // (64-bit, words 18-19) bytes used in the gather buffer (k_special_gather: long listed rows copied to the device)
+    CTR_NEED64 = 20,    // set by the main launch's 32-bit instantiation when a wave belongs to the 64-bit one (rows of 32 .. 63 characters)
     CTR_WORDS = 32
 };
 

@@ -754,7 +754,9 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
             v64.only64 = true;
             launch_filter(bp.max_err, v64, fa, 1, capped((n + 63) / 64), st);
         } else {
+            fa.skip64_unless_needed = true;     // (both instantiations over all rows, the 32-bit one first)
             launch_filter(bp.max_err, v, fa, blocks_for(n, 256), capped((n + 63) / 64), st);
+            fa.skip64_unless_needed = false;
         }
     }
     {
