@@ -191,6 +191,8 @@ struct Lane {
     std::vector<TimedSpan> timed;
     std::vector<hipEvent_t> pool;
     size_t pool_used = 0;
+    hipEvent_t last_end = nullptr;   // the event that closed the last span (Timer): a span that follows it directly starts there
+    bool index_just_timed = false;   // the span "k_index" was the last thing queued (sct_match_stream): "k_filter" follows it directly
 
     hipEvent_t ev() {
         if (pool_used == pool.size()) {
@@ -264,21 +266,26 @@ struct sct_ctx {
     Lane &lane0() { return *lanes[0]; }
 };
 
+// follows_previous: nothing was queued on the lane's stream since the previous span ended — this one starts at that span's end event.
+// (An event record between two kernels is a barrier packet: the kernel trace shows 10.4 us between two spans that each record their
+// own, 12 records and 62 us per batch; with shared boundaries 7 records.)
 struct Timer {
     Lane *l;
     TimedSpan t{};
     bool on;
-    Timer(sct_ctx *c, Lane &lane, const char *name) : l(&lane), on(c->timing) {
+    Timer(sct_ctx *c, Lane &lane, const char *name, bool follows_previous = false) : l(&lane), on(c->timing) {
         if (!on) return;
         t.name = name;
-        t.a = l->ev();
+        const bool shared = follows_previous && l->last_end != nullptr;
+        t.a = shared ? l->last_end : l->ev();
         t.b = l->ev();
         if (!t.a || !t.b) { on = false; return; }
-        (void)hipEventRecord(t.a, l->stream);
+        if (!shared) (void)hipEventRecord(t.a, l->stream);
     }
     ~Timer() {
         if (!on) return;
         (void)hipEventRecord(t.b, l->stream);
+        l->last_end = t.b;
         l->timed.push_back(t);
     }
 };
@@ -300,6 +307,8 @@ static void collect_timing(sct_ctx *c, Lane &l) {
     }
     l.timed.clear();
     l.pool_used = 0;
+    l.last_end = nullptr;
+    l.index_just_timed = false;
 }
 
 static int lane_create(Lane **out) {
@@ -715,7 +724,8 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.prefix_len = bp.prefix_len;
     SctFilterVariant v{false, bp.rt_families, bp.use_slots && !bp.rt_families, bp.use_thirds, bp.use_wide, false, false, false};
     {
-        Timer t(c, l, "k_filter");
+        Timer t(c, l, "k_filter", l.index_just_timed);
+        l.index_just_timed = false;
         fa.n = n;
         fa.n_dev = nullptr;
         fa.rows = nullptr;
@@ -763,7 +773,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         // rows with more ties / verified matches than the main launch keeps: once more with larger lists.  How many
         // there are is only known on the device: a fixed grid strides over them.  Rows this launch cannot hold either go
         // to the exhaustive scan (list_scan).
-        Timer t(c, l, "k_filter_retry");
+        Timer t(c, l, "k_filter_retry", true);
         v.retry = true;
         fa.rec_out = nullptr;
         fa.gather_out = nullptr;
@@ -784,7 +794,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         // go to the retry launch's slot array; what it cannot hold goes on to list_long -> the scan kernels of the slow path.
         // With bucket slots (the BASELINE shapes) in two stages: 16 rows per wave first — up to 4 windows and 80 list entries per row —,
         // then 4 rows per wave for what that hands on.
-        Timer t(c, l, "k_filter_special");
+        Timer t(c, l, "k_filter_special", true);
         v.retry = false;
         v.special = true;
         fa.n = 0;
@@ -884,11 +894,11 @@ static int queue_batch(sct_ctx *c, Lane &l) {
         const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
         uint64_t *total = reinterpret_cast<uint64_t *>(l.ctr() + CTR_TOTAL);
         {
-            Timer t(c, l, "k_offsets");
+            Timer t(c, l, "k_offsets", true);    // (right behind the filter launches)
             k_sum_blocks<uint32_t><<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), nullptr);
             k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
         }
-        Timer t(c, l, "k_fill");
+        Timer t(c, l, "k_fill", true);
         if (l.hits16_ptr)
             k_offsets_fill<uint16_t><<<(unsigned)nb, 256, 0, st>>>(l.cnt.as<uint32_t>(), n, l.sums.as<uint64_t>(), total, l.hit_offs.as<int64_t>(), nullptr,
                                                                   l.cnt32_ptr, l.ctr(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
@@ -1152,6 +1162,8 @@ extern "C" int sct_run(sct_ctx *c, int32_t max_err, int32_t threads, int64_t *n_
     c->last_ms.clear();
     l.timed.clear();
     l.pool_used = 0;
+    l.last_end = nullptr;
+    l.index_just_timed = false;
     if (int rc = reset_counters(l)) return rc;
     if (int rc = queue_batch(c, l)) return rc;
     HIPCHK(hipStreamSynchronize(l.stream));  // the one host synchronisation of a run without listed rows
@@ -1382,6 +1394,8 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     for (int i = 0; i < L; i++) {
         c->lanes[i]->timed.clear();
         c->lanes[i]->pool_used = 0;
+        c->lanes[i]->last_end = nullptr;
+        c->lanes[i]->index_just_timed = false;
     }
     if (int rc = ensure_host_hits(c, (size_t)(n < (1 << 18) ? (1 << 18) : n + n / 4))) return rc;
     // a call of one chunk lets the fill kernel write the hits into the page-locked result buffer itself
@@ -1503,6 +1517,7 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
                 }
             }
         }
+        l.index_just_timed = true;
         if (int rc = queue_batch(c, l)) return rc;
         if (!l.direct_min_e || (!l.direct_cnt && count_format != SCT_CNT_OFFS64)) {
             Timer t(c, l, "copy_d2h");
@@ -1728,6 +1743,8 @@ extern "C" int sct_wl_count(sct_ctx *c, const char *segs, const int64_t *offs, c
     c->last_ms.clear();
     l.timed.clear();
     l.pool_used = 0;
+    l.last_end = nullptr;
+    l.index_just_timed = false;
     HIPCHK(hipMemsetAsync(c->wl_counts.p, 0, 4 * nk, st));
     HIPCHK(hipMemsetAsync(c->wl_first.p, 0xFF, 4 * nk, st));
     if (n > 0) {
@@ -1789,6 +1806,8 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
     c->last_ms.clear();
     l.timed.clear();
     l.pool_used = 0;
+    l.last_end = nullptr;
+    l.index_just_timed = false;
     l.have_result = false;
     uint64_t *d_total = reinterpret_cast<uint64_t *>(l.ctr() + CTR_TOTAL);
     uint64_t total = 0;
