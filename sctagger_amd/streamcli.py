@@ -423,6 +423,7 @@ class _Device(threading.Thread):
     def run(self):
         try:
             self.m = _native.Matcher(self.device)
+            self.m.set_option("timing", 0)      # (no per-kernel HIP events: a call on a block of 10^5 rows is a dozen launches)
             self.have_bc.wait()
             if self.bc is not None:
                 self.m.set_barcodes(self.bc, self.bl)
