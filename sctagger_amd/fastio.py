@@ -19,7 +19,6 @@ import ctypes
 import gzip
 import os
 import zlib
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -295,7 +294,8 @@ class GzipChunkWriter:
     def __init__(self, path, level=4, threads=8):
         self.f = open(path, "wb")
         self.level = level
-        self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
+        from concurrent.futures import ThreadPoolExecutor      # (here, not at the top: the import pulls in logging, traceback and
+        self.pool = ThreadPoolExecutor(max_workers=max(1, threads))  # tokenize — 15 ms of the streaming command's start for nothing)
         self.max_pending = 2 * max(1, threads)      # every thread busy and one piece waiting for it (round 3: 32 in all — at 10^8
         self.pending = []                           # rows the writer, not the device, was what the command waited for)
 
