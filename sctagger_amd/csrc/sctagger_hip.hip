@@ -39,6 +39,7 @@
 //   k_wl_count                        extract_sr_bc_from_lr: whitelist dictionary probes (scTagger.py:818-826)
 //   k_adapter_count / k_adapter_fill  extract_lr_bc: adapter alignment over whole reads (scTagger.py:176-196)
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1323,7 +1324,10 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
         void *p[4] = {nullptr, nullptr, nullptr, nullptr};
         int n = 0;
         ~Registered() {
-            for (int i = 0; i < n; i++) (void)hipHostUnregister(p[i]);
+            for (int i = 0; i < n; i++) {
+                const hipError_t e = hipHostUnregister(p[i]);
+                if (e != hipSuccess || getenv("SCT_TRACE_STREAM")) fprintf(stderr, "sctagger_hip: hipHostUnregister(%p): %s\n", p[i], hipGetErrorString(e));
+            }
             (void)hipGetLastError();
         }
     } registered;
@@ -1345,6 +1349,24 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
         candidate(index, index_bytes);
         candidate(min_e, (size_t)n);
         candidate(counts, counts_bytes);  // (64-bit offsets are copied down, faster into locked pages)
+        // ... and the smaller ones that share a page with one of those: a copy to or from such an array would otherwise go through the
+        // runtime's own locking and unlocking of that page while a kernel reads its neighbour in place (the allocator puts a call's
+        // arrays side by side often enough: 128 of 3 200 calls of tools/history/fault_hunt.py)
+        const int n_big = nr;
+        auto neighbour = [&](const void *p, size_t bytes) {
+            if (!p || !bytes || bytes >= ((size_t)1 << 20) || nr >= 4 || device_view(p, bytes)) return;
+            const uintptr_t lo = (uintptr_t)p & ~(page - 1), hi = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
+            for (int i = 0; i < n_big; i++)
+                if (lo < ((rg[i].hi + page - 1) & ~(page - 1)) && hi > (rg[i].lo & ~(page - 1))) {
+                    rg[nr].lo = (uintptr_t)p;
+                    rg[nr].hi = (uintptr_t)p + bytes;
+                    nr++;
+                    return;
+                }
+        };
+        neighbour(index, index_bytes);
+        neighbour(min_e, (size_t)n);
+        neighbour(counts, counts_bytes);
         std::sort(rg, rg + nr, [](const Range &a, const Range &b) { return a.lo < b.lo; });
         int k = 0;
         for (int i = 1; i < nr; i++) {
@@ -1352,6 +1374,15 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
             else rg[++k] = rg[i];
         }
         for (int i = 0; i < (nr ? k + 1 : 0); i++) {
+            // The caller's pages must stay where they are while the kernels read them in place.  numpy asks for transparent huge pages
+            // for every array of 4 MB or more (madvise MADV_HUGEPAGE), and khugepaged collapses such a range into huge pages whenever
+            // it gets to it — also in the middle of a call, under a locked range: the GPU's mapping is invalidated and the kernel
+            // that reads the rows ends in "Memory access fault by GPU" (round 4: tools/soak.py, two of three runs of one sequence;
+            // none of four with "register" = 0).  Take the range out of khugepaged's reach first.
+            {
+                const uintptr_t a0 = rg[i].lo & ~(page - 1), a1 = (rg[i].hi + page - 1) & ~(page - 1);
+                (void)madvise((void *)a0, (size_t)(a1 - a0), MADV_NOHUGEPAGE);
+            }
             if (!inject_alloc_failure() && hipHostRegister((void *)rg[i].lo, (size_t)(rg[i].hi - rg[i].lo), hipHostRegisterDefault) == hipSuccess) {
                 registered.p[registered.n++] = (void *)rg[i].lo;
                 own[n_own].lo = rg[i].lo;
@@ -1363,6 +1394,13 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
     }
     const uint8_t *zc_segs = (const uint8_t *)device_view(segs, (size_t)seg_bytes);
     const char *zc_index = (const char *)device_view(index, index_bytes);
+    if (getenv("SCT_TRACE_STREAM")) {   // one line per call: which of the caller's arrays the kernels will touch in place
+        fprintf(stderr, "sctagger_hip: stream n=%lld segs=%p+%lld index=%p+%zu min_e=%p counts=%p+%zu; locked here:", (long long)n, (const void *)segs,
+                (long long)seg_bytes, index, index_bytes, (void *)min_e, counts, counts_bytes);
+        for (int i = 0; i < n_own; i++) fprintf(stderr, " [%p, %p)", (void *)own[i].lo, (void *)own[i].hi);
+        fprintf(stderr, "; in place: segs %p index %p min_e %p counts %p\n", (const void *)zc_segs, (const void *)zc_index, device_view(min_e, (size_t)n),
+                count_format == SCT_CNT_OFFS64 ? nullptr : device_view(counts, counts_bytes));
+    }
     // outputs the kernels can write in place (page-locked arrays): min_e and the compact counts; the 64-bit offsets need the
     // hits of the earlier chunks added and stay on the copy path
     uint8_t *zc_min_e = (uint8_t *)device_view(min_e, (size_t)n);
