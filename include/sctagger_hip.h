@@ -192,7 +192,11 @@ int sct_sync(sct_ctx *ctx);
  *                            window lanes read them over the link.  Same results.
  *   "register"         0|1   1 (default): pageable segs / index / min_e / counts buffers of a stream call of at least 4 MB of
  *                            segments are page-locked for the duration of the call (hipHostRegister) and then read and
- *                            written in place as well; 0: they go through staged copies
+ *                            written in place as well; 0: they go through staged copies.  The locked pages are first marked
+ *                            MADV_NOHUGEPAGE — and stay so: a transparent-huge-page collapse under a locked range (numpy asks for
+ *                            huge pages for arrays of 4 MB and more) invalidates the device's mapping in the middle of a kernel
+ *                            (DESIGN.md 5c).  Environment SCT_TRACE_STREAM=1: one line per call on stderr — the caller's arrays,
+ *                            what was locked, what the kernels touch in place.
  *   "fail_alloc_at"    k     TEST HOOK for the error paths (error codes instead of the reference's asserts,
  *                            scTagger.py:140-143, :760-761): the k-th allocation attempt the context makes from now on — device
  *                            memory, page-locked host memory, page-locking of a caller buffer, a lane's stream — fails once as if
