@@ -96,8 +96,8 @@ void sct_free_hits(sct_ctx *ctx, uint32_t *hits);
  *   read and written IN PLACE by the kernels through their device mapping ("zero copy", option "zero_copy"): nothing is
  *   uploaded, the rows cross the link inside the filter kernel while it computes, and the call runs as ONE chunk of up to 2^24
  *   rows (more rows: several such chunks one after the other; a chunk also ends before 3 GiB of segment bytes, the offsets on
- *   the device being 32-bit and relative to the chunk).  Large pageable buffers are page-locked for the duration of the call
- *   (option "register") and take the same route.  What cannot be mapped is uploaded in chunks (option "chunk_rows") that move
+ *   the device being 32-bit and relative to the chunk).  With the option "register" = 1 large pageable buffers are page-locked for the duration
+ *   of the call and take the same route (off by default: see the option).  What cannot be mapped is uploaded in chunks (option "chunk_rows") that move
  *   through several streams (option "lanes") so that the upload of chunk k+1, the kernels of chunk k and the download of chunk
  *   k-1 overlap.
  *   Limits: row counts, seg_bytes, hit offsets and the hit total are 64-bit throughout (the reference's own c_int index,
@@ -190,12 +190,13 @@ int sct_sync(sct_ctx *ctx);
  *   "gather"           0|1   1 (default): in a zero-copy batch the rows of more than 63 characters are copied to the device
  *                            (one coalesced pass, k_special_gather) before the special launch cuts them into windows; 0: its
  *                            window lanes read them over the link.  Same results.
- *   "register"         0|1   1 (default): pageable segs / index / min_e / counts buffers of a stream call of at least 4 MB of
+ *   "register"         0|1   1: pageable segs / index / min_e / counts buffers of a stream call of at least 4 MB of
  *                            segments are page-locked for the duration of the call (hipHostRegister) and then read and
- *                            written in place as well; 0: they go through staged copies.  The locked pages are first marked
+ *                            written in place as well; 0 (default since round 4): they go through staged copies — 15.5 ms per
+ *                            10 M rows against 16 - 35 ms with locking, now that the locked pages are first marked
  *                            MADV_NOHUGEPAGE — and stay so: a transparent-huge-page collapse under a locked range (numpy asks for
  *                            huge pages for arrays of 4 MB and more) invalidates the device's mapping in the middle of a kernel
- *                            (DESIGN.md 5c).  Environment SCT_TRACE_STREAM=1: one line per call on stderr — the caller's arrays,
+ *                            (DESIGN.md 5c); locking huge pages was what made it fast (11 ms), and what made it unsafe.  Environment SCT_TRACE_STREAM=1: one line per call on stderr — the caller's arrays,
  *                            what was locked, what the kernels touch in place.
  *   "fail_alloc_at"    k     TEST HOOK for the error paths (error codes instead of the reference's asserts,
  *                            scTagger.py:140-143, :760-761): the k-th allocation attempt the context makes from now on — device

@@ -252,7 +252,8 @@ struct sct_ctx {
     int slots_mode = -1;       // -1 = by the share of long buckets, 0 = never, 1 = whenever the tables hold them
     double long_share = 1.0;   // share of the seed keys whose bucket does not fit a slot (sct_set_barcodes)
     bool zero_copy = true;     // stream API: kernels read page-locked caller buffers in place instead of uploading them
-    bool auto_register = true; // ... and pageable ones are page-locked for the duration of the call
+    bool auto_register = false; // option "register": pageable ones are page-locked for the duration of the call (off by default since
+                                // round 4: DESIGN.md 5c, the third defect)
     int stream_lanes = 5;      // chunks of a stream call in flight (each on a lane of its own)
     int64_t chunk_rows = 0;    // rows per chunk of the stream API; 0 = chosen by where the caller's buffers live
     // what the last run / stream call measured and counted

@@ -101,6 +101,7 @@ def test_stream_sites_zero_copy_registered_and_staged():
 
     def make():
         m = _native.Matcher(0)
+        m.set_option("register", 1)       # (page-locking caller memory for the call: an option since round 4)
         m.set_barcodes(bc)
         return m
 

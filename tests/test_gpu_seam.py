@@ -318,6 +318,7 @@ def test_pageable_arrays_that_share_pages(m):
     m.set_barcodes(bc)
     want = m.match(segs, offs, 2, 16)
     lens = np.diff(offs).astype(np.uint8)
+    m.set_option("register", 1)          # (page-locking caller memory is an option since round 4; it is what this test is about)
     for pad in (0, 3, 4093):
         for order in (0, 1):
             # one buffer, the arrays back to back: [segs (locked: > 4 MB)] [min_e (small)] [lens (small)] [counts u32 (1 MB: locked)] [offs64]
@@ -340,6 +341,7 @@ def test_pageable_arrays_that_share_pages(m):
             me, ho, hits = m.match_stream(view["segs"], view["offs"].view(np.int64), 2, 16, index_format=_native.IDX_OFFS64, count_format=_native.CNT_OFFS64,
                                           min_e=view["min_e"])
             util.assert_same((me, ho, hits), want, "carved arrays, offsets, pad %d order %d" % (pad, order))
+    m.set_option("register", 0)
 
 
 def test_streaming_command_many_ties_and_many_short_rows(tmp_path):
