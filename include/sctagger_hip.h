@@ -196,7 +196,10 @@ int sct_sync(sct_ctx *ctx);
  *                            10 M rows against 16 - 35 ms with locking, now that the locked pages are first marked
  *                            MADV_NOHUGEPAGE — and stay so: a transparent-huge-page collapse under a locked range (numpy asks for
  *                            huge pages for arrays of 4 MB and more) invalidates the device's mapping in the middle of a kernel
- *                            (DESIGN.md 5c); locking huge pages was what made it fast (11 ms), and what made it unsafe.  Environment SCT_TRACE_STREAM=1: one line per call on stderr — the caller's arrays,
+ *                            (DESIGN.md 5c); locking huge pages was what made it fast (11 ms).  NOT SAFE on the MI355X pool this
+ *                            was developed on even so: with locking one soak run in a few ended in "Memory access fault by
+ *                            GPU" on a host address, cause not established; never without.  Leave it off unless the host is
+ *                            known not to move locked pages.  Environment SCT_TRACE_STREAM=1: one line per call on stderr — the caller's arrays,
  *                            what was locked, what the kernels touch in place.
  *   "fail_alloc_at"    k     TEST HOOK for the error paths (error codes instead of the reference's asserts,
  *                            scTagger.py:140-143, :760-761): the k-th allocation attempt the context makes from now on — device
