@@ -131,3 +131,25 @@ def test_cli_relaunch_mechanics(tmp_path):
     assert note not in small.stderr and note not in already.stderr and forced.stderr.count(note) == 1
     assert forced.returncode == small.returncode == already.returncode
     assert (b"no CPU fallback" in forced.stderr) == (forced.returncode != 0)
+
+
+def test_pool_sizes_follow_the_cpus_the_process_may_use(monkeypatch):
+    """streamcli.effective_cpus / inflate_threads / cpu_workers_for: sized by the affinity mask cut down to the cgroup's CPU quota
+    (a container on a 256-thread host may own 16 of them), every one overridable by its environment variable."""
+    from sctagger_amd import streamcli
+    for v in ("SCT_CPUS", "SCT_INFLATE_THREADS", "SCT_CLI_WORKERS"):
+        monkeypatch.delenv(v, raising=False)
+    n = streamcli.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    monkeypatch.setenv("SCT_CPUS", "16")
+    assert streamcli.effective_cpus() == 16
+    monkeypatch.setattr(streamcli, "compressing_output", False)
+    assert streamcli.inflate_threads() == 8                  # half of them decode
+    assert streamcli.cpu_workers_for(1) == 8 and streamcli.cpu_workers_for(12) == 12     # at least one worker per device
+    monkeypatch.setattr(streamcli, "compressing_output", True)
+    assert streamcli.inflate_threads() == 1                  # zlib output on fewer than 32 CPUs: the serial decoder beside the compressors
+    monkeypatch.setenv("SCT_CPUS", "64")
+    assert streamcli.inflate_threads() == 32 and streamcli.cpu_workers_for(1) == 16
+    monkeypatch.setenv("SCT_INFLATE_THREADS", "5")
+    monkeypatch.setenv("SCT_CLI_WORKERS", "3")
+    assert streamcli.inflate_threads() == 5 and streamcli.cpu_workers_for(1) == 3 and streamcli.cpu_workers_for(4) == 4
