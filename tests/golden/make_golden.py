@@ -24,6 +24,9 @@ Fixture families:
   g10 bl=14, e<=2, 400 segs x 150 barcodes (-t 1, -t 16); g11 bl=9, e<=1 and e<=2, 400 segs x 80 barcodes (-t 4)
       (python make_golden.py g10 generates these two)
   g12 3000 segs x 5000 barcodes, e<=2 (-t 16): sub-sample of BASELINE configs[1] (python make_golden.py g12)
+  g14 the seed filter's SPECIAL launch (rows of 64..753 characters cut into windows, bytes outside ACGT at -t > 1:
+      scTagger.py:677-682, :681): 300 rows of 14..900 characters, every window boundary of tests/test_gpu_special.py
+      included, 3 % bytes outside ACGT, x 120 barcodes at (e, t) = (2,16), (2,1), (1,4), (2,64) (python make_golden.py g14)
   g9  250 segs x 45000 barcodes, e<=2 and e<=1           (-t 8): a set large enough for the library to drop the
       bucket slots at e<=2 (python make_golden.py g9 generates only this family)
 """
@@ -178,6 +181,28 @@ def ragged_pair(name, nseg, nbc, seed):
     return lr, sr
 
 
+def special_pair(name, nbc, seed):
+    """G14: long and noisy rows.  Lengths around every window boundary of the special launch for e = 2 and e = 1 (63 | 64;
+    step = 63 - (bl + e - 1); 16 windows end at 16 * step + bl + e - 1), twice each, plus random lengths up to 900."""
+    from tests import util
+    rng = np.random.default_rng(seed)
+    bc = synth.make_barcodes(nbc, bl=16, seed=seed)
+    edge = [14, 15, 16]
+    for e in (2, 1):
+        step = 63 - (16 + e - 1)
+        edge += [63, 64, 65, step + 17, step + 18, 2 * step + 16, 2 * step + 17, 2 * step + 18, 15 * step + 17, 16 * step + 16,
+                 16 * step + 17, 16 * step + 18, 900]
+    lengths = edge * 2 + list(rng.integers(14, 200, size=190)) + list(rng.integers(200, 760, size=46)) + list(rng.integers(760, 901, size=6))
+    segs, offs = util.rows_of_lengths(bc, [int(x) for x in lengths], seed + 1, junk=0.03)
+    lr = os.path.join(HERE, name + ".lr.tsv")
+    sr = os.path.join(HERE, name + ".sr.tsv")
+    synth.write_barcodes_tsv(sr, bc, seed=seed)
+    with open(lr, "wb") as f:
+        for i in range(len(lengths)):
+            f.write(b"w%d\t2\t30\t" % i + segs[offs[i]:offs[i + 1]].tobytes() + b"\n")
+    return lr, sr
+
+
 def trie_unit_vectors(mod):
     """G4: Trie.insert / Trie.query on tiny tries (duplicates preserved)."""
     cases = []
@@ -277,6 +302,11 @@ def high_byte_vectors(mod):
 
 def main():
     mod = load_reference()
+    if "g14" in sys.argv[1:]:   # the special launch's domain: long rows, bytes outside ACGT at -t > 1
+        lr, sr = special_pair("g14", 120, seed=14)
+        for e, t in ((2, 16), (2, 1), (1, 4), (2, 64)):
+            expected(mod, "g14", lr, sr, e, 16, t)
+        return
     if "g13" in sys.argv[1:]:   # bytes >= 128: where the reference raises and where it never looks
         high_byte_vectors(mod)
         return
