@@ -39,7 +39,6 @@
 //   k_wl_count                        extract_sr_bc_from_lr: whitelist dictionary probes (scTagger.py:818-826)
 //   k_adapter_count / k_adapter_fill  extract_lr_bc: adapter alignment over whole reads (scTagger.py:176-196)
 #include <hip/hip_runtime.h>
-#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -52,6 +51,7 @@
 #include <vector>
 
 #include "../../include/sctagger_hip.h"
+#include "sct_copy_pool.h"
 #include "sct_core.h"
 #include "sct_tables.h"
 
@@ -184,6 +184,8 @@ struct Lane {
     uint64_t hits_cap = 0;      // entries hits_ptr can take
     uint16_t *hits16_ptr = nullptr;  // 16-bit hits of a one-chunk stream call: the fill kernel writes them itself (hits_cap = their room)
     bool direct_min_e = false, direct_cnt = false, direct_hits = false;
+    bool cnt8_soft = false;     // a row with more than 255 hits is not an error of this batch: the one-byte counts go into a slot of the ring, whose
+                                // way out takes the chunk's 64-bit offsets instead (sct_stream.hip.h)
     BatchParams bp;
     int64_t n_hits = 0;
     int64_t stats[6] = {0, 0, 0, 0, 0, 0};
@@ -222,6 +224,17 @@ struct Lane {
 
 static constexpr int STREAM_LANES_MAX = 8;
 
+// A slot of the context's page-locked ring (sct_stream.hip.h): ONE hipHostMalloc holding a chunk's segment bytes, its index as the
+// copy threads narrowed it, and what the kernels write back per row (min_e, one-byte counts) plus the device's block sums.
+struct RingSlot {
+    char *base = nullptr;     // host address
+    char *dev = nullptr;      // the same memory as the device addresses it
+    size_t bytes = 0;
+    size_t seg_cap = 0;       // segment bytes the slot takes (at offset 0)
+    int64_t row_cap = 0;      // rows
+    size_t o_idx = 0, o_min = 0, o_cnt = 0, o_sums = 0;   // offsets of the index, min_e, counts and block-sum areas
+};
+
 struct sct_ctx {
     int device = 0;
     // barcodes
@@ -237,6 +250,11 @@ struct sct_ctx {
     // stream API: page-locked result buffer, owned by the context, valid until the next stream call
     uint32_t *h_hits = nullptr;
     size_t h_hits_cap = 0;  // entries
+    // stream API on pageable caller arrays: the page-locked ring, the threads that copy into and out of it, a page-locked scratch
+    std::vector<RingSlot> ring;
+    CopyPool *pool = nullptr;
+    void *h_scratch = nullptr;
+    size_t h_scratch_cap = 0;
     // whitelist dictionary (extract_sr_bc_from_lr) and adapter alignment (extract_lr_bc): lane 0's rows
     DevBuf wl_table, wl_counts, wl_first, wl_skip;
     DevBuf ad_peq, ad_strand, ad_dist, ad_locs, ad_first, ad_last;
@@ -252,8 +270,13 @@ struct sct_ctx {
     int slots_mode = -1;       // -1 = by the share of long buckets, 0 = never, 1 = whenever the tables hold them
     double long_share = 1.0;   // share of the seed keys whose bucket does not fit a slot (sct_set_barcodes)
     bool zero_copy = true;     // stream API: kernels read page-locked caller buffers in place instead of uploading them
-    bool auto_register = false; // option "register": pageable ones are page-locked for the duration of the call (off by default since
-                                // round 4: DESIGN.md 5c, the third defect)
+    bool use_ring = true;      // stream API: pageable caller arrays go through the context's page-locked ring (sct_stream.hip.h)
+    int ring_slots = 0;        // slots of the ring; 0 = lanes in use + 2
+    int ring_lanes = 3;        // chunks of the ring route in flight on the device
+    int64_t ring_rows = 0;     // rows per chunk of the ring route; 0 = 2^20 (fewer for small calls)
+    bool ring_ramp = true;     // ... reached by doubling from an eighth of that: the device starts early
+    int copy_threads = -1;     // threads of the copy pool; -1 = half of the CPUs the process may use, at most 8
+    int last_route = 0;        // route of the last stream call: 0 staged copies, 1 zero copy, 2 ring
     int stream_lanes = 5;      // chunks of a stream call in flight (each on a lane of its own)
     int64_t chunk_rows = 0;    // rows per chunk of the stream API; 0 = chosen by where the caller's buffers live
     // what the last run / stream call measured and counted
@@ -390,6 +413,10 @@ extern "C" void sct_destroy(sct_ctx *c) {
                       &c->ad_peq, &c->ad_strand, &c->ad_dist, &c->ad_locs, &c->ad_first, &c->ad_last};
     for (DevBuf *b : bufs) b->release();
     if (c->h_hits) (void)hipHostFree(c->h_hits);
+    if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+    delete c->pool;
+    for (RingSlot &s : c->ring)
+        if (s.base) (void)hipHostFree(s.base);
     delete c;
 }
 
@@ -424,6 +451,16 @@ extern "C" int sct_get_option(sct_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
     else if (!strcmp(key, "zero_copy")) *value = c->zero_copy;
     else if (!strcmp(key, "force_exhaustive")) *value = c->force_exhaustive;
+    else if (!strcmp(key, "ring")) *value = c->use_ring;
+    else if (!strcmp(key, "ring_rows")) *value = c->ring_rows;
+    else if (!strcmp(key, "ring_slots")) *value = c->ring_slots;
+    else if (!strcmp(key, "copy_threads")) *value = c->pool ? c->pool->threads() : c->copy_threads;
+    else if (!strcmp(key, "last_route")) *value = c->last_route;
+    else if (!strcmp(key, "ring_bytes")) {
+        size_t b = 0;
+        for (const RingSlot &sl : c->ring) b += sl.bytes;
+        *value = (int64_t)b;
+    }
     else if (!strcmp(key, "device_free_bytes") || !strcmp(key, "device_total_bytes")) {
         size_t fr = 0, tot = 0;
         HIPCHK(hipSetDevice(c->device));
@@ -455,7 +492,24 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
         c->chunk_rows = value;
     } else if (!strcmp(key, "zero_copy")) c->zero_copy = value != 0;
     else if (!strcmp(key, "gather")) c->no_gather = value == 0;
-    else if (!strcmp(key, "register")) c->auto_register = value != 0;
+    else if (!strcmp(key, "ring")) c->use_ring = value != 0;
+    else if (!strcmp(key, "ring_ramp")) c->ring_ramp = value != 0;
+    else if (!strcmp(key, "ring_lanes")) {
+        if (value < 1 || value > STREAM_LANES_MAX) return fail(SCT_E_ARG, "ring_lanes must be in 1 .. %d", STREAM_LANES_MAX);
+        c->ring_lanes = (int)value;
+    }
+    else if (!strcmp(key, "ring_rows")) {
+        if (value < 0 || value > ((int64_t)1 << 24)) return fail(SCT_E_ARG, "ring_rows must be in 0 .. 2^24");
+        c->ring_rows = value;
+    } else if (!strcmp(key, "ring_slots")) {
+        if (value < 0 || value > 32) return fail(SCT_E_ARG, "ring_slots must be in 0 .. 32");
+        c->ring_slots = (int)value;
+    } else if (!strcmp(key, "copy_threads")) {
+        if (value < -1 || value > 64) return fail(SCT_E_ARG, "copy_threads must be in -1 .. 64");
+        c->copy_threads = (int)value;
+        delete c->pool;   // (idle between calls: a context is used by one host thread at a time)
+        c->pool = nullptr;
+    }
     else if (!strcmp(key, "fail_alloc_at")) {   // tests of the error paths: see FaultCounters
         if (value < 0) return fail(SCT_E_ARG, "fail_alloc_at must be >= 0");
         c->fault.fail_at = value;
@@ -668,6 +722,7 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
     l.hits_cap = l.hits.cap / 4;
     l.hits16_ptr = nullptr;
     l.direct_min_e = l.direct_cnt = l.direct_hits = false;
+    l.cnt8_soft = false;
     return SCT_OK;
 }
 
@@ -1093,7 +1148,7 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
         HIPCHK(hipStreamSynchronize(l.stream));
         HIPCHK(hipGetLastError());
     }
-    if (l.bp.count_format == SCT_CNT_U8 && h[CTR_CNT_OVERFLOW])
+    if (l.bp.count_format == SCT_CNT_U8 && h[CTR_CNT_OVERFLOW] && !l.cnt8_soft)
         return fail(SCT_E_RANGE, "a row has more than 255 hits: ask for SCT_CNT_U32 or SCT_CNT_OFFS64 counts");
     if (l.bp.use_join) c->last_join += 1;
     l.n_hits = (int64_t)ctr64(h, CTR_TOTAL);
@@ -1191,470 +1246,66 @@ extern "C" int sct_download(sct_ctx *c, uint8_t *min_e, int64_t *hit_offs, uint3
     return SCT_OK;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// the stream API: the seam in one call.
-// Page-locked (or registered) caller buffers — the shipped default: ZERO COPY.  The kernels read segs / index and write min_e /
-// counts / hits in the caller's memory through its device mapping; the call is ONE chunk of up to 2^24 rows on lane 0 (more
-// rows, or more than 3 GiB of segment bytes: further chunks, one after the other on lanes 0..L-1):
-//   index -> uint32 offsets (k_index_*) -> filter launches (rows cross the link inside k_filter) -> offsets -> fill -> counters
-// Buffers that cannot be mapped are uploaded: the rows are cut into chunks (option "chunk_rows", default 2^20 for page-locked
-// memory with "zero_copy" off, 2^24 for pageable memory) that move through L lanes (option "lanes", default 5)
-//   lane k mod L:   H2D(chunk k) -> index / byte checks -> filter launches -> offsets -> fill -> D2H(min_e, counts, counters)
-// queued L - 1 chunks ahead of the chunk the host is waiting for, so that while chunk k computes, the chunks after it are on
-// their way to the device and the results of the chunks before it on their way back (measured: DESIGN.md 5b — the chunked
-// pipeline needs 6.6 - 8.2 ms per 10 M rows where zero copy needs 5.1).
-// ------------------------------------------------------------------------------------------------------------
-static int ensure_host_hits(sct_ctx *c, size_t entries) {
-    if (entries <= c->h_hits_cap) return SCT_OK;
-    // copies into the old buffer may still be in flight
-    for (Lane *l : c->lanes) HIPCHK(hipStreamSynchronize(l->stream));
-    size_t want = c->h_hits_cap ? c->h_hits_cap : (size_t)1 << 20;
-    while (want < entries) want *= 2;
-    uint32_t *p = nullptr;
-    hipError_t e = inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc((void **)&p, want * sizeof(uint32_t), hipHostMallocDefault);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(e == hipErrorOutOfMemory ? SCT_E_NOMEM : SCT_E_HIP, "hipHostMalloc(%zu) for the hit buffer: %s", want * sizeof(uint32_t), hipGetErrorString(e));
-    }
-    if (c->h_hits) {
-        memcpy(p, c->h_hits, c->h_hits_cap * sizeof(uint32_t));
-        (void)hipHostFree(c->h_hits);
-    }
-    c->h_hits = p;
-    c->h_hits_cap = want;
-    return SCT_OK;
-}
+#include "sct_stream.hip.h"
 
-// the page-locked result buffer as the kernels must address it (hipHostMalloc memory is mapped into the device's address space;
-// on ROCm the two addresses coincide, but that is the runtime's business): NULL if it is not mapped
-static uint32_t *host_hits_device_view(sct_ctx *c) {
-    if (!c->h_hits) return nullptr;
-    hipPointerAttribute_t at;
-    uint32_t *d = nullptr;
-    if (hipPointerGetAttributes(&at, c->h_hits) == hipSuccess && at.type == hipMemoryTypeHost) d = (uint32_t *)at.devicePointer;
-    (void)hipGetLastError();
-    return d;
-}
-
-static inline size_t index_entry_size(int fmt) {
-    return fmt == SCT_IDX_OFFS64 ? 8 : fmt == SCT_IDX_OFFS32 ? 4 : fmt == SCT_IDX_LEN16 ? 2 : 1;
-}
-
-struct ChunkPlan {
-    int64_t r0, r1;  // rows
-    int64_t b0, b1;  // bytes of segs
-    int64_t hit_base = 0;
-    uint64_t narrow_cap = 0;  // 16-bit hits: what the narrowing kernel queued with the chunk could write
-};
-
-extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes, const void *index, int32_t index_format, int64_t n,
-                                int32_t max_err, int32_t threads, uint8_t *min_e, void *counts, int32_t count_format, int32_t hits_format,
-                                const void **hits_out, int64_t *n_hits_out) {
-    if (!c) return fail(SCT_E_ARG, "ctx is NULL");
-    FaultScope fault_scope(&c->fault);
-    if (!hits_out || !n_hits_out) return fail(SCT_E_ARG, "sct_match_stream: NULL output pointer");
-    *hits_out = nullptr;
-    *n_hits_out = 0;
-    if (n < 0 || seg_bytes < 0) return fail(SCT_E_ARG, "sct_match_stream: negative size");
-    if (n > 0 && (!index || !min_e)) return fail(SCT_E_ARG, "sct_match_stream: NULL index or min_e");
-    if (!counts) return fail(SCT_E_ARG, "sct_match_stream: counts is NULL");
-    if (seg_bytes > 0 && !segs) return fail(SCT_E_ARG, "segs is NULL");
-    if (index_format < SCT_IDX_OFFS64 || index_format > SCT_IDX_LEN16) return fail(SCT_E_ARG, "unknown index format %d", index_format);
-    if (count_format < SCT_CNT_OFFS64 || count_format > SCT_CNT_U8) return fail(SCT_E_ARG, "unknown count format %d", count_format);
-    if (hits_format != SCT_HITS_U32 && hits_format != SCT_HITS_U16) return fail(SCT_E_ARG, "unknown hits format %d", hits_format);
-    const bool hits16 = hits_format == SCT_HITS_U16;
-    if (hits16 && c->have_bc && c->np > 65536)
-        return fail(SCT_E_RANGE, "%d barcodes give pattern ids beyond 16 bits: ask for SCT_HITS_U32", c->n_bc);
-    HIPCHK(hipSetDevice(c->device));
-    BatchParams bp;
-    if (int rc = batch_params(c, max_err, threads, count_format, bp)) return rc;
-    const bool by_offs = index_format == SCT_IDX_OFFS64 || index_format == SCT_IDX_OFFS32;
-    auto offs_at = [&](int64_t i) -> int64_t {
-        return index_format == SCT_IDX_OFFS64 ? ((const int64_t *)index)[i] : (int64_t)((const int32_t *)index)[i];
+// sct_match's hit arrays: malloc'ed, handed to the caller, given back through sct_free_hits.  The last few that came back are kept
+// for the next call (any context, any thread): 33 MB per 10 M rows at 25 k barcodes are 8 000 pages to map, fault in and unmap
+// again every call otherwise — a millisecond of a call that takes six.
+struct HitArrays {
+    static constexpr int KEEP = 2;
+    static constexpr size_t KEEP_BYTES_MAX = (size_t)1 << 30;
+    std::mutex mu;
+    struct Known {
+        uint32_t *p;
+        size_t bytes;
     };
-    if (by_offs && index) {
-        if (offs_at(0) != 0) return fail(SCT_E_ARG, "offs[0] must be 0");
-        if (offs_at(n) != seg_bytes) return fail(SCT_E_ARG, "offs[n] = %lld but segs holds %lld bytes", (long long)offs_at(n), (long long)seg_bytes);
-    }
-    if (n == 0) {
-        if (seg_bytes != 0) return fail(SCT_E_ARG, "no rows but %lld segment bytes", (long long)seg_bytes);
-        if (count_format == SCT_CNT_OFFS64) ((int64_t *)counts)[0] = 0;
-        c->last_ms.clear();
-        memset(c->stats, 0, sizeof(c->stats));
-        *hits_out = c->h_hits;
-        return SCT_OK;
-    }
-    // Page-locked host memory (sct_host_alloc, hipHostMalloc, hipHostRegister) is mapped into the device's address space: the
-    // kernels read the rows and their index from it directly ("zero copy"), at the rate of the PCIe link (57 GB/s measured,
-    // profiles/r02_pcie_probe.json), every byte once — there is no upload step to wait for.  Pageable memory is copied.
-    // ... but only if the WHOLE array is: its first and its last byte must both lie in mapped host memory, the same distance apart on
-    // the device.  (The caller's arrays are page-locked below in whole pages: an array that merely BEGINS in the last page of a
-    // neighbour's locked range, too small to be locked itself, looked "mapped" by its first byte, and a kernel's write behind
-    // that page was a GPU memory fault — now and then, as the allocator happened to place the arrays.)
-    struct OwnRange {
-        uintptr_t lo, hi;
-    } own[4];          // what THIS call page-locked
-    int n_own = 0;
-    auto device_view = [&](const void *p, size_t bytes) -> const void * {
-        if (!p || !c->zero_copy) return nullptr;
-        for (int i = 0; i < n_own; i++) {   // an array that begins inside a range of ours must lie inside it altogether
-            const uintptr_t a = (uintptr_t)p;
-            if (a >= own[i].lo && a < own[i].hi && a + bytes > own[i].hi) return nullptr;
-        }
-        hipPointerAttribute_t at;
-        const char *d0 = nullptr, *d1 = nullptr;
-        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) d0 = (const char *)at.devicePointer;
-        (void)hipGetLastError();
-        if (!d0) return nullptr;
-        if (bytes <= 1) return d0;
-        if (hipPointerGetAttributes(&at, (const char *)p + (bytes - 1)) == hipSuccess && at.type == hipMemoryTypeHost) d1 = (const char *)at.devicePointer;
-        (void)hipGetLastError();
-        return (d1 && d1 - d0 == (ptrdiff_t)(bytes - 1)) ? d0 : nullptr;
-    };
-    // Pageable caller buffers of some size are page-locked for the duration of the call (hipHostRegister: 3.5 ms for 230 MB
-    // the first time, next to nothing when the same pages come again) and then take the zero-copy route too — numpy arrays
-    // handed to sct_match cost 20 ms per 10 M rows through staged copies, 9 ms this way.  Whatever cannot be registered
-    // (already partly registered, read-only mappings) is copied as before.
-    // Two of the caller's arrays may share a PAGE (numpy's min_e and hit_offs of one sct_match call are neighbours on the heap):
-    // page-locking them one by one registers that page twice, and a kernel's write to it then faulted ("Memory access fault by
-    // GPU", round 4's first run of the pageable bench leg).  So the candidates are merged first: arrays whose PAGES touch or
-    // overlap are locked as ONE range — from the first byte of the first to the last byte of the last, not rounded to pages: the
-    // runtime takes any other array that begins inside a registered range for registered as a whole, and refuses a copy into it
-    // (or, through the zero-copy path, lets a kernel write behind the locked pages) if it reaches beyond.
-    struct Registered {
-        void *p[4] = {nullptr, nullptr, nullptr, nullptr};
-        int n = 0;
-        ~Registered() {
-            for (int i = 0; i < n; i++) {
-                const hipError_t e = hipHostUnregister(p[i]);
-                if (e != hipSuccess || getenv("SCT_TRACE_STREAM")) fprintf(stderr, "sctagger_hip: hipHostUnregister(%p): %s\n", p[i], hipGetErrorString(e));
-            }
-            (void)hipGetLastError();
-        }
-    } registered;
-    const size_t counts_bytes = count_format == SCT_CNT_OFFS64 ? 8 * (size_t)(n + 1) : count_format == SCT_CNT_U32 ? 4 * (size_t)n : (size_t)n;
-    const size_t index_bytes = index_entry_size(index_format) * (size_t)(by_offs ? n + 1 : n);
-    if (c->zero_copy && c->auto_register && (size_t)seg_bytes >= ((size_t)4 << 20)) {
-        struct Range {
-            uintptr_t lo, hi;   // first byte, one past the last byte
-        } rg[4];
-        int nr = 0;
-        const uintptr_t page = 4096;
-        auto candidate = [&](const void *p, size_t bytes) {
-            if (!p || bytes < ((size_t)1 << 20) || device_view(p, bytes)) return;
-            rg[nr].lo = (uintptr_t)p;
-            rg[nr].hi = (uintptr_t)p + bytes;
-            nr++;
-        };
-        candidate(segs, (size_t)seg_bytes);
-        candidate(index, index_bytes);
-        candidate(min_e, (size_t)n);
-        candidate(counts, counts_bytes);  // (64-bit offsets are copied down, faster into locked pages)
-        // ... and the smaller ones that share a page with one of those: a copy to or from such an array would otherwise go through the
-        // runtime's own locking and unlocking of that page while a kernel reads its neighbour in place (the allocator puts a call's
-        // arrays side by side often enough: 128 of 3 200 calls of tools/history/fault_hunt.py)
-        const int n_big = nr;
-        auto neighbour = [&](const void *p, size_t bytes) {
-            if (!p || !bytes || bytes >= ((size_t)1 << 20) || nr >= 4 || device_view(p, bytes)) return;
-            const uintptr_t lo = (uintptr_t)p & ~(page - 1), hi = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
-            for (int i = 0; i < n_big; i++)
-                if (lo < ((rg[i].hi + page - 1) & ~(page - 1)) && hi > (rg[i].lo & ~(page - 1))) {
-                    rg[nr].lo = (uintptr_t)p;
-                    rg[nr].hi = (uintptr_t)p + bytes;
-                    nr++;
-                    return;
-                }
-        };
-        neighbour(index, index_bytes);
-        neighbour(min_e, (size_t)n);
-        neighbour(counts, counts_bytes);
-        std::sort(rg, rg + nr, [](const Range &a, const Range &b) { return a.lo < b.lo; });
-        int k = 0;
-        for (int i = 1; i < nr; i++) {
-            if ((rg[i].lo & ~(page - 1)) <= ((rg[k].hi + page - 1) & ~(page - 1))) rg[k].hi = std::max(rg[k].hi, rg[i].hi);   // a page in common
-            else rg[++k] = rg[i];
-        }
-        for (int i = 0; i < (nr ? k + 1 : 0); i++) {
-            // The caller's pages must stay where they are while the kernels read them in place.  numpy asks for transparent huge pages
-            // for every array of 4 MB or more (madvise MADV_HUGEPAGE), and khugepaged collapses such a range into huge pages whenever
-            // it gets to it — also in the middle of a call, under a locked range: the GPU's mapping is invalidated and the kernel
-            // that reads the rows ends in "Memory access fault by GPU" (round 4: tools/soak.py, two of three runs of one sequence;
-            // none of four with "register" = 0).  Take the range out of khugepaged's reach first.
-            {
-                const uintptr_t a0 = rg[i].lo & ~(page - 1), a1 = (rg[i].hi + page - 1) & ~(page - 1);
-                (void)madvise((void *)a0, (size_t)(a1 - a0), MADV_NOHUGEPAGE);
-            }
-            if (!inject_alloc_failure() && hipHostRegister((void *)rg[i].lo, (size_t)(rg[i].hi - rg[i].lo), hipHostRegisterDefault) == hipSuccess) {
-                registered.p[registered.n++] = (void *)rg[i].lo;
-                own[n_own].lo = rg[i].lo;
-                own[n_own].hi = rg[i].hi;
-                n_own++;
-            }
-            (void)hipGetLastError();
-        }
-    }
-    const uint8_t *zc_segs = (const uint8_t *)device_view(segs, (size_t)seg_bytes);
-    const char *zc_index = (const char *)device_view(index, index_bytes);
-    if (getenv("SCT_TRACE_STREAM")) {   // one line per call: which of the caller's arrays the kernels will touch in place
-        fprintf(stderr, "sctagger_hip: stream n=%lld segs=%p+%lld index=%p+%zu min_e=%p counts=%p+%zu; locked here:", (long long)n, (const void *)segs,
-                (long long)seg_bytes, index, index_bytes, (void *)min_e, counts, counts_bytes);
-        for (int i = 0; i < n_own; i++) fprintf(stderr, " [%p, %p)", (void *)own[i].lo, (void *)own[i].hi);
-        fprintf(stderr, "; in place: segs %p index %p min_e %p counts %p\n", (const void *)zc_segs, (const void *)zc_index, device_view(min_e, (size_t)n),
-                count_format == SCT_CNT_OFFS64 ? nullptr : device_view(counts, counts_bytes));
-    }
-    // outputs the kernels can write in place (page-locked arrays): min_e and the compact counts; the 64-bit offsets need the
-    // hits of the earlier chunks added and stay on the copy path
-    uint8_t *zc_min_e = (uint8_t *)device_view(min_e, (size_t)n);
-    void *zc_counts = count_format == SCT_CNT_OFFS64 ? nullptr : (void *)device_view(counts, counts_bytes);
-    int64_t chunk = c->chunk_rows;
-    if (chunk <= 0) {
-        // Zero copy: ONE launch over as many rows as possible — a launch begins with every resident wave asking for its rows at
-        // once and ends with compute only, about a quarter of a millisecond in which link and chip do not overlap
-        // (1 M-row launches: 0.58 ms each against 0.43 ms per 1 M rows of a 10 M-row launch).  Uploaded page-locked segments:
-        // 2^20 rows per chunk keep the lanes busy.  Pageable segments: every copy is staged by the runtime and blocks this
-        // thread, so nothing overlaps anyway, and few large copies are staged faster than many small ones.
-        hipPointerAttribute_t at;
-        const bool pinned = zc_segs != nullptr || (hipPointerGetAttributes(&at, segs) == hipSuccess && at.type == hipMemoryTypeHost);
-        (void)hipGetLastError();
-        chunk = zc_segs ? (int64_t)1 << 24 : pinned ? (int64_t)1 << 20 : (int64_t)1 << 24;
-        // the offsets on the device are 32-bit and relative to the chunk
-        const int64_t by_bytes = seg_bytes / ((int64_t)3 << 30) + 1;
-        if ((n + chunk - 1) / chunk < by_bytes) chunk = (n + by_bytes - 1) / by_bytes;
-    }
-    const int64_t n_chunks = (n + chunk - 1) / chunk;
-    const int L = (int)(n_chunks < c->stream_lanes ? n_chunks : c->stream_lanes);
-    while ((int)c->lanes.size() < L) {
-        Lane *l = nullptr;
-        if (int rc = lane_create(&l)) return rc;
-        c->lanes.push_back(l);
-    }
-    c->last_ms.clear();
-    memset(c->stats, 0, sizeof(c->stats));
-    for (int i = 0; i < L; i++) {
-        c->lanes[i]->timed.clear();
-        c->lanes[i]->pool_used = 0;
-        c->lanes[i]->last_end = nullptr;
-        c->lanes[i]->index_just_timed = false;
-    }
-    if (int rc = ensure_host_hits(c, (size_t)(n < (1 << 18) ? (1 << 18) : n + n / 4))) return rc;
-    // a call of one chunk lets the fill kernel write the hits into the page-locked result buffer itself
-    uint32_t *zc_hits = (n_chunks == 1 && !hits16 && c->zero_copy) ? host_hits_device_view(c) : nullptr;
-    // 16-bit hits: the lists are assembled on the device as always and a last kernel writes them, narrowed, into the result buffer
-    uint16_t *zc_hits16 = hits16 ? (uint16_t *)host_hits_device_view(c) : nullptr;
-    if (hits16 && !zc_hits16) return fail(SCT_E_STATE, "the page-locked result buffer is not mapped into the device");
-    std::vector<ChunkPlan> plan((size_t)n_chunks);
-    const size_t isz = index_entry_size(index_format);
-    int64_t bytes_seen = 0;   // lengths formats: running sum of the row lengths
-    int64_t hit_base = 0;
-    int rc_all = SCT_OK;
-    auto drain = [&]() {
-        for (Lane *l : c->lanes) (void)hipStreamSynchronize(l->stream);
-    };
-
-    // phase A of chunk k: everything that can be queued without knowing any result
-    auto phase_a = [&](int64_t k) -> int {
-        Lane &l = *c->lanes[(size_t)(k % L)];
-        ChunkPlan &cp = plan[(size_t)k];
-        cp.r0 = k * chunk;
-        cp.r1 = cp.r0 + chunk < n ? cp.r0 + chunk : n;
-        const int64_t m = cp.r1 - cp.r0;
-        if (by_offs) {
-            cp.b0 = offs_at(cp.r0);
-            cp.b1 = offs_at(cp.r1);
-        } else if (n_chunks == 1) {
-            cp.b0 = 0;   // the device checks that the lengths add up to seg_bytes (k_index_lens); the host need not read them
-            cp.b1 = seg_bytes;
-            bytes_seen = seg_bytes;
-        } else {
-            cp.b0 = bytes_seen;
-            int64_t s = 0;
-            if (index_format == SCT_IDX_LEN8) {
-                const uint8_t *p = (const uint8_t *)index + cp.r0;
-                for (int64_t i = 0; i < m; i++) s += p[i];
-            } else {
-                const uint16_t *p = (const uint16_t *)index + cp.r0;
-                for (int64_t i = 0; i < m; i++) s += p[i];
-            }
-            cp.b1 = cp.b0 + s;
-            bytes_seen = cp.b1;
-        }
-        if (cp.b0 < 0 || cp.b1 < cp.b0 || cp.b1 > seg_bytes)
-            return fail(SCT_E_ARG, "the row index runs outside segs (rows %lld..%lld: bytes %lld..%lld of %lld)", (long long)cp.r0, (long long)cp.r1,
-                        (long long)cp.b0, (long long)cp.b1, (long long)seg_bytes);
-        const int64_t bytes = cp.b1 - cp.b0;
-        if (bytes >= 0xFFFFFFF0ll) return fail(SCT_E_ARG, "a chunk of %lld rows holds %lld bytes: lower the chunk_rows option", (long long)m, (long long)bytes);
-        l.bp = bp;
-        l.n_seg = m;
-        l.seg_bytes = bytes;
-        l.wide = false;
-        l.have_offs64 = false;
-        if (int rc = lane_ensure(l, m, bp)) return rc;
-        if (zc_min_e) {
-            l.min_e_ptr = zc_min_e + cp.r0;
-            l.direct_min_e = true;
-        }
-        if (zc_counts) {
-            if (count_format == SCT_CNT_U8) l.cnt8_ptr = (uint8_t *)zc_counts + cp.r0;
-            else l.cnt32_ptr = (uint32_t *)zc_counts + cp.r0;
-            l.direct_cnt = true;
-        }
-        if (zc_hits) {
-            l.hits_ptr = zc_hits;
-            l.hits_cap = c->h_hits_cap;
-            l.direct_hits = true;
-        }
-        if (hits16 && n_chunks == 1) {   // the only chunk: its hits start at 0, the fill kernel can write them narrowed
-            l.hits16_ptr = zc_hits16;
-            l.hits_cap = 2 * (uint64_t)c->h_hits_cap;
-            cp.narrow_cap = l.hits_cap;
-        }
-        if (l.offs32.ensure(4 * (size_t)(m + 1))) return g_code;
-        if (!zc_segs && l.segs.ensure((size_t)bytes + 64)) return g_code;
-        if ((!zc_index || !by_offs) && l.index_in.ensure(isz * (size_t)(m + 1) + 16)) return g_code;
-        hipStream_t st = l.stream;
-        if (int rc = reset_counters(l)) return rc;
-        const void *idx_dev = zc_index ? (const void *)(zc_index + isz * (size_t)cp.r0) : l.index_in.p;
-        if (zc_segs) {
-            l.segs_ptr = zc_segs + cp.b0;
-            l.host_segs = segs + cp.b0;
-        } else {
-            l.segs_ptr = l.segs.as<uint8_t>();
-            l.host_segs = nullptr;
-        }
-        if (!zc_segs || !zc_index) {
-            Timer t(c, l, "copy_h2d");
-            if (!zc_segs && bytes) HIPCHK(hipMemcpyAsync(l.segs.p, segs + cp.b0, (size_t)bytes, hipMemcpyHostToDevice, st));
-            if (!zc_index)
-                HIPCHK(hipMemcpyAsync(l.index_in.p, (const char *)index + isz * (size_t)cp.r0, isz * (size_t)(by_offs ? m + 1 : m), hipMemcpyHostToDevice, st));
-        }
+    std::vector<Known> out;    // arrays the callers hold: their sizes
+    std::vector<Known> kept;   // arrays that came back
+    uint32_t *get(size_t bytes) {
         {
-            Timer t(c, l, "k_index");
-            unsigned long long *bad = reinterpret_cast<unsigned long long *>(l.ctr() + CTR_BAD_ROW);
-            if (index_format == SCT_IDX_OFFS64)
-                k_index_offs<int64_t><<<blocks_for(m + 1, 256), 256, 0, st>>>((const int64_t *)idx_dev, m, bytes, l.offs32.as<uint32_t>(), bad);
-            else if (index_format == SCT_IDX_OFFS32)
-                k_index_offs<int32_t><<<blocks_for(m + 1, 256), 256, 0, st>>>((const int32_t *)idx_dev, m, bytes, l.offs32.as<uint32_t>(), bad);
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < kept.size(); i++)
+                if (kept[i].bytes >= bytes && kept[i].bytes <= 2 * bytes + ((size_t)1 << 20)) {
+                    Known k = kept[i];
+                    kept.erase(kept.begin() + (ptrdiff_t)i);
+                    out.push_back(k);
+                    return k.p;
+                }
+        }
+        uint32_t *p = (uint32_t *)malloc(bytes ? bytes : 4);
+        if (p) {
+            std::lock_guard<std::mutex> lk(mu);
+            out.push_back(Known{p, bytes});
+        }
+        return p;
+    }
+    void put(uint32_t *p) {
+        if (!p) return;
+        uint32_t *drop = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t bytes = 0;
+            bool known = false;
+            for (size_t i = 0; i < out.size(); i++)
+                if (out[i].p == p) {
+                    bytes = out[i].bytes;
+                    out.erase(out.begin() + (ptrdiff_t)i);
+                    known = true;
+                    break;
+                }
+            if (!known || bytes < ((size_t)1 << 20) || bytes > KEEP_BYTES_MAX) drop = p;   // small ones: the allocator's business
             else {
-                const int64_t nb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
-                uint64_t *total = reinterpret_cast<uint64_t *>(l.ctr() + CTR_TOTAL);  // free until the hit counts are summed
-                // a zero-copy index crosses the link once: the first pass leaves a copy on the device for the second.
-                // (Tried in round 3: the index in two parts, the head's filter launch beside the rest's lengths on a second stream.
-                // Nothing gained, 4.89 -> 5.04 ms per 10 M rows: the lengths are link traffic like the segments — 10 of the
-                // 219 MB a 10 M-row call reads — and the link is busy from the call's first microsecond to the start of the tail.)
-                if (index_format == SCT_IDX_LEN8) {
-                    uint8_t *keep = zc_index ? l.index_in.as<uint8_t>() : nullptr;
-                    k_sum_blocks<uint8_t><<<(unsigned)nb, 256, 0, st>>>((const uint8_t *)idx_dev, m, l.sums.as<uint64_t>(), keep);
-                    k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
-                    k_index_lens<uint8_t><<<(unsigned)nb, 256, 0, st>>>(keep ? keep : (const uint8_t *)idx_dev, m, l.sums.as<uint64_t>(), total, bytes,
-                                                                       l.offs32.as<uint32_t>(), bad);
-                } else {
-                    uint16_t *keep = zc_index ? l.index_in.as<uint16_t>() : nullptr;
-                    k_sum_blocks<uint16_t><<<(unsigned)nb, 256, 0, st>>>((const uint16_t *)idx_dev, m, l.sums.as<uint64_t>(), keep);
-                    k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
-                    k_index_lens<uint16_t><<<(unsigned)nb, 256, 0, st>>>(keep ? keep : (const uint16_t *)idx_dev, m, l.sums.as<uint64_t>(), total, bytes,
-                                                                        l.offs32.as<uint32_t>(), bad);
+                kept.push_back(Known{p, bytes});
+                if ((int)kept.size() > KEEP) {
+                    drop = kept.front().p;
+                    kept.erase(kept.begin());
                 }
             }
         }
-        l.index_just_timed = true;
-        if (int rc = queue_batch(c, l)) return rc;
-        if (!l.direct_min_e || (!l.direct_cnt && count_format != SCT_CNT_OFFS64)) {
-            Timer t(c, l, "copy_d2h");
-            if (!l.direct_min_e) HIPCHK(hipMemcpyAsync(min_e + cp.r0, l.min_e.p, (size_t)m, hipMemcpyDeviceToHost, st));
-            if (!l.direct_cnt) {
-                if (count_format == SCT_CNT_U8) HIPCHK(hipMemcpyAsync((uint8_t *)counts + cp.r0, l.cnt_out.p, (size_t)m, hipMemcpyDeviceToHost, st));
-                else if (count_format == SCT_CNT_U32)
-                    HIPCHK(hipMemcpyAsync((uint32_t *)counts + cp.r0, l.cnt_out.p, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
-            }
-        }
-        HIPCHK(hipEventRecord(l.done, st));
-        return SCT_OK;
-    };
-
-    // phase B of chunk k: wait for phase A, look at its counters, bring the hits home
-    auto phase_b = [&](int64_t k) -> int {
-        Lane &l = *c->lanes[(size_t)(k % L)];
-        ChunkPlan &cp = plan[(size_t)k];
-        const int64_t m = cp.r1 - cp.r0;
-        hipStream_t st = l.stream;
-        HIPCHK(hipEventSynchronize(l.done));
-        bool slow = false;
-        if (int rc = finish_batch(c, l, cp.r0, &slow)) return rc;
-        cp.hit_base = hit_base;
-        if (int rc = ensure_host_hits(c, (size_t)(hit_base + l.n_hits + 1))) return rc;
-        {
-            Timer t(c, l, "copy_d2h");
-            if (slow) {  // what phase A copied was not final
-                if (!l.direct_min_e) HIPCHK(hipMemcpyAsync(min_e + cp.r0, l.min_e.p, (size_t)m, hipMemcpyDeviceToHost, st));
-                if (!l.direct_cnt) {
-                    if (count_format == SCT_CNT_U8) HIPCHK(hipMemcpyAsync((uint8_t *)counts + cp.r0, l.cnt_out.p, (size_t)m, hipMemcpyDeviceToHost, st));
-                    else if (count_format == SCT_CNT_U32)
-                        HIPCHK(hipMemcpyAsync((uint32_t *)counts + cp.r0, l.cnt_out.p, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
-                }
-            }
-            if (count_format == SCT_CNT_OFFS64) {
-                // the chunk's offsets start at 0: add the hits of the chunks before it, then copy (the last entry of a chunk
-                // and the first of the next are the same element of the caller's array, with the same value)
-                if (hit_base) k_rebase<<<blocks_for(m + 1, 256), 256, 0, st>>>(l.hit_offs.as<int64_t>(), m + 1, hit_base);
-                HIPCHK(hipMemcpyAsync((int64_t *)counts + cp.r0, l.hit_offs.p, 8 * (size_t)(m + 1), hipMemcpyDeviceToHost, st));
-            }
-            if (hits16) {
-                // (the buffer was sized for uint32 entries: twice what the narrowed lists need)
-                if (l.n_hits && (n_chunks > 1 || slow || (uint64_t)l.n_hits > cp.narrow_cap)) {
-                    if (l.hits16_ptr && !slow) {
-                        // the fill kernel found the result buffer too small and wrote nothing: fill the 32-bit array on the device first
-                        if (l.hits.ensure(4 * (size_t)(l.n_hits + 1))) return g_code;
-                        k_fill<<<blocks_for(m, 256), 256, 0, st>>>(l.cnt.as<uint32_t>(), l.slots.as<uint32_t>(), l.slots_retry.as<uint32_t>(),
-                                                                   l.wave_base.as<uint64_t>(), l.slot_off.as<uint64_t>(), l.hit_offs.as<int64_t>(), l.cnt.as<uint32_t>(), m,
-                                                                   l.hits.as<uint32_t>(), l.hits.cap / 4, l.ctr(), nullptr);
-                        l.hits_ptr = l.hits.as<uint32_t>();
-                    }
-                    // (ensure_host_hits above may have moved the buffer: ask for its device view again)
-                    uint16_t *out16 = (uint16_t *)host_hits_device_view(c);
-                    if (!out16) return fail(SCT_E_STATE, "the page-locked result buffer is not mapped into the device");
-                    k_narrow_hits<<<blocks_for(l.n_hits, 2048), 256, 0, st>>>(l.hits_ptr, l.ctr(), ~0ull, out16 + hit_base);
-                }
-            } else if (l.n_hits && !l.direct_hits) {
-                HIPCHK(hipMemcpyAsync(c->h_hits + hit_base, l.hits_ptr, 4 * (size_t)l.n_hits, hipMemcpyDeviceToHost, st));
-            }
-        }
-        hit_base += l.n_hits;
-        for (int i = 0; i < 6; i++) c->stats[i] += l.stats[i];
-        return SCT_OK;
-    };
-
-    // host time spent queueing (phase A) and waiting + collecting (phase B), reported beside the device spans
-    double host_a = 0, host_b = 0;
-    auto clk = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    for (int64_t k = 0; k < n_chunks + (L - 1) && rc_all == SCT_OK; k++) {
-        const double t0 = clk();
-        if (k < n_chunks) rc_all = phase_a(k);
-        const double t1 = clk();
-        const int64_t j = k - (L - 1);
-        if (rc_all == SCT_OK && j >= 0) rc_all = phase_b(j);
-        host_a += t1 - t0;
-        host_b += clk() - t1;
+        free(drop);
     }
-    if (rc_all != SCT_OK) {
-        const std::string keep = g_err;
-        drain();
-        (void)hipGetLastError();
-        g_err = keep;
-        return rc_all;
-    }
-    for (int i = 0; i < L; i++) HIPCHK(hipStreamSynchronize(c->lanes[(size_t)i]->stream));
-    HIPCHK(hipGetLastError());
-    if (!by_offs && bytes_seen != seg_bytes)
-        return fail(SCT_E_ARG, "the row lengths add up to %lld but segs holds %lld bytes", (long long)bytes_seen, (long long)seg_bytes);
-    for (int i = 0; i < L; i++) collect_timing(c, *c->lanes[(size_t)i]);
-    c->last_ms.emplace_back("host_queue", sct_ctx::Span{host_a, (int)n_chunks});
-    c->last_ms.emplace_back("host_wait", sct_ctx::Span{host_b, (int)n_chunks});
-    c->lane0().have_result = false;  // lane 0 no longer holds a resident upload's result
-    c->lane0().n_seg = -1;
-    *hits_out = c->h_hits;
-    *n_hits_out = hit_base;
-    return SCT_OK;
-}
+};
+static HitArrays g_hit_arrays;
 
 extern "C" int sct_match(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n, int32_t max_err, int32_t threads,
                          uint8_t *min_e, int64_t *hit_offs, uint32_t **hits, int64_t *n_hits) {
@@ -1667,15 +1318,15 @@ extern "C" int sct_match(sct_ctx *c, const char *segs, const int64_t *offs, int6
     int64_t total = 0;
     int rc = sct_match_stream(c, segs, offs[n], offs, SCT_IDX_OFFS64, n, max_err, threads, min_e, hit_offs, SCT_CNT_OFFS64, SCT_HITS_U32, &h, &total);
     if (rc) return rc;
-    uint32_t *out = inject_alloc_failure() ? nullptr : (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(total ? total : 1));
+    uint32_t *out = inject_alloc_failure() ? nullptr : g_hit_arrays.get(sizeof(uint32_t) * (size_t)(total ? total : 1));
     if (!out) return fail(SCT_E_NOMEM, "out of host memory for %lld hits", (long long)total);
-    if (total) memcpy(out, h, sizeof(uint32_t) * (size_t)total);
+    par_copy(c, out, h, sizeof(uint32_t) * (size_t)total);   // (33 MB per 10 M rows at 25 k barcodes: on the copy pool)
     *hits = out;
     *n_hits = total;
     return SCT_OK;
 }
 
-extern "C" void sct_free_hits(sct_ctx *, uint32_t *hits) { free(hits); }
+extern "C" void sct_free_hits(sct_ctx *, uint32_t *hits) { g_hit_arrays.put(hits); }
 
 extern "C" int sct_last_timing_ex(sct_ctx *c, const char **names, float *ms, int32_t *launches, int cap) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");

@@ -2,8 +2,6 @@
 the call reports SCT_E_NOMEM (or, where a caller buffer merely could not be page-locked, carries on through staged copies),
 nothing leaks, and the same context then gives the right answer.  The reference aborts on an assert instead
 (/root/reference/scTagger.py:140-143, :760-761; SURVEY.md §5: error codes)."""
-import os
-
 import numpy as np
 import pytest
 
@@ -96,17 +94,13 @@ def test_match_sites_by_scheme(scheme):
     _walk(make, lambda m: m.match(segs, offs, e, 16), want, "sct_match (%s)" % scheme, expect_sites=20)
 
 
-def test_stream_sites_zero_copy_registered_and_staged():
-    bc, segs, offs = _inputs(n=300_000)            # > 4 MB of segment bytes: pageable arrays are page-locked for the call
+def test_stream_sites_zero_copy_ring_and_staged():
+    bc, segs, offs = _inputs(n=300_000)
     want = trie_oracle.match(bc, segs, offs, 2, threads=16, workers=16)
     lens = np.diff(offs).astype(np.uint16)
 
-    with_locking = bool(os.environ.get("SCT_TEST_REGISTER"))   # page-locking caller memory: an option since round 4, and not safe on this
-                                                               # pool: its sites are walked only when asked for
-
     def make():
         m = _native.Matcher(0)
-        m.set_option("register", 1 if with_locking else 0)
         m.set_barcodes(bc)
         return m
 
@@ -115,12 +109,28 @@ def test_stream_sites_zero_copy_registered_and_staged():
         ho = np.zeros(cnt.size + 1, np.int64)
         np.cumsum(cnt, out=ho[1:])
         return me.copy(), ho, hits.astype(np.uint32)
-    f1, s1 = _walk(make, stream, want, "sct_match_stream (pageable%s)" % (" -> registered" if with_locking else ", staged"), expect_sites=15)
-    if with_locking:
-        assert s1 >= 1     # hipHostRegister failing is not an error: staged copies
+
+    # pageable arrays: the context's page-locked ring (round 5): its slots and the lanes of its chunks are sites too
+    def ring(m):
+        out = stream(m)
+        assert m.get_option("last_route") == 2
+        return out
+    _walk(make, ring, want, "sct_match_stream (pageable, ring)", expect_sites=25)
+
+    def ring_match(m):       # sct_match itself: int64 offsets in, int64 CSR out, the hit array handed over
+        m.set_option("ring_rows", 50_000)
+        return m.match(segs, offs, 2, 16)
+    _walk(make, ring_match, want, "sct_match (pageable, ring of small chunks)", expect_sites=25)
+
+    def staged_one(m):       # the ring switched off: staged copies, one chunk
+        m.set_option("ring", 0)
+        out = stream(m)
+        assert m.get_option("last_route") == 0
+        return out
+    _walk(make, staged_one, want, "sct_match_stream (pageable, staged)", expect_sites=15)
 
     def staged(m):
-        m.set_option("register", 0)
+        m.set_option("ring", 0)
         m.set_option("chunk_rows", 70_000)
         return stream(m)
     _walk(make, staged, want, "sct_match_stream (staged, 5 chunks on lanes)", expect_sites=25)

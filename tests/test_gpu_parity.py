@@ -44,21 +44,29 @@ def check_stream_variants(m, segs, offs, e, t, want, chunk_rows=None):
             idx.append((_native.IDX_LEN8, lens.astype(np.uint8)))
         if n and lens.max() <= 65535:
             idx.append((_native.IDX_LEN16, lens.astype(np.uint16)))
-        for k, (ifmt, index) in enumerate(idx):
-            for cfmt in (_native.CNT_OFFS64, _native.CNT_U32, _native.CNT_U8):
-                if k > 1 and cfmt != _native.CNT_U8:
-                    continue                       # the length formats with one count format are enough
-                if cfmt == _native.CNT_U8 and max_cnt > 255:
-                    with pytest.raises(_native.SctError) as ei:
-                        m.match_stream(segs, index, e, t, index_format=ifmt, count_format=cfmt)
-                    assert ei.value.code == _native.E_RANGE
-                    continue
-                hfmt = _native.HITS_U16 if (k + cfmt) % 2 == 0 and 2 * m.n_bc <= 65536 else _native.HITS_U32
-                me, cnt, hits = m.match_stream(segs, index, e, t, index_format=ifmt, count_format=cfmt, hits_format=hfmt)
-                assert hits.dtype == (np.uint16 if hfmt == _native.HITS_U16 else np.uint32)
-                util.assert_same((me, counts_to_offsets(cnt, cfmt), hits.astype(np.uint32)), want, "stream idx=%d cnt=%d hits=%d" % (ifmt, cfmt, hfmt))
+        # pageable arrays: through the context's page-locked ring (the default), and through staged copies ("ring" = 0; every other format pair)
+        for ring in (1, 0):
+            m.set_option("ring", ring)
+            for k, (ifmt, index) in enumerate(idx):
+                for cfmt in (_native.CNT_OFFS64, _native.CNT_U32, _native.CNT_U8):
+                    if k > 1 and cfmt != _native.CNT_U8:
+                        continue                       # the length formats with one count format are enough
+                    if not ring and (k + cfmt) % 2:
+                        continue
+                    if cfmt == _native.CNT_U8 and max_cnt > 255:
+                        with pytest.raises(_native.SctError) as ei:
+                            m.match_stream(segs, index, e, t, index_format=ifmt, count_format=cfmt)
+                        assert ei.value.code == _native.E_RANGE
+                        continue
+                    hfmt = _native.HITS_U16 if (k + cfmt) % 2 == 0 and 2 * m.n_bc <= 65536 else _native.HITS_U32
+                    me, cnt, hits = m.match_stream(segs, index, e, t, index_format=ifmt, count_format=cfmt, hits_format=hfmt)
+                    assert hits.dtype == (np.uint16 if hfmt == _native.HITS_U16 else np.uint32)
+                    assert n == 0 or m.get_option("last_route") == (2 if ring else 0)
+                    util.assert_same((me, counts_to_offsets(cnt, cfmt), hits.astype(np.uint32)), want,
+                                     "stream idx=%d cnt=%d hits=%d ring=%d" % (ifmt, cfmt, hfmt, ring))
     finally:
         m.set_option("chunk_rows", 0)
+        m.set_option("ring", 1)
 
 
 def pinned_copy(m, a, skew=0):

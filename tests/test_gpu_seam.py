@@ -308,19 +308,17 @@ def test_bad_input_leaves_no_output_file(tmp_path):
         assert gzip.open(o, "rb").read() == f.read()
 
 
-@pytest.mark.skipif(not os.environ.get("SCT_TEST_REGISTER"), reason="page-locking caller memory (option \"register\") is off by default and not safe "
-                    "on this pool: one soak run in a few ends in a GPU memory fault with it (DESIGN.md 5c); set SCT_TEST_REGISTER=1 to run")
 def test_pageable_arrays_that_share_pages(m):
-    """Caller arrays as a heap places them: neighbours that share pages.  The library page-locks large pageable arrays for the
-    call in WHOLE pages; a small array that only begins in such a page must not be taken for mapped (round 4: a GPU memory fault,
-    now and then), and two large neighbours must not lock their shared page twice."""
+    """Caller arrays as a heap places them: neighbours that share pages, at odd alignments.  (Round 4 page-locked such arrays for the
+    call and had to tell neighbours apart page by page; since round 5 nothing of the caller's is locked: the arrays go through the
+    context's page-locked ring, whose copy threads must cope with any alignment and with outputs that touch their inputs' pages.)"""
     bc = synth.make_barcodes(800, seed=23)
     n = 250_000
     segs, offs = synth.make_segments(n, bc, seed=23)
     m.set_barcodes(bc)
     want = m.match(segs, offs, 2, 16)
     lens = np.diff(offs).astype(np.uint8)
-    m.set_option("register", 1)          # (page-locking caller memory is an option since round 4; it is what this test is about)
+    m.set_option("ring_rows", 40_000)    # several chunks, so that slots are reused within the call
     for pad in (0, 3, 4093):
         for order in (0, 1):
             # one buffer, the arrays back to back: [segs (locked: > 4 MB)] [min_e (small)] [lens (small)] [counts u32 (1 MB: locked)] [offs64]
@@ -343,7 +341,8 @@ def test_pageable_arrays_that_share_pages(m):
             me, ho, hits = m.match_stream(view["segs"], view["offs"].view(np.int64), 2, 16, index_format=_native.IDX_OFFS64, count_format=_native.CNT_OFFS64,
                                           min_e=view["min_e"])
             util.assert_same((me, ho, hits), want, "carved arrays, offsets, pad %d order %d" % (pad, order))
-    m.set_option("register", 0)
+            assert m.get_option("last_route") == 2
+    m.set_option("ring_rows", 0)
 
 
 def test_streaming_command_many_ties_and_many_short_rows(tmp_path):
