@@ -234,18 +234,50 @@ class Loops:
         return {"ms_per_step": 1e3 * elapsed / max(steps, 1)}, {k: float(np.mean(v)) for k, v in per_kernel.items()}, elapsed
 
     def pageable(self, steps, warmup, threads=THREADS):
-        """INTEGRATION.md §2's call as a maintainer pastes it: sct_match on ordinary (pageable) numpy arrays, int64 offsets in,
-        int64 CSR + a malloc'ed uint32 hit array out.  The library page-locks the arrays for the duration of the call."""
+        """INTEGRATION.md §2's call as a maintainer pastes it: sct_match on ordinary (pageable) numpy arrays, int64 offsets in, fresh
+        numpy arrays for min_e and the int64 CSR offsets out, the malloc'ed uint32 hit array taken over.  Nothing of the caller's is
+        page-locked: the library moves the arrays through its own page-locked ring on its copy threads (csrc/sct_stream.hip.h).
+        Timed twice: the calls alone (every result kept until the loop ends), and as round 4's loop did — the previous result dropped
+        while the next call's is assigned: Python then unmaps 123 MB per step, which is the interpreter's time, not the call's."""
+        m = self.m
         segs, offs = np.array(self.segs, copy=True), np.array(self.offs, copy=True)
         for _ in range(max(1, warmup)):
-            self.m.match(segs, offs, self.max_err, threads)
+            m.match(segs, offs, self.max_err, threads)
+        keep = []
         t0 = time.perf_counter()
         for _ in range(steps):
-            r = self.m.match(segs, offs, self.max_err, threads)
+            keep.append(m.match(segs, offs, self.max_err, threads))
         dt = (time.perf_counter() - t0) / max(steps, 1)
-        return {"ms_per_step": 1e3 * dt, "value": self.n_seg / dt, "hits": int(r[2].size), "threads": threads,
+        spans = {name: round(ms, 4) for name, ms, _k in m.last_timing_ex()}
+        hits = int(keep[-1][2].size)
+        route, ring_mb, copy_threads = m.get_option("last_route"), m.get_option("ring_bytes") / 1e6, m.get_option("copy_threads")
+        del keep
+        r = None
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = m.match(segs, offs, self.max_err, threads)
+        dt_drop = (time.perf_counter() - t0) / max(steps, 1)
+        del r
+        m.set_option("ring", 0)        # round 4's route, for the record: the runtime's staged copies
+        try:
+            m.match(segs, offs, self.max_err, threads)
+            keep = []
+            t0 = time.perf_counter()
+            for _ in range(max(2, steps // 2)):
+                keep.append(m.match(segs, offs, self.max_err, threads))
+            dt_staged = (time.perf_counter() - t0) / max(2, steps // 2)
+            del keep
+        finally:
+            m.set_option("ring", 1)
+        return {"ms_per_step": 1e3 * dt, "value": self.n_seg / dt, "hits": hits, "threads": threads,
+                "ms_per_step_dropping_the_previous_result": 1e3 * dt_drop, "ms_per_step_staged_copies": 1e3 * dt_staged,
+                "route": {0: "staged", 1: "zero-copy", 2: "ring"}.get(route, str(route)), "ring_MB": round(ring_mb, 1), "copy_threads": copy_threads,
+                "caller_memory_page_locked": False, "spans_ms": spans,
                 "what": "sct_match(ctx, segs, offs int64, n, max_err, threads, min_e, hit_offs int64, &hits, &n_hits) on pageable numpy arrays "
-                        "(INTEGRATION.md §2), result copied into a fresh numpy array as the binding there does"}
+                        "(INTEGRATION.md §2) through the context's page-locked ring; fresh numpy outputs every call, the hit array taken over "
+                        "without a copy; ms_per_step: the calls alone (results kept until the loop ends); ..._dropping_the_previous_result: "
+                        "round 4's loop (Python unmaps the previous 123 MB inside the timed region); ..._staged_copies: option ring = 0, round 4's route"}
+
     def algorithmic_bytes(self):
         """per segment (L + 4) in + (1 + 4 + 4 h) out, plus the barcode set read once per launch."""
         h = self.hits / float(self.n_seg)
@@ -335,12 +367,13 @@ def pcie_roofline(e2e, seg_bytes):
                     "plain streaming kernel or hipMemcpy reaches on this box (profiles/r02_pcie_probe.json)"}
 
 
-def other_config(name, device, steps, warmup):
-    """One more BASELINE configuration through both loops on a context of its own -> its entry of `other_configs`."""
+def other_config(name, device, steps, warmup, seg_seed=None):
+    """One more BASELINE configuration through both loops on a context of its own -> its entry of `other_configs`.
+    seg_seed: the rows of another seed than the workload's (cfg4: rank r's shard is seed 40 + r)."""
     n_seg, n_bc, bl, max_err = WORKLOADS[name]
     t0 = time.perf_counter()
-    bc = synth.make_barcodes(n_bc, bl=bl, seed=SEEDS[name])
-    segs, offs = make_batch(n_seg, bc, SEEDS[name])
+    bc = synth.make_barcodes(n_bc, bl=bl, seed=SEEDS.get(name, 3))
+    segs, offs = make_batch(n_seg, bc, SEEDS.get(name, 3) if seg_seed is None else seg_seed)
     t_gen = time.perf_counter() - t0
     desc = "%s: %d LR segments x %d barcodes per GPU, bl=%d, e<=%d, 22-bp segments (SURVEY 8(d))" % (name, n_seg, n_bc, bl, max_err)
     m = _native.Matcher(device)
@@ -364,7 +397,7 @@ def other_config(name, device, steps, warmup):
             extra["resident_with_join"] = {"ms_per_step": jres["ms_per_step"], "kernels_ms": {k: round(v, 4) for k, v in javg.items()},
                                            "join_batches": jp["join_batches"], "join_fallbacks": jp["join_fallbacks"],
                                            "note": "k_filter's span covers the join's kernels (tuples, probes per table slice, finish) in this leg"}
-        return {"workload": desc, "seed": SEEDS[name], **extra,
+        return {"workload": desc, "seed": SEEDS.get(name, 3) if seg_seed is None else seg_seed, **extra,
                 "value_device_e2e": n_seg / (e2e["ms_per_step"] * 1e-3), "ms_per_step": e2e["ms_per_step"],
                 "value_resident": n_seg / (res["ms_per_step"] * 1e-3), "ms_per_step_resident": res["ms_per_step"],
                 "steps": steps, "warmup": warmup, "hits_per_segment": round(h, 4), "paths": paths,
@@ -501,9 +534,11 @@ def main():
     device = local_rank % ndev
     numa = shard.bind_to_device_numa(device) if world > 1 else None
     bc_seed = SEEDS.get(wl, 3)
+    t_gen0 = time.perf_counter()
     bc = synth.make_barcodes(n_bc, bl=bl, seed=bc_seed)
     seed = SEEDS.get(wl, 3) if world == 1 else 40 + rank   # cfg4's shards are seeds 40..47
     segs, offs = make_batch(n_seg, bc, seed, seg_len=args.seg_len, frac_empty=args.frac_empty)
+    t_gen = time.perf_counter() - t_gen0
 
     m = _native.Matcher(device)
     for kv in args.option:
@@ -572,7 +607,11 @@ def main():
             "segments": n_seg, "seed": seed, "workload": wl,
             "e2e_ms_per_step": round(e2e["ms_per_step"], 4) if e2e else None,
             "resident_ms_per_step": round(res["ms_per_step"], 4) if res else None,
-            "e2e_spans_ms": e2e["spans_ms"] if e2e else None}
+            "e2e_spans_ms": e2e["spans_ms"] if e2e else None,
+            # what tells a slow host from a slow link when the ranks differ: seconds this rank spent making its inputs (numpy on the
+            # CPUs it was given), its pools' CPU share, and its own resident kernel time (the chip alone)
+            "input_generation_s": round(t_gen, 2), "cpus_per_rank": _native.host_cpus(),
+            "resident_k_filter_ms": round(avg["k_filter"], 4) if avg.get("k_filter") else None}
     per_rank = shard.gather_objects(dist, mine)
     if world > 1 and ndev >= world and len({p["device"] for p in per_rank}) < world:
         # every rank must have a GPU of its own when the box has enough of them: a scaling figure from ranks that share one is void
@@ -616,6 +655,16 @@ def main():
             "roofline_e2e": pcie_roofline(e2e, segs.size),
             "per_rank": per_rank,
         }
+        if world > 1:
+            # the N = 1 anchor of the same shard size (bench.py --gpus 1 --workload cfg4, or other_configs.cfg4_shard of the N = 1 line)
+            # handed in by whoever runs the curve: SCT_BENCH_ANCHOR = segments/s of ONE device
+            try:
+                anchor = float(os.environ.get("SCT_BENCH_ANCHOR", ""))
+            except ValueError:
+                anchor = None
+            out["scaling_efficiency_vs"] = ({"anchor_segments_per_s": anchor, "value_over_n_times_anchor": round(value / (world * anchor), 4)}
+                                            if anchor else {"anchor_segments_per_s": None, "note": "set SCT_BENCH_ANCHOR to the N = 1 value at this shard size"})
+            out["slowest_rank"] = max(per_rank, key=lambda p: p["e2e_ms_per_step"] or 0)["rank"] if e2e else None
         if world == 1 and not args.no_cpu_baseline:
             # the reference's pool at -t 16 (its default), 64 and the host's core count (4^k >= t prefix tasks, each of which scans
             # every segment: more tasks are not always faster); `cpu_baseline` = the best of the ladder, all of it listed
@@ -643,6 +692,14 @@ def main():
                 except Exception as e:   # informative; the bench line must come out
                     oc[name] = {"error": repr(e)}
             oc["cfg3_noise"] = noise
+            try:
+                # the N = 1 anchor of an 8-GPU curve: at N = 8 every rank runs cfg4's 12.5 M-row shard (rank 0: seed 40), at N = 1 / 2 / 4
+                # the 10 M rows of cfg3 — a curve across the two needs this line to compare like with like
+                oc["cfg4_shard"] = dict(other_config("cfg4", device, max(2, min(args.steps, 5)), 1, seg_seed=40),
+                                        what="rank 0's shard of cfg4 (12.5 M rows, seed 40) on ONE device: the anchor for --gpus 8 "
+                                             "(SCT_BENCH_ANCHOR = its value_device_e2e)")
+            except Exception as e:
+                oc["cfg4_shard"] = {"error": repr(e)}
             out["other_configs"] = oc
             try:
                 out["strong_scaling_one_input"] = strong_scaling(bc, segs, offs, max_err, device)

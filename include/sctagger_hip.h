@@ -47,6 +47,11 @@ int sct_device_count(void);
  * page-locked buffers on the NUMA node the device hangs off (/sys/bus/pci/devices/<id>/numa_node). */
 int sct_device_pci_bus_id(int device, char *buf, int len);
 
+/* CPUs the library sizes its host-side pool by (the copy threads of the stream seam: half of them, at most 8): the affinity mask
+ * cut down to the cgroup's CPU quota (environment SCT_CPUS overrides the count), divided by LOCAL_WORLD_SIZE when several ranks
+ * share the node (one process per GPU: the reference's Pool(threads), scTagger.py:703-704, sizes itself by -t alone). */
+int sct_host_cpus(void);
+
 /* Create / destroy a context bound to `device`. */
 int sct_create(int device, sct_ctx **out);
 void sct_destroy(sct_ctx *ctx);
@@ -92,14 +97,18 @@ void sct_free_hits(sct_ctx *ctx, uint32_t *hits);
 /*
  * The same seam for callers that care about the PCIe link: compact transfer formats and an engine that keeps the link busy;
  * sct_match above is this call with 64-bit offsets both ways.
- *   Page-locked buffers (sct_host_alloc, or any hipHostMalloc / hipHostRegister memory) for segs / index / min_e / counts are
+ *   Page-locked buffers (sct_host_alloc, or any hipHostMalloc memory) for segs / index / min_e / counts are
  *   read and written IN PLACE by the kernels through their device mapping ("zero copy", option "zero_copy"): nothing is
  *   uploaded, the rows cross the link inside the filter kernel while it computes, and the call runs as ONE chunk of up to 2^24
  *   rows (more rows: several such chunks one after the other; a chunk also ends before 3 GiB of segment bytes, the offsets on
- *   the device being 32-bit and relative to the chunk).  With the option "register" = 1 large pageable buffers are page-locked for the duration
- *   of the call and take the same route (off by default: see the option).  What cannot be mapped is uploaded in chunks (option "chunk_rows") that move
- *   through several streams (option "lanes") so that the upload of chunk k+1, the kernels of chunk k and the download of chunk
- *   k-1 overlap.
+ *   the device being 32-bit and relative to the chunk).
+ *   Ordinary (pageable) arrays — what the reference's seam hands over, scTagger.py:616-627, and what sct_match gets from numpy —
+ *   go through a ring of page-locked slots OWNED BY THE CONTEXT (option "ring", default on): a pool of copy threads (option
+ *   "copy_threads") moves chunk k+1 into a slot — the offsets narrowed to one byte per row on the way — while the zero-copy kernels
+ *   read chunk k from its slot and chunk k-1's min_e / counts are widened into the caller's arrays.  Nothing of the caller's is
+ *   page-locked, and no caller pointer is given to the HIP runtime.  6 - 7 ms per 10 M rows of 22 characters against 4.8 ms on
+ *   page-locked arrays and 20 ms through the runtime's staged copies (option "ring" = 0, which also covers page-locked buffers with
+ *   "zero_copy" = 0: chunks of "chunk_rows" rows uploaded on "lanes" streams).
  *   Limits: row counts, seg_bytes, hit offsets and the hit total are 64-bit throughout (the reference's own c_int index,
  *   scTagger.py:618, ends at 2^31 segment bytes); sct_upload_segments takes at most 2^31 - 16 rows per call.  Tested: 20 M rows
  *   in one call at the default chunking, 4.5 GB of segment bytes in one call, and 4.43 x 10^9 hits (> 2^32; a 17.7 GB
@@ -150,9 +159,10 @@ int sct_run(sct_ctx *ctx, int32_t max_err, int32_t threads, int64_t *n_hits);
 int sct_download(sct_ctx *ctx, uint8_t *min_e, int64_t *hit_offs, uint32_t *hits);
 
 /*
- * Page-locked host memory.  Optional: every entry point accepts ordinary (pageable) buffers; buffers obtained here
- * are copied to and from the device by DMA at the full PCIe rate, asynchronously, instead of through the runtime's
- * bounce buffer.
+ * Page-locked host memory.  Optional: every entry point accepts ordinary (pageable) buffers — those are moved through
+ * page-locked memory of the context's own by memcpy (the stream seam: a ring and copy threads; everything else: two 4 MB pieces),
+ * never handed to the HIP runtime.  Buffers obtained here are read and written in place by the kernels (the stream seam) or copied
+ * by DMA at the full PCIe rate.
  * sct_host_alloc returns NULL on failure (message in sct_last_error).
  */
 void *sct_host_alloc(sct_ctx *ctx, size_t bytes);
@@ -182,35 +192,44 @@ int sct_sync(sct_ctx *ctx);
  *   "slots"           -1|0|1 8-byte bucket slots of the 16-character seed tables: -1 = used while few keys hold more
  *                            than three barcodes (3.5 % at max_err 2, 10 % below; default), 0 = never, 1 = always
  *   "chunk_rows"       n     rows per chunk of sct_match_stream / sct_match; 0 (default) = 2^24 when segs is read in place
- *                            (page-locked or registered, "zero_copy" on), 2^20 when it is page-locked but uploaded ("zero_copy"
- *                            off), 2^24 when it is pageable and could not be registered (staged copies do not overlap with anything)
+ *                            (page-locked, "zero_copy" on), 2^20 when it is page-locked but uploaded ("zero_copy" off), "ring_rows" on the
+ *                            ring route, 2^24 when it is pageable and the ring is off (staged copies do not overlap with anything)
  *   "lanes"            1..8  chunks of a stream call in flight at once, each on a stream of its own (default 5)
  *   "zero_copy"        0|1   1 (default): sct_match_stream's kernels read page-locked segs / index buffers in place over the
  *                            host link; 0: they are uploaded first
  *   "gather"           0|1   1 (default): in a zero-copy batch the rows of more than 63 characters are copied to the device
  *                            (one coalesced pass, k_special_gather) before the special launch cuts them into windows; 0: its
  *                            window lanes read them over the link.  Same results.
- *   "register"         0|1   1: pageable segs / index / min_e / counts buffers of a stream call of at least 4 MB of
- *                            segments are page-locked for the duration of the call (hipHostRegister) and then read and
- *                            written in place as well; 0 (default since round 4): they go through staged copies — 15.5 ms per
- *                            10 M rows against 16 - 35 ms with locking, now that the locked pages are first marked
- *                            MADV_NOHUGEPAGE — and stay so: a transparent-huge-page collapse under a locked range (numpy asks for
- *                            huge pages for arrays of 4 MB and more) invalidates the device's mapping in the middle of a kernel
- *                            (DESIGN.md 5c); locking huge pages was what made it fast (11 ms).  NOT SAFE on the MI355X pool this
- *                            was developed on even so: with locking one soak run in a few ended in "Memory access fault by
- *                            GPU" on a host address, cause not established; never without.  Leave it off unless the host is
- *                            known not to move locked pages.  Environment SCT_TRACE_STREAM=1: one line per call on stderr — the caller's arrays,
- *                            what was locked, what the kernels touch in place.
+ *   "ring"             0|1   1 (default): a stream call whose segs are NOT page-locked goes through the context's page-locked ring
+ *                            (above); 0: through the runtime's staged copies, which page-lock the caller's pages in place for the
+ *                            duration of each large copy.  (Round 4 had an option "register" that page-locked the caller's arrays
+ *                            for the whole call, hipHostRegister, so that the kernels read them in place: one soak run in a few ended
+ *                            in "Memory access fault by GPU" on a host address, cause never established.  Removed in round 5: the
+ *                            ring is faster than it was and locks nothing of the caller's.)
+ *   "ring_rows"        n     rows per chunk of the ring route; 0 (default) = 2^20, an eighth of the call's rows if that is less (at
+ *                            least 65 536); "chunk_rows" > 0 overrides.  A slot holds 32 bytes of segments per row of a full chunk; a
+ *                            chunk ends before that many bytes (a single longer row gets a slot of its own size).
+ *   "ring_ramp"        0|1   1 (default): the first chunks are smaller — an eighth of "ring_rows", doubling — so that the device starts early
+ *   "ring_lanes"       1..8  chunks of the ring route in flight on the device (default 3)
+ *   "ring_slots"       n     slots of the ring; 0 (default) = "ring_lanes" + 2.  Slots are allocated when first needed, sized by the
+ *                            call (powers of two), and kept: sct_get_option "ring_bytes" = page-locked bytes the ring holds
+ *                            (200 MB after a 10 M-row call at the defaults; 0.2 ms per MB to allocate, once)
+ *   "copy_threads"    -1|n   threads of the context's copy pool (created at the first call that needs it): -1 (default) = half of
+ *                            the CPUs the process may use (affinity mask, cgroup CPU quota; environment SCT_CPUS overrides), at
+ *                            most 8; 0 = the calling thread does every copy itself
+ *                            Environment SCT_TRACE_STREAM=1: one line per call on stderr — the route, and which of the caller's arrays
+ *                            the kernels touch in place; SCT_TRACE_RING=1: per chunk of the ring route, when its copies ran and when
+ *                            the calling thread passed its stations.
  *   "fail_alloc_at"    k     TEST HOOK for the error paths (error codes instead of the reference's asserts,
  *                            scTagger.py:140-143, :760-761): the k-th allocation attempt the context makes from now on — device
- *                            memory, page-locked host memory, page-locking of a caller buffer, a lane's stream — fails once as if
- *                            memory had run out (SCT_E_NOMEM; a caller buffer that cannot be page-locked is copied instead,
- *                            silently); 0 = off.  sct_get_option "alloc_calls" counts the attempts since it was set.
+ *                            memory, page-locked host memory (result buffer, ring slots, bounce pieces), a lane's stream — fails once
+ *                            as if memory had run out (SCT_E_NOMEM); 0 = off.  sct_get_option "alloc_calls" counts the attempts since it was set.
  */
 int sct_set_option(sct_ctx *ctx, const char *key, int64_t value);
-/* Reads an option back ("join", "lanes", "chunk_rows", "zero_copy", "force_exhaustive", "fail_alloc_at") or one of the read-only
- * values "alloc_calls" (allocation attempts since "fail_alloc_at" was last set), "device_free_bytes", "device_total_bytes"
- * (hipMemGetInfo of the context's device). */
+/* Reads an option back ("join", "lanes", "chunk_rows", "zero_copy", "force_exhaustive", "fail_alloc_at", "ring", "ring_rows",
+ * "ring_slots", "copy_threads") or one of the read-only values "alloc_calls" (allocation attempts since "fail_alloc_at" was last set),
+ * "device_free_bytes", "device_total_bytes" (hipMemGetInfo of the context's device), "ring_bytes" (page-locked bytes the ring holds),
+ * "last_route" (the last stream call: 0 = staged copies, 1 = zero copy, 2 = the ring). */
 int sct_get_option(sct_ctx *ctx, const char *key, int64_t *value);
 
 /*

@@ -6,6 +6,7 @@ calls raise.  The library is built in-tree by `__graft_entry__.build()` or
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -21,7 +22,7 @@ EXPORTS = (
     "sct_device_count", "sct_create", "sct_destroy", "sct_last_error", "sct_prefix_len", "sct_set_barcodes",
     "sct_match", "sct_free_hits", "sct_upload_segments", "sct_run", "sct_download", "sct_sync", "sct_set_option",
     "sct_last_timing", "sct_last_stats", "sct_wl_set", "sct_wl_count", "sct_adapter_align", "sct_free_locs",
-    "sct_host_alloc", "sct_host_free", "sct_match_stream", "sct_last_timing_ex", "sct_device_pci_bus_id", "sct_get_option",
+    "sct_host_alloc", "sct_host_free", "sct_match_stream", "sct_last_timing_ex", "sct_device_pci_bus_id", "sct_get_option", "sct_host_cpus",
 )
 
 # index / count formats of sct_match_stream (include/sctagger_hip.h)
@@ -119,6 +120,11 @@ def device_count():
     return int(load().sct_device_count())
 
 
+def host_cpus():
+    """CPUs the library sizes its copy pool by (cgroup quota, SCT_CPUS, this rank's share of them: sct_host_cpus)."""
+    return int(load().sct_host_cpus())
+
+
 def device_pci_bus_id(device):
     """-> e.g. '0000:c1:00.0', or None if the runtime does not tell."""
     buf = ctypes.create_string_buffer(64)
@@ -144,6 +150,7 @@ class Matcher:
         self._check(self._lib.sct_create(int(device), ctypes.byref(self._ctx)))
         self.device = int(device)
         self._pinned = []
+        self._out_bases = []     # match(): output buffers to use again once the caller has dropped the arrays it was given
         self.n_bc = 0
         self.bl = 0
         self.n_seg = 0
@@ -230,12 +237,35 @@ class Matcher:
             raise ValueError("segs holds %d bytes but offs[-1] is %d" % (segs.size, int(offs[-1])))
         return segs, offs
 
+    _OUT_KEEP = 4            # output buffers match() holds on to: two results' worth (the previous one lives until the next is assigned)
+    _OUT_MIN = 1 << 20       # smaller ones are the allocator's business
+
+    def _out(self, n, dtype):
+        """An output array of match(): ordinary (pageable) memory.  Large ones are taken from the few buffers this Matcher keeps, if
+        the caller has dropped every array that was cut from one (numpy counts the views of a buffer for us): a fresh 80 MB array per
+        call is 20 000 pages mapped, zeroed, faulted in and unmapped again — 2.5 ms of a call that takes 7."""
+        nbytes = n * np.dtype(dtype).itemsize
+        if nbytes < self._OUT_MIN:
+            return np.empty(n, dtype=dtype)
+        for base in self._out_bases:
+            if base.nbytes >= nbytes and base.nbytes <= 2 * nbytes and sys.getrefcount(base) <= 3:   # the list, `base`, the argument
+                return base[:nbytes].view(dtype)
+        base = np.empty(nbytes, dtype=np.uint8)
+        if len(self._out_bases) >= self._OUT_KEEP:
+            for i, b in enumerate(self._out_bases):
+                if sys.getrefcount(b) <= 3:
+                    del self._out_bases[i]
+                    break
+        if len(self._out_bases) < self._OUT_KEEP:
+            self._out_bases.append(base)
+        return base[:nbytes].view(dtype)
+
     def match(self, segs, offs, max_err, threads=1):
         """sct_match: -> (min_e uint8[n], hit_offs int64[n+1], hits uint32[total])."""
         segs, offs = self._csr(segs, offs)
         n = offs.size - 1
-        min_e = np.empty(n, dtype=np.uint8)
-        hit_offs = np.empty(n + 1, dtype=np.int64)
+        min_e = self._out(n, np.uint8)
+        hit_offs = self._out(n + 1, np.int64)
         hp = ctypes.c_void_p()
         nh = ctypes.c_int64()
         self._check(self._lib.sct_match(self._ctx, _ptr(segs), _ptr(offs), n, int(max_err), int(threads),

@@ -18,31 +18,36 @@
 #include <vector>
 
 // CPUs this process may really use: its affinity mask cut down to its cgroup's CPU quota (v2 cpu.max, v1 cfs files); SCT_CPUS
-// overrides.  (A container on a 256-thread host may own 16 of them; a pool sized by the 256 spends the quota in the first
+// overrides that count; with LOCAL_WORLD_SIZE ranks on the node, a rank's share of them.  (A container on a 256-thread host may own 16 of them; a pool sized by the 256 spends the quota in the first
 // milliseconds of every scheduler period and is then suspended — sctagger_amd/streamcli.py effective_cpus() is the same rule.)
 static inline int sct_effective_cpus() {
-    if (const char *env = getenv("SCT_CPUS")) {
-        const int v = atoi(env);
-        if (v > 0) return v;
+    int cores = 0;
+    if (const char *env = getenv("SCT_CPUS")) cores = atoi(env);
+    if (cores <= 0) {
+        cpu_set_t set;
+        cores = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)sysconf(_SC_NPROCESSORS_ONLN);
+        double quota = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32];
+            double p = 0;
+            if (fscanf(f, "%31s %lf", q, &p) == 2 && q[0] != 'm' && p > 0) quota = atof(q) / p;
+            fclose(f);
+        } else {
+            FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+            double q = 0, p = 0;
+            if (fq && fp && fscanf(fq, "%lf", &q) == 1 && fscanf(fp, "%lf", &p) == 1 && q > 0 && p > 0) quota = q / p;
+            if (fq) fclose(fq);
+            if (fp) fclose(fp);
+        }
+        if (quota > 0) {
+            const int by_quota = (int)(quota + 0.5) < 1 ? 1 : (int)(quota + 0.5);
+            if (by_quota < cores) cores = by_quota;
+        }
     }
-    cpu_set_t set;
-    int cores = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)sysconf(_SC_NPROCESSORS_ONLN);
-    double quota = 0;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char q[32];
-        double p = 0;
-        if (fscanf(f, "%31s %lf", q, &p) == 2 && q[0] != 'm' && p > 0) quota = atof(q) / p;
-        fclose(f);
-    } else {
-        FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
-        double q = 0, p = 0;
-        if (fq && fp && fscanf(fq, "%lf", &q) == 1 && fscanf(fp, "%lf", &p) == 1 && q > 0 && p > 0) quota = q / p;
-        if (fq) fclose(fq);
-        if (fp) fclose(fp);
-    }
-    if (quota > 0) {
-        const int by_quota = (int)(quota + 0.5) < 1 ? 1 : (int)(quota + 0.5);
-        if (by_quota < cores) cores = by_quota;
+    // one process per GPU (torchrun / shard.launch_ranks set LOCAL_WORLD_SIZE): a rank takes its share
+    if (const char *lw = getenv("LOCAL_WORLD_SIZE")) {
+        const int ranks = atoi(lw);
+        if (ranks > 1) cores /= ranks;
     }
     return cores < 1 ? 1 : cores;
 }

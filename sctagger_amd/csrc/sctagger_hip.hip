@@ -255,6 +255,9 @@ struct sct_ctx {
     CopyPool *pool = nullptr;
     void *h_scratch = nullptr;
     size_t h_scratch_cap = 0;
+    // two page-locked pieces through which every other copy between the device and host memory that is not page-locked goes (copy_up / copy_down)
+    void *bounce[2] = {nullptr, nullptr};
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     // whitelist dictionary (extract_sr_bc_from_lr) and adapter alignment (extract_lr_bc): lane 0's rows
     DevBuf wl_table, wl_counts, wl_first, wl_skip;
     DevBuf ad_peq, ad_strand, ad_dist, ad_locs, ad_first, ad_last;
@@ -363,6 +366,8 @@ extern "C" int sct_prefix_len(int threads) {
     return k;
 }
 
+extern "C" int sct_host_cpus(void) { return sct_effective_cpus(); }
+
 extern "C" int sct_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -414,6 +419,10 @@ extern "C" void sct_destroy(sct_ctx *c) {
     for (DevBuf *b : bufs) b->release();
     if (c->h_hits) (void)hipHostFree(c->h_hits);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+    for (int i = 0; i < 2; i++) {
+        if (c->bounce[i]) (void)hipHostFree(c->bounce[i]);
+        if (c->bounce_ev[i]) (void)hipEventDestroy(c->bounce_ev[i]);
+    }
     delete c->pool;
     for (RingSlot &s : c->ring)
         if (s.base) (void)hipHostFree(s.base);
@@ -521,6 +530,110 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     return SCT_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Copies between the device and host memory that is NOT page-locked.  Handed to hipMemcpy as it is, such memory is page-locked in
+// place by the runtime for the duration of a large copy (the same mechanism as hipHostRegister, whose use on caller arrays ended
+// soak runs in GPU memory faults in round 4: DESIGN.md 5c) or staged on the calling thread.  So nothing but page-locked memory ever
+// reaches the runtime from this library: other memory goes through two page-locked pieces of the context, filled and emptied by
+// memcpy on the copy pool.  (The stream seam has its own ring: sct_stream.hip.h.)
+// ------------------------------------------------------------------------------------------------------------
+static constexpr size_t BOUNCE_BYTES = (size_t)4 << 20;
+static constexpr size_t BOUNCE_DIRECT_MAX = (size_t)64 << 10;   // up to this size the runtime copies through its own staging buffer
+
+static void par_copy(sct_ctx *c, void *dst, const void *src, size_t bytes);
+
+static bool is_page_locked(const void *p) {
+    hipPointerAttribute_t at;
+    const bool yes = p && hipPointerGetAttributes(&at, p) == hipSuccess && (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice);
+    (void)hipGetLastError();
+    return yes;
+}
+
+static int bounce_ensure(sct_ctx *c) {
+    for (int i = 0; i < 2; i++) {
+        if (!c->bounce[i]) {
+            hipError_t e = inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc(&c->bounce[i], BOUNCE_BYTES, hipHostMallocDefault);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                c->bounce[i] = nullptr;
+                return fail(e == hipErrorOutOfMemory ? SCT_E_NOMEM : SCT_E_HIP, "hipHostMalloc(%zu): %s", BOUNCE_BYTES, hipGetErrorString(e));
+            }
+        }
+        if (!c->bounce_ev[i]) HIPCHK(hipEventCreateWithFlags(&c->bounce_ev[i], hipEventDisableTiming));
+    }
+    return SCT_OK;
+}
+
+// host -> device, queued on st.  Page-locked `src`: queued only (src must stay until st is synchronised).  Other memory: on return
+// src has been read (it may be freed or changed).
+static int copy_up(sct_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (!bytes) return SCT_OK;
+    if (is_page_locked(src)) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        return SCT_OK;
+    }
+    if (bytes <= BOUNCE_DIRECT_MAX) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return SCT_OK;
+    }
+    if (int rc = bounce_ensure(c)) return rc;
+    bool used[2] = {false, false};
+    for (size_t at = 0, i = 0; at < bytes; at += BOUNCE_BYTES, i ^= 1) {
+        const size_t m = bytes - at < BOUNCE_BYTES ? bytes - at : BOUNCE_BYTES;
+        if (used[i]) HIPCHK(hipEventSynchronize(c->bounce_ev[i]));
+        par_copy(c, c->bounce[i], (const char *)src + at, m);
+        HIPCHK(hipMemcpyAsync((char *)dst + at, c->bounce[i], m, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(c->bounce_ev[i], st));
+        used[i] = true;
+    }
+    for (int i = 0; i < 2; i++)
+        if (used[i]) HIPCHK(hipEventSynchronize(c->bounce_ev[i]));   // (the pieces are the context's: the next copy_up may fill them at once)
+    return SCT_OK;
+}
+
+// device -> host, behind everything queued on st.  Page-locked `dst`: queued only.  Other memory: on return dst holds the bytes.
+static int copy_down(sct_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (!bytes) return SCT_OK;
+    if (is_page_locked(dst)) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+        return SCT_OK;
+    }
+    if (bytes <= BOUNCE_DIRECT_MAX) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return SCT_OK;
+    }
+    if (int rc = bounce_ensure(c)) return rc;
+    size_t queued_at[2] = {0, 0}, queued_m[2] = {0, 0};
+    bool used[2] = {false, false};
+    auto drain = [&](int i) -> int {
+        HIPCHK(hipEventSynchronize(c->bounce_ev[i]));
+        par_copy(c, (char *)dst + queued_at[i], c->bounce[i], queued_m[i]);
+        used[i] = false;
+        return SCT_OK;
+    };
+    for (size_t at = 0, i = 0; at < bytes; at += BOUNCE_BYTES, i ^= 1) {
+        const size_t m = bytes - at < BOUNCE_BYTES ? bytes - at : BOUNCE_BYTES;
+        if (used[i])
+            if (int rc = drain((int)i)) return rc;
+        HIPCHK(hipMemcpyAsync(c->bounce[i], (const char *)src + at, m, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(c->bounce_ev[i], st));
+        queued_at[i] = at;
+        queued_m[i] = m;
+        used[i] = true;
+    }
+    // (the older piece first: they were queued in that order)
+    const int first = (used[0] && used[1] && queued_at[1] < queued_at[0]) ? 1 : 0;
+    for (int k = 0; k < 2; k++) {
+        const int i = k == 0 ? first : 1 - first;
+        if (used[i])
+            if (int rc = drain(i)) return rc;
+    }
+    return SCT_OK;
+}
+
 // rev_compl of the reference (scTagger.py:148-156) on raw bytes
 static inline uint8_t comp_byte(uint8_t b) {
     switch (b) {
@@ -570,7 +683,8 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
     }
     if (c->pat.ensure(sizeof(uint2) * (size_t)(np ? np : 1))) return g_code;
     // every copy below reads a host vector of this scope: each path out of the function synchronises the stream first
-    if (np) HIPCHK(hipMemcpyAsync(c->pat.p, pat.data(), sizeof(uint2) * (size_t)np, hipMemcpyHostToDevice, st));
+    if (np)
+        if (int rc = copy_up(c, c->pat.p, pat.data(), sizeof(uint2) * (size_t)np, st)) return rc;
     if (bl >= 8 && bl <= 16) {
         // seed tables (sct_tables.h): counting sort of the pattern ids by key, per family, plus the bucket slots.
         // The thirds families (20/22-bit keys) are only worth their 38 MB of offsets for very large barcode sets.
@@ -603,23 +717,23 @@ extern "C" int sct_set_barcodes(sct_ctx *c, const char *bc, int32_t n, int32_t b
                 rc = g_code;
                 break;
             }
-            hipError_t e = hipMemcpyAsync(c->tab_slot.p, tb.slot.data(), tb.slot.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(c->tab_grp.p, tb.grp.data(), tb.grp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess && ft.pid16 && !pid16.empty())
-                e = hipMemcpyAsync(c->tab_ent16.p, pid16.data(), pid16.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(c->tab_code.p, tb.code.data(), tb.code.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(c->tab_off.p, tb.off.data(), tb.off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(c->tab_ent.p, tb.ent.data(), tb.ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess && !tb.fb.empty())
-                e = hipMemcpyAsync(c->tab_fb.p, tb.fb.data(), tb.fb.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess && !tb.wfb.empty())
-                e = hipMemcpyAsync(c->tab_wfb.p, tb.wfb.data(), tb.wfb.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st);
-            const hipError_t es = hipStreamSynchronize(st);  // also on failure: the vectors above are about to go away
-            if (e == hipSuccess) e = es;
-            if (e != hipSuccess) {
-                rc = fail(SCT_E_HIP, "uploading the seed tables: %s", hipGetErrorString(e));
-                break;
-            }
+            struct Up {
+                void *dst;
+                const void *src;
+                size_t bytes;
+            } ups[] = {{c->tab_slot.p, tb.slot.data(), tb.slot.size() * sizeof(uint64_t)},
+                       {c->tab_grp.p, tb.grp.data(), tb.grp.size() * sizeof(uint32_t)},
+                       {c->tab_ent16.p, pid16.data(), ft.pid16 ? pid16.size() * sizeof(uint16_t) : 0},
+                       {c->tab_code.p, tb.code.data(), tb.code.size() * sizeof(uint32_t)},
+                       {c->tab_off.p, tb.off.data(), tb.off.size() * sizeof(uint32_t)},
+                       {c->tab_ent.p, tb.ent.data(), tb.ent.size() * sizeof(uint32_t)},
+                       {c->tab_fb.p, tb.fb.data(), tb.fb.size() * sizeof(uint16_t)},
+                       {c->tab_wfb.p, tb.wfb.data(), tb.wfb.size() * sizeof(uint16_t)}};
+            for (const Up &u : ups)
+                if (rc == SCT_OK && u.bytes) rc = copy_up(c, u.dst, u.src, u.bytes, st);
+            const hipError_t es = hipStreamSynchronize(st);
+            if (rc == SCT_OK && es != hipSuccess) rc = fail(SCT_E_HIP, "uploading the seed tables: %s", hipGetErrorString(es));
+            if (rc) break;
             c->ft = ft;
             c->have_tables = true;
             c->have_thirds = thirds;
@@ -1183,8 +1297,8 @@ static int upload_segments(sct_ctx *c, const char *segs, const int64_t *offs, in
     l.n_seg = -1;
     l.have_result = false;
     if (int rc = reset_counters(l)) return rc;
-    if (bytes) HIPCHK(hipMemcpyAsync(l.segs.p, segs, (size_t)bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(l.offs64.p, offs, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+    if (int rc = copy_up(c, l.segs.p, segs, (size_t)bytes, st)) return rc;
+    if (int rc = copy_up(c, l.offs64.p, offs, sizeof(int64_t) * (size_t)(n + 1), st)) return rc;
     // validation on the device, before any kernel trusts the offsets: non-decreasing, inside the byte buffer; the host only
     // reads back two words.  Bytes >= 128: see k_validate.
     const int64_t items = (!check_bytes || (n + 1) > (bytes + 15) / 16) ? (n + 1) : (bytes + 15) / 16;
@@ -1239,9 +1353,12 @@ extern "C" int sct_download(sct_ctx *c, uint8_t *min_e, int64_t *hit_offs, uint3
     if (!l.have_result) return fail(SCT_E_STATE, "sct_download without a completed sct_run");
     HIPCHK(hipSetDevice(c->device));
     const int64_t n = l.n_seg;
-    if (min_e && n) HIPCHK(hipMemcpyAsync(min_e, l.min_e.p, (size_t)n, hipMemcpyDeviceToHost, l.stream));
-    if (hit_offs) HIPCHK(hipMemcpyAsync(hit_offs, l.hit_offs.p, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, l.stream));
-    if (hits && l.n_hits) HIPCHK(hipMemcpyAsync(hits, l.hits.p, 4 * (size_t)l.n_hits, hipMemcpyDeviceToHost, l.stream));
+    if (min_e && n)
+        if (int rc = copy_down(c, min_e, l.min_e.p, (size_t)n, l.stream)) return rc;
+    if (hit_offs)
+        if (int rc = copy_down(c, hit_offs, l.hit_offs.p, 8 * (size_t)(n + 1), l.stream)) return rc;
+    if (hits && l.n_hits)
+        if (int rc = copy_down(c, hits, l.hits.p, 4 * (size_t)l.n_hits, l.stream)) return rc;
     HIPCHK(hipStreamSynchronize(l.stream));
     return SCT_OK;
 }
@@ -1410,7 +1527,7 @@ extern "C" int sct_wl_set(sct_ctx *c, const char *keys, const int32_t *key_lens,
     }
     hipStream_t st = c->lane0().stream;
     if (c->wl_table.ensure(tab.size() * sizeof(SctWlSlot))) return g_code;
-    HIPCHK(hipMemcpyAsync(c->wl_table.p, tab.data(), tab.size() * sizeof(SctWlSlot), hipMemcpyHostToDevice, st));
+    if (int rc = copy_up(c, c->wl_table.p, tab.data(), tab.size() * sizeof(SctWlSlot), st)) return rc;
     HIPCHK(hipStreamSynchronize(st));
     c->wl_mask = mask;
     c->wl_len_set = len_set;
@@ -1438,19 +1555,17 @@ extern "C" int sct_wl_count(sct_ctx *c, const char *segs, const int64_t *offs, c
     HIPCHK(hipMemsetAsync(c->wl_counts.p, 0, 4 * nk, st));
     HIPCHK(hipMemsetAsync(c->wl_first.p, 0xFF, 4 * nk, st));
     if (n > 0) {
-        HIPCHK(hipMemcpyAsync(c->wl_skip.p, skip, (size_t)n, hipMemcpyHostToDevice, st));
+        if (int rc = copy_up(c, c->wl_skip.p, skip, (size_t)n, st)) return rc;
         Timer t(c, l, "k_wl_count");
         k_wl_count<<<blocks_for(n, 256), 256, 0, st>>>(l.segs.as<uint8_t>(), l.offs64.as<int64_t>(), c->wl_skip.as<uint8_t>(), n,
                                                       c->wl_table.as<SctWlSlot>(), c->wl_mask, c->wl_len_set,
                                                       c->wl_counts.as<uint32_t>(), c->wl_first.as<uint32_t>());
     }
     std::vector<uint32_t> hc(nk), hf(nk);
-    hipError_t e = hipMemcpyAsync(hc.data(), c->wl_counts.p, 4 * nk, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(hf.data(), c->wl_first.p, 4 * nk, hipMemcpyDeviceToHost, st);
-    const hipError_t es = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = es;
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) return fail(SCT_E_HIP, "whitelist counting failed: %s", hipGetErrorString(e));
+    if (int rc = copy_down(c, hc.data(), c->wl_counts.p, 4 * nk, st)) return rc;
+    if (int rc = copy_down(c, hf.data(), c->wl_first.p, 4 * nk, st)) return rc;
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
     collect_timing(c, l);
     for (int32_t i = 0; i < c->wl_n; i++) {
         counts[i] = hc[(size_t)i];
@@ -1540,10 +1655,15 @@ extern "C" int sct_adapter_align(sct_ctx *c, const char *adapter, int32_t m, con
     }
     if (n == 0) loc_offs[0] = 0;
     if (e == hipSuccess && n > 0) {
-        e = hipMemcpyAsync(strand, c->ad_strand.p, (size_t)n, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(dist, c->ad_dist.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(loc_offs, l.hit_offs.p, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && total) e = hipMemcpyAsync(h, c->ad_locs.p, 4 * (size_t)total, hipMemcpyDeviceToHost, st);
+        int rc2 = copy_down(c, strand, c->ad_strand.p, (size_t)n, st);
+        if (!rc2) rc2 = copy_down(c, dist, c->ad_dist.p, 4 * (size_t)n, st);
+        if (!rc2) rc2 = copy_down(c, loc_offs, l.hit_offs.p, 8 * (size_t)(n + 1), st);
+        if (!rc2 && total) rc2 = copy_down(c, h, c->ad_locs.p, 4 * (size_t)total, st);
+        if (rc2) {
+            (void)hipStreamSynchronize(st);
+            free(h);
+            return rc2;
+        }
     }
     {
         const hipError_t es = hipStreamSynchronize(st);

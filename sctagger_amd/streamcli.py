@@ -116,30 +116,39 @@ last_inflate_stats = {}     # what the last gzip input was decoded with (for SCT
 def effective_cpus():
     """CPUs this process may really use: its affinity mask, cut down to the CPU quota of its cgroup (v2 cpu.max, v1 cfs quota) —
     a container on a 256-thread host may own 16 of them, and a pool sized by the 256 spends its quota in the first milliseconds of
-    every scheduler period and is then suspended, the thread that feeds the device included.  SCT_CPUS overrides."""
+    every scheduler period and is then suspended, the thread that feeds the device included.  SCT_CPUS overrides that count.
+    One process per GPU (LOCAL_WORLD_SIZE ranks on this node: torchrun, shard.launch_ranks): a rank takes its share of them —
+    eight ranks on a 16-CPU quota size their pools by 2.  (csrc/sct_copy_pool.h sct_effective_cpus is the same rule in C.)"""
     env = os.environ.get("SCT_CPUS")
     if env:
-        return max(1, int(env))
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
-    quota = None
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            q, p = f.read().split()[:2]
-            if q != "max":
-                quota = float(q) / float(p)
-    except Exception:
+        cores = max(1, int(env))
+    else:
         try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
-                q, p = float(f.read()), float(g.read())
-                if q > 0 and p > 0:
-                    quota = q / p
+            cores = len(os.sched_getaffinity(0))
         except Exception:
-            pass
-    if quota:
-        cores = min(cores, max(1, int(quota + 0.5)))
+            cores = os.cpu_count() or 1
+        quota = None
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as f:
+                q, p = f.read().split()[:2]
+                if q != "max":
+                    quota = float(q) / float(p)
+        except Exception:
+            try:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    q, p = float(f.read()), float(g.read())
+                    if q > 0 and p > 0:
+                        quota = q / p
+            except Exception:
+                pass
+        if quota:
+            cores = min(cores, max(1, int(quota + 0.5)))
+    try:
+        ranks = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        ranks = 1
+    if ranks > 1:
+        cores //= ranks
     return max(1, cores)
 
 
@@ -424,6 +433,9 @@ class _Device(threading.Thread):
         try:
             self.m = _native.Matcher(self.device)
             self.m.set_option("timing", 0)      # (no per-kernel HIP events: a call on a block of 10^5 rows is a dozen launches)
+            # a worker's first blocks may come in ordinary arrays (parsed before the context existed): through the context's page-locked
+            # ring, copied by the worker itself — the command's CPUs are spoken for (parse / render / gzip workers)
+            self.m.set_option("copy_threads", 0)
             self.have_bc.wait()
             if self.bc is not None:
                 self.m.set_barcodes(self.bc, self.bl)
@@ -467,7 +479,7 @@ class _Worker(threading.Thread):
 
     def _ensure(self, nbytes):
         # Ordinary (pageable) arrays at first, so that parsing does not have to wait for the device context (the library
-        # page-locks them for the duration of each call, option "register"); once the context exists the worker moves to
+        # moves them through its page-locked ring: nothing of ours is page-locked or handed to the runtime); once the context exists the worker moves to
         # page-locked arrays of its own (sct_host_alloc), which the kernels read and write in place without any per-call
         # registration: a call on a 16 MB block took 5.7 ms, 13 ns per row, where the device needs half a nanosecond.
         want_pinned = self.dev.ready.is_set() and self.dev.error is None and self.dev.m is not None

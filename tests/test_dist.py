@@ -64,6 +64,43 @@ import json
 import pytest
 
 
+RANK_POOLS = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    from sctagger_amd import _native, shard, streamcli
+    rank, local_rank, world = shard.rank_info()
+    print(json.dumps({"rank": rank, "world": world, "python": streamcli.effective_cpus(), "library": _native.host_cpus(),
+                      "inflate": streamcli.inflate_threads()}), flush=True)
+""") % ROOT
+
+
+def test_eight_ranks_share_the_cpu_quota(tmp_path, capfd):
+    """shard.launch_ranks(8, ...) on a node that grants 16 CPUs (SCT_CPUS=16): every rank sizes its pools —
+    the command's workers (streamcli.effective_cpus) and the library's copy threads (sct_host_cpus) — by its share, 2; nothing
+    touches a GPU here.  (The reference's own fan-out is Pool(threads), /root/reference/scTagger.py:703-704: one size for all.)"""
+    script = tmp_path / "pools.py"
+    script.write_text(RANK_POOLS)
+    env = {k: v for k, v in os.environ.items() if k not in ("SCT_INFLATE_THREADS", "LOCAL_WORLD_SIZE")}
+    env["SCT_CPUS"] = "16"
+    assert shard_mod().launch_ranks(8, str(script), [], env=env, timeout=300) == 0
+    out = capfd.readouterr().out
+    seen = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert sorted(d["rank"] for d in seen) == list(range(8)), out
+    for d in seen:
+        assert d["world"] == 8 and d["python"] == 2 and d["library"] == 2 and 1 <= d["inflate"] <= 2, d
+    # and one process alone takes them all
+    one = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, timeout=120)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    d = json.loads(one.stdout.decode().splitlines()[-1])
+    assert d["python"] == 16 and d["library"] == 16, d
+
+
+def shard_mod():
+    sys.path.insert(0, ROOT)
+    from sctagger_amd import shard
+    return shard
+
+
 @pytest.mark.gpu
 def test_two_ranks_on_the_device(tmp_path):
     """bench.py's N = 2 path with the DEVICE in both ranks (they share GPU 0 on a one-GPU box): torchrun launch, gloo
