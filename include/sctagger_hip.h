@@ -107,8 +107,9 @@ void sct_free_hits(sct_ctx *ctx, uint32_t *hits);
  *   "copy_threads") moves chunk k+1 into a slot — the offsets narrowed to one byte per row on the way — while the zero-copy kernels
  *   read chunk k from its slot and chunk k-1's min_e / counts are widened into the caller's arrays.  Nothing of the caller's is
  *   page-locked, and no caller pointer is given to the HIP runtime.  6 - 7 ms per 10 M rows of 22 characters against 4.8 ms on
- *   page-locked arrays and 20 ms through the runtime's staged copies (option "ring" = 0, which also covers page-locked buffers with
- *   "zero_copy" = 0: chunks of "chunk_rows" rows uploaded on "lanes" streams).
+ *   page-locked arrays, 11 - 13 ms with the ring off (option "ring" = 0: the same memory through two 4 MB bounce pieces on the
+ *   calling thread) and 20 ms through the runtime's own staged copies, which round 4 used.  Page-locked buffers with "zero_copy" = 0
+ *   are uploaded in chunks of "chunk_rows" rows on "lanes" streams.
  *   Limits: row counts, seg_bytes, hit offsets and the hit total are 64-bit throughout (the reference's own c_int index,
  *   scTagger.py:618, ends at 2^31 segment bytes); sct_upload_segments takes at most 2^31 - 16 rows per call.  Tested: 20 M rows
  *   in one call at the default chunking, 4.5 GB of segment bytes in one call, and 4.43 x 10^9 hits (> 2^32; a 17.7 GB
@@ -201,8 +202,9 @@ int sct_sync(sct_ctx *ctx);
  *                            (one coalesced pass, k_special_gather) before the special launch cuts them into windows; 0: its
  *                            window lanes read them over the link.  Same results.
  *   "ring"             0|1   1 (default): a stream call whose segs are NOT page-locked goes through the context's page-locked ring
- *                            (above); 0: through the runtime's staged copies, which page-lock the caller's pages in place for the
- *                            duration of each large copy.  (Round 4 had an option "register" that page-locked the caller's arrays
+ *                            (above); 0: chunk by chunk through the context's two bounce pieces, on the calling thread.  Either way
+ *                            the HIP runtime is given page-locked memory only: handed pageable memory, it page-locks the caller's
+ *                            pages in place for the duration of each large copy.  (Round 4 had an option "register" that page-locked the caller's arrays
  *                            for the whole call, hipHostRegister, so that the kernels read them in place: one soak run in a few ended
  *                            in "Memory access fault by GPU" on a host address, cause never established.  Removed in round 5: the
  *                            ring is faster than it was and locks nothing of the caller's.)

@@ -13,6 +13,7 @@
  * n + n / 1000 + 64 bytes.  tests/test_fastio.py and tools/fuzz_inflate.c decode what this writes with zlib and with the
  * command's own decoders.
  */
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,10 +36,9 @@ static const uint8_t fd_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 
 
 static uint8_t fd_len_code[256];     /* length - 3 -> length code 0..28 */
 static uint8_t fd_dist_code[512];    /* distance - 1 below 256 -> code; 256 + ((distance - 1) >> 7) for the others */
-static int fd_tables_ready = 0;
+static pthread_once_t fd_tables_once = PTHREAD_ONCE_INIT;
 
-static void fd_init_tables(void) {
-    if (fd_tables_ready) return;
+static void fd_fill_tables(void) {
     for (int c = 0; c < 29; c++) {
         const int hi = c == 28 ? 258 : fd_len_base[c] + (1 << fd_len_extra[c]) - 1;
         for (int l = fd_len_base[c]; l <= hi && l <= 258; l++) fd_len_code[l - 3] = (uint8_t)c;
@@ -51,8 +51,9 @@ static void fd_init_tables(void) {
             else fd_dist_code[256 + (d >> 7)] = (uint8_t)c;
         }
     }
-    __atomic_store_n(&fd_tables_ready, 1, __ATOMIC_RELEASE);
 }
+/* (every compressing thread calls this first; pthread_once orders the table writes before every reader) */
+static void fd_init_tables(void) { pthread_once(&fd_tables_once, fd_fill_tables); }
 static inline int fd_dcode(uint32_t dist_minus_1) { return dist_minus_1 < 256 ? fd_dist_code[dist_minus_1] : fd_dist_code[256 + (dist_minus_1 >> 7)]; }
 
 /* ---- Huffman code lengths (limited to `maxlen` bits) from frequencies ------------------------------------------------------- */

@@ -45,8 +45,12 @@ int64_t sctio_inflate_run(void *p, uint8_t *out, int64_t cap, int32_t *status, i
  * CRC-32 (the gzip polynomial), slice by 8, and the combination of two CRCs (what zlib calls crc32_combine)
  * ------------------------------------------------------------------------------------------------------------------------- */
 static uint32_t crc_tab[8][256];
+static int crc_can_fold = 0;   /* the CPU has carry-less multiplication (crc_fold below); set once, in crc_init */
 static pthread_once_t crc_once = PTHREAD_ONCE_INIT;
 static void crc_init(void) {
+#if defined(__x86_64__)
+    crc_can_fold = (__builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1")) ? 1 : 0;
+#endif
     for (uint32_t i = 0; i < 256; i++) {
         uint32_t c = i;
         for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
@@ -124,7 +128,6 @@ __attribute__((target("pclmul,sse4.1"))) static uint32_t crc_fold(uint32_t c, co
     x1 = _mm_xor_si128(x1, x2);
     return (uint32_t)_mm_extract_epi32(x1, 1);
 }
-static int crc_can_fold = -1;
 #endif
 
 uint32_t sctio_crc32(uint32_t crc, const uint8_t *p, int64_t n) {
@@ -132,7 +135,6 @@ uint32_t sctio_crc32(uint32_t crc, const uint8_t *p, int64_t n) {
     uint32_t c = ~crc;
 #if defined(__x86_64__)
     if (n >= 256) {
-        if (crc_can_fold < 0) crc_can_fold = (__builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1")) ? 1 : 0;
         if (crc_can_fold) {
             const int64_t m = n & ~(int64_t)15;
             c = crc_fold(c, p, m);
@@ -635,11 +637,22 @@ static int precode_complete(const uint8_t *in, int64_t in_len, int64_t at) {
     return kraft == 128u;
 }
 
+/* Symbols (bytes) a piece may hold before it ends at the next block boundary: sixteen times the chunk's compressed bytes — a
+ * -lr file compresses 4 : 1, so an ordinary chunk is decoded whole — and never more than 128 M.  (Until round 5: 256 times + 64 M —
+ * a stream of zeros, or a crafted one, made pieces of gigabytes, several of them in flight, where the serial decoder works in
+ * constant memory.  What a piece does not take, the chain hands to its serial decoder or to the next piece.) */
+static int64_t piece_limit(const pinf_t *h) {
+    int64_t lim = h->chunk_bytes * 16;
+    if (lim < ((int64_t)8 << 20)) lim = (int64_t)8 << 20;
+    if (lim > ((int64_t)128 << 20)) lim = (int64_t)128 << 20;
+    return lim;
+}
+
 /* pass 1 of chunk k (no lock held) */
 static void pass1(pinf_t *h, int k, sct_inf *s, symbuf b, int64_t hint) {
     chunk_t *c = &h->chunks[k];
     const int64_t first = chunk_first_bit(h, k), stop = k + 1 < h->n_chunks ? chunk_first_bit(h, k + 1) : INT64_MAX;
-    const int64_t max_out = h->chunk_bytes * 256 + (64 << 20);
+    const int64_t max_out = piece_limit(h);
     c->found = 0;
     c->ended = 0;
     if (k == 0) {
@@ -733,7 +746,7 @@ static void redo(pinf_t *h, int64_t from_bit, int64_t target, const uint8_t *win
     memset(r, 0, sizeof(*r));
     sctinf_start_at(s, h->in, h->in_len, from_bit, win, win_fill);
     s->stop_bit = target;
-    const int64_t limit = h->chunk_bytes * 256 + (64 << 20);   /* pieces are handed over whole: not unboundedly large */
+    const int64_t limit = piece_limit(h);   /* pieces are handed over whole: not unboundedly large */
     int64_t cap = 8 << 20, n = 0;
     uint8_t *buf = (uint8_t *)malloc((size_t)(SCTIO_PIECE_HEAD + cap + WINDOW));
     int32_t st = 0;
@@ -775,6 +788,13 @@ static void *worker(void *arg) {
     pinf_t *h = (pinf_t *)arg;
     sct_inf *s = (sct_inf *)sctio_inflate_new();
     pthread_mutex_lock(&h->mu);
+    if (!s && !h->chain_done) {
+        /* no memory for this thread's decoder state: if every worker ended up here nobody would ever finish the chain and the
+         * consumer would wait for ever — the stream fails instead, like any other allocation on the way */
+        h->chain_error = -4;
+        h->chain_done = 1;
+        pthread_cond_broadcast(&h->cv);
+    }
     for (;;) {
         if (h->stop || !s) break;
         chain_advance(h);

@@ -25,7 +25,9 @@
 //   STAGED      page-locked buffers with the option "zero_copy" = 0, or pageable ones with "ring" = 0: the rows are uploaded in
 //               chunks (option "chunk_rows") that move through L lanes (option "lanes", default 5)
 //                 lane k mod L:   H2D(chunk k) -> index / byte checks -> filter launches -> offsets -> fill -> D2H(results)
-//               (measured: DESIGN.md 5b — 6.6 - 8.2 ms per 10 M rows page-locked where zero copy needs 4.8; pageable 20 ms).
+//               (measured: DESIGN.md 5b — 6.6 - 8.2 ms per 10 M rows page-locked where zero copy needs 4.8).  Memory that is not
+//               page-locked goes through the context's two bounce pieces here as everywhere else (copy_up / copy_down), one piece
+//               after the other on the calling thread: 11 - 13 ms per 10 M rows — the ring route without its pipeline.
 #pragma once
 #include <memory>
 
@@ -257,6 +259,7 @@ struct StreamCall {
     void *zc_counts = nullptr;
     uint32_t *zc_hits = nullptr;
     uint16_t *zc_hits16 = nullptr;
+    bool pl_min_e = false, pl_counts = false;   // the caller's min_e / counts arrays are page-locked (a copy to them may be left queued)
     // the plan
     bool ring = false;
     bool ramp = false;       // ring route: the chunks grow from an eighth of `chunk` rows to `chunk` rows
@@ -317,6 +320,8 @@ int StreamCall::choose_route() {
         zc_min_e = (uint8_t *)mapped_view(min_e, (size_t)n);
         zc_counts = count_format == SCT_CNT_OFFS64 ? nullptr : (void *)mapped_view(counts, counts_bytes);
     }
+    pl_min_e = is_page_locked(min_e) && is_page_locked(min_e + (n ? n - 1 : 0));
+    pl_counts = is_page_locked(counts) && is_page_locked((const char *)counts + (counts_bytes ? counts_bytes - 1 : 0));
     hipPointerAttribute_t at;
     const bool pinned = zc_segs != nullptr || (segs && hipPointerGetAttributes(&at, segs) == hipSuccess && at.type == hipMemoryTypeHost);
     (void)hipGetLastError();
@@ -340,8 +345,8 @@ int StreamCall::choose_route() {
         // Zero copy: ONE launch over as many rows as possible — a launch begins with every resident wave asking for its rows at
         // once and ends with compute only, about a quarter of a millisecond in which link and chip do not overlap
         // (1 M-row launches: 0.58 ms each against 0.43 ms per 1 M rows of a 10 M-row launch).  Uploaded page-locked segments:
-        // 2^20 rows per chunk keep the lanes busy.  Pageable segments with the ring switched off: every copy is staged by the
-        // runtime and blocks this thread, so nothing overlaps anyway, and few large copies are staged faster than many small ones.
+        // 2^20 rows per chunk keep the lanes busy.  Pageable segments with the ring switched off: every copy goes through the bounce
+        // pieces on this thread, so nothing overlaps anyway: one chunk.
         chunk = zc_segs ? (int64_t)1 << 24 : pinned ? (int64_t)1 << 20 : (int64_t)1 << 24;
         // the offsets on the device are 32-bit and relative to the chunk
         const int64_t by_bytes = seg_bytes / ((int64_t)3 << 30) + 1;
@@ -488,9 +493,12 @@ int StreamCall::phase_a(int64_t k, const ChunkIO &io) {
         l.host_segs = nullptr;
     }
     if (!io.segs_dev || !io.idx_dev) {
+        // (page-locked memory: queued; anything else goes through the context's bounce pieces — copy_up — and has been read on return)
         Timer t(c, l, "copy_h2d");
-        if (!io.segs_dev && bytes) HIPCHK(hipMemcpyAsync(l.segs.p, io.segs_src, (size_t)bytes, hipMemcpyHostToDevice, st));
-        if (!io.idx_dev) HIPCHK(hipMemcpyAsync(l.index_in.p, io.idx_src, esz * (size_t)(offs_index ? m + 1 : m), hipMemcpyHostToDevice, st));
+        if (!io.segs_dev && bytes)
+            if (int rc_ = copy_up(c, l.segs.p, io.segs_src, (size_t)bytes, st)) return rc_;
+        if (!io.idx_dev)
+            if (int rc_ = copy_up(c, l.index_in.p, io.idx_src, esz * (size_t)(offs_index ? m + 1 : m), st)) return rc_;
     }
     {
         Timer t(c, l, "k_index");
@@ -524,6 +532,9 @@ int StreamCall::phase_a(int64_t k, const ChunkIO &io) {
         }
     }
     l.index_just_timed = c->timing;   // the span "k_index" was the last thing queued: "k_filter" starts where it ended
+    l.record_filters_done = c->chunk_order && !ring && n_chunks > 1;
+    l.wait_for = (l.record_filters_done && k > 0) ? lane_of(k - 1).filters_done : nullptr;
+    if (l.wait_for) l.index_just_timed = false;   // (a wait sits between the two spans)
     if (int rc_ = queue_batch(c, l)) return rc_;
     if (ring) {
         // the way out seeds its prefix sums with the device's block sums (hits in front of every SCAN_BLOCK rows of the chunk)
@@ -531,10 +542,11 @@ int StreamCall::phase_a(int64_t k, const ChunkIO &io) {
         const int64_t nb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
         if (slot_counts && count_format == SCT_CNT_OFFS64 && nb > 0)
             HIPCHK(hipMemcpyAsync(s.base + s.o_sums, l.sums.p, 8 * (size_t)nb, hipMemcpyDeviceToHost, st));
-    } else if (!l.direct_min_e || (!l.direct_cnt && count_format != SCT_CNT_OFFS64)) {
+    } else if ((!l.direct_min_e && pl_min_e) || (!l.direct_cnt && count_format != SCT_CNT_OFFS64 && pl_counts)) {
+        // results into page-locked arrays of the caller's: queued behind the kernels (other arrays: phase B, through the bounce pieces)
         Timer t(c, l, "copy_d2h");
-        if (!l.direct_min_e) HIPCHK(hipMemcpyAsync(io.min_e_dst, l.min_e.p, (size_t)m, hipMemcpyDeviceToHost, st));
-        if (!l.direct_cnt && count_format != SCT_CNT_OFFS64)
+        if (!l.direct_min_e && pl_min_e) HIPCHK(hipMemcpyAsync(io.min_e_dst, l.min_e.p, (size_t)m, hipMemcpyDeviceToHost, st));
+        if (!l.direct_cnt && count_format != SCT_CNT_OFFS64 && pl_counts)
             HIPCHK(hipMemcpyAsync(io.cnt_dst, l.cnt_out.p, (count_format == SCT_CNT_U8 ? 1 : 4) * (size_t)m, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipEventRecord(l.done, st));
@@ -558,16 +570,17 @@ int StreamCall::phase_b(int64_t k) {
         Timer t(c, l, "copy_d2h");
         if (!ring) {
             const ChunkIO io = caller_io(k);
-            if (slow) {  // what phase A copied was not final
-                if (!l.direct_min_e) HIPCHK(hipMemcpyAsync(io.min_e_dst, l.min_e.p, (size_t)m, hipMemcpyDeviceToHost, st));
-                if (!l.direct_cnt && count_format != SCT_CNT_OFFS64)
-                    HIPCHK(hipMemcpyAsync(io.cnt_dst, l.cnt_out.p, (count_format == SCT_CNT_U8 ? 1 : 4) * (size_t)m, hipMemcpyDeviceToHost, st));
-            }
+            // what phase A copied (into page-locked arrays) was not final if the slow path ran; arrays that are not page-locked get
+            // theirs here, through the context's bounce pieces (copy_down: back when the bytes have arrived)
+            if (!l.direct_min_e && (slow || !pl_min_e))
+                if (int rc_ = copy_down(c, io.min_e_dst, l.min_e.p, (size_t)m, st)) return rc_;
+            if (!l.direct_cnt && count_format != SCT_CNT_OFFS64 && (slow || !pl_counts))
+                if (int rc_ = copy_down(c, io.cnt_dst, l.cnt_out.p, (count_format == SCT_CNT_U8 ? 1 : 4) * (size_t)m, st)) return rc_;
             if (count_format == SCT_CNT_OFFS64) {
                 // the chunk's offsets start at 0: add the hits of the chunks before it, then copy (the last entry of a chunk
                 // and the first of the next are the same element of the caller's array, with the same value)
                 if (hit_base) k_rebase<<<blocks_for(m + 1, 256), 256, 0, st>>>(l.hit_offs.as<int64_t>(), m + 1, hit_base);
-                HIPCHK(hipMemcpyAsync((int64_t *)counts + cp.r0, l.hit_offs.p, 8 * (size_t)(m + 1), hipMemcpyDeviceToHost, st));
+                if (int rc_ = copy_down(c, (int64_t *)counts + cp.r0, l.hit_offs.p, 8 * (size_t)(m + 1), st)) return rc_;
             }
         }
         if (hits16) {

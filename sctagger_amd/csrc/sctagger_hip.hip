@@ -159,6 +159,9 @@ struct BatchParams {
 struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t filters_done = nullptr;   // option "chunk_order": recorded behind a chunk's filter launches ...
+    hipEvent_t wait_for = nullptr;       // ... and what the next chunk's filter launches wait for (set per batch by the stream call)
+    bool record_filters_done = false;
     uint32_t *h_ctr = nullptr;  // page-locked copy of the counter record
     // rows
     int64_t n_seg = -1, seg_bytes = 0;
@@ -214,6 +217,8 @@ struct Lane {
         for (hipEvent_t e : pool) (void)hipEventDestroy(e);
         pool.clear();
         if (done) (void)hipEventDestroy(done);
+        if (filters_done) (void)hipEventDestroy(filters_done);
+        filters_done = nullptr;
         if (h_ctr) (void)hipHostFree(h_ctr);
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
@@ -276,6 +281,7 @@ struct sct_ctx {
     bool use_ring = true;      // stream API: pageable caller arrays go through the context's page-locked ring (sct_stream.hip.h)
     int ring_slots = 0;        // slots of the ring; 0 = lanes in use + 2
     int ring_lanes = 3;        // chunks of the ring route in flight on the device
+    bool chunk_order = false;  // zero-copy / staged chunks: a chunk's filter launches wait for the previous chunk's (experiment)
     int64_t ring_rows = 0;     // rows per chunk of the ring route; 0 = 2^20 (fewer for small calls)
     bool ring_ramp = true;     // ... reached by doubling from an eighth of that: the device starts early
     int copy_threads = -1;     // threads of the copy pool; -1 = half of the CPUs the process may use, at most 8
@@ -343,6 +349,7 @@ static int lane_create(Lane **out) {
     Lane *l = new Lane();
     hipError_t e = inject_alloc_failure() ? hipErrorOutOfMemory : hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&l->done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l->filters_done, hipEventDisableTiming);
     if (e == hipSuccess) e = inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc((void **)&l->h_ctr, sizeof(uint32_t) * CTR_WORDS, hipHostMallocDefault);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -503,6 +510,7 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "gather")) c->no_gather = value == 0;
     else if (!strcmp(key, "ring")) c->use_ring = value != 0;
     else if (!strcmp(key, "ring_ramp")) c->ring_ramp = value != 0;
+    else if (!strcmp(key, "chunk_order")) c->chunk_order = value != 0;
     else if (!strcmp(key, "ring_lanes")) {
         if (value < 1 || value > STREAM_LANES_MAX) return fail(SCT_E_ARG, "ring_lanes must be in 1 .. %d", STREAM_LANES_MAX);
         c->ring_lanes = (int)value;
@@ -837,6 +845,8 @@ static int lane_ensure(Lane &l, int64_t n, const BatchParams &bp) {
     l.hits16_ptr = nullptr;
     l.direct_min_e = l.direct_cnt = l.direct_hits = false;
     l.cnt8_soft = false;
+    l.record_filters_done = false;
+    l.wait_for = nullptr;
     return SCT_OK;
 }
 
@@ -1043,10 +1053,15 @@ static int queue_batch(sct_ctx *c, Lane &l) {
     const int64_t n = l.n_seg;
     hipStream_t st = l.stream;
     l.have_result = false;
+    if (l.wait_for) {   // option "chunk_order": this chunk's filter launches behind the previous chunk's (its fill then runs beside them)
+        HIPCHK(hipStreamWaitEvent(st, l.wait_for, 0));
+        l.wait_for = nullptr;
+    }
     if (n > 0) {
         if (bp.filter_ok) {
             if (l.wide) queue_filter_launches<int64_t>(c, l, l.offs64.as<int64_t>());
             else queue_filter_launches<uint32_t>(c, l, l.offs32.as<uint32_t>());
+            if (l.record_filters_done) HIPCHK(hipEventRecord(l.filters_done, st));
         } else {
             Timer t(c, l, "k_route");
             if (l.wide)

@@ -93,6 +93,36 @@ def test_devices_threads_against_goldens(name, e, t):
         assert util.render(bcs, names, segs, offs, *three) == f.read()
 
 
+def test_contexts_are_kept_between_seam_calls():
+    """match_trie keeps one context per `devices` entry alive; the seed tables are rebuilt only when the barcode
+    set changes (the reference re-creates its Pool on every call, /root/reference/scTagger.py:703)."""
+    match_trie.release_contexts()
+    bc_a, bc_b = synth.make_barcodes(3000, seed=61), synth.make_barcodes(2000, seed=62)
+    segs, offs = synth.make_segments(20_000, bc_a, seed=61)
+    names = ["r%d" % i for i in range(offs.size - 1)]
+    want = {}
+    with _native.Matcher(0) as m:
+        for key, bc in (("a", bc_a), ("b", bc_b)):
+            m.set_barcodes(bc)
+            want[key] = m.match(segs, offs, 2, 16)
+    as_text = lambda bc: [b.tobytes().decode() for b in bc]
+    seen = []
+    for key, bc in (("a", bc_a), ("a", bc_a), ("b", bc_b), ("a", bc_a)):
+        match_trie.set_inputs(as_text(bc), names, segs, offs)
+        spans = {}
+        got = match_trie.run_get_matches_prefix_arrays(2, 16, devices=(0, 0), spans=spans)
+        util.assert_same(got, want[key], "barcode set %s through kept contexts" % key)
+        seen.append([(t["context_s"], t["set_barcodes_s"]) for t in spans["threads"]])
+        del got
+    ctxs = dict(match_trie._contexts)
+    assert sorted(ctxs) == [(0, 0), (0, 1)] and all(c.m is not None for c in ctxs.values())
+    # the second call found contexts and tables in place: nothing but hashing the barcodes
+    assert all(c < 1e-3 and b < 0.005 for c, b in seen[1]), seen
+    assert all(c < 1e-3 for c, _ in seen[2]) and any(b > seen[1][0][1] for _, b in seen[2]), seen    # new barcodes: tables rebuilt, contexts kept
+    match_trie.release_contexts()
+    assert not match_trie._contexts and all(c.m is None for c in ctxs.values())
+
+
 def test_cli_devices_flag(tmp_path):
     g = util.GOLDEN
     for name, e, t, exp in (("g2", 2, 5, "g2.e2.t5.expected.tsv"), ("g12", 2, 16, "g12.e2.t16.expected.tsv")):

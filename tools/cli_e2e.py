@@ -66,7 +66,7 @@ def _crc32_combine(crc1, crc2, len2):
     return int(streamcli._iolib().sctio_crc32_combine(crc1, crc2, len2))
 
 
-def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_rows=20000, quiet=False, extra=(), plain=False, level=1, runs=2):
+def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_rows=20000, quiet=False, extra=(), plain=False, level=1, runs=3):
     """-> dict with the CLI's wall time over n rows x 25 k barcodes (gz TSV in, gz TSV out) and the sample check.
     level = gzip level of the -lr file (the reference's producer writes level 9, gzip.open's default: scTagger.py:377)."""
     import bench
@@ -91,18 +91,21 @@ def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_
     if not quiet:
         print("inputs written in %.1fs: %s (%.0f MB raw, %.0f MB gz at level %d)" % (time.time() - t0, lr, raw / 1e6, gz / 1e6, level), flush=True)
     out = os.path.join(work, "out.tsv.gz")
-    walls = []
-    for _ in range(runs):          # the second run has the input file and the libraries in the page cache
+    walls, timings = [], []
+    for i in range(runs):          # (from the second run on the input file and the libraries are in the page cache)
         try:
             os.remove(out)         # (a fresh output file, as in a first run)
         except OSError:
             pass
+        err = os.path.join(work, "cli.%d.err" % i)
         t0 = time.time()
         subprocess.check_call([sys.executable, os.path.join(ROOT, "scTagger.py"), "match_trie", "-lr", lr, "-sr", sr, "-mr", "2", "-t", "16", "-o", out] + list(extra),
-                              stderr=open(os.path.join(work, "cli.err"), "w"), env=dict(os.environ, SCT_CLI_TIMING="1"))
+                              stderr=open(err, "w"), env=dict(os.environ, SCT_CLI_TIMING="1"))
         walls.append(time.time() - t0)
-    wall = min(walls)
-    timing = [l.strip() for l in open(os.path.join(work, "cli.err")) if "timing" in l]
+        timings.append([l.strip() for l in open(err) if "timing" in l])
+    # the MEDIAN run is the one quoted (two runs of one build differed by 43 %), with ITS timing lines
+    quoted = sorted(range(runs), key=lambda i: walls[i])[(runs - 1) // 2]
+    wall, timing = walls[quoted], timings[quoted]
     out_bytes = os.path.getsize(out)
     # rows out, and the first rows against the oracle (the output is read back in pieces: 100 M rows are 4 GB of text)
     from oracle import trie_oracle
@@ -131,7 +134,7 @@ def run(n=10_000_000, work="/tmp/sct_e2e", bc=None, segs=None, offs=None, check_
             "segments_per_s": n / wall, "in_raw_MB": round(raw / 1e6), "in_gz_MB": round(gz / 1e6, 1) if not plain else None, "in_gzip_level": None if plain else level,
             "out_gz_MB": round(out_bytes / 1e6, 1), "sample_checked_rows": k, "extra_args": list(extra), "timing_lines": timing[-5:],
             "what": "scTagger.py match_trie -lr lr.tsv%s -sr sr.tsv -mr 2 -t 16 -o out.tsv.gz in a child process (python start-up, "
-                    "gunzip + parse, match, render + gzip), best of %d runs" % ("" if plain else ".gz", runs)}
+                    "gunzip + parse, match, render + gzip); wall_s = the median of %d runs, timing_lines = that run's" % ("" if plain else ".gz", runs)}
 
 
 if __name__ == "__main__":

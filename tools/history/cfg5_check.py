@@ -3,7 +3,7 @@
 the exhaustive scan on a sub-sample, and a timing of the filter path on a larger batch."""
 import sys, os, time, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root (this file lives in tools/history/)
 from sctagger_amd import _native, synth
 import bench
 

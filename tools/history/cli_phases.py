@@ -4,7 +4,7 @@
 import gzip, json, os, sys, time, zlib
 t_start = time.perf_counter()
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # this file lives in tools/history/
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from sctagger_amd import _native, fastio, synth, match_trie

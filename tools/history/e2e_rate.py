@@ -4,7 +4,7 @@ page-locked buffers, by chunk size and transfer format; and the resident-input r
 numbers of record come from bench.py."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root (this file lives in tools/history/)
 from sctagger_amd import _native, synth
 import bench
 

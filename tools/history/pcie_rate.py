@@ -3,7 +3,7 @@
 bench workload. Reported in DESIGN.md; never the bench's `value`."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repository root (this file lives in tools/history/)
 from sctagger_amd import _native, synth
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 cd /tmp && export TMPDIR=/tmp
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD" "GRBM_GUI_ACTIVE" "TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-30)
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/$out/pmc_$name -o pmc -- python3 $R/tools/cliff_probe.py $n $nbc $e > $R/$out/pmc_$name.json 2> $R/$out/pmc_$name.err || tail -3 $R/$out/pmc_$name.err
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/$out/pmc_$name -o pmc -- python3 $R/tools/history/cliff_probe.py $n $nbc $e > $R/$out/pmc_$name.json 2> $R/$out/pmc_$name.err || tail -3 $R/$out/pmc_$name.err
 done
 python3 - <<PY
 import csv, glob, collections

@@ -4,7 +4,7 @@ set -o pipefail
 out=gpurun_out/wide; mkdir -p $out
 for nbc in ${SIZES:-3600000 1000000 400000 100000}; do
   for w in 0 1; do
-    SCT_WIDE=$w timeout -k 10 300 python tools/cliff_probe.py 1000000 $nbc 2 2000 > $out/w${w}_$nbc.json 2> $out/w${w}_$nbc.err || { tail -5 $out/w${w}_$nbc.err; exit 1; }
+    SCT_WIDE=$w timeout -k 10 300 python tools/history/cliff_probe.py 1000000 $nbc 2 2000 > $out/w${w}_$nbc.json 2> $out/w${w}_$nbc.err || { tail -5 $out/w${w}_$nbc.err; exit 1; }
     python - $out/w${w}_$nbc.json <<'PY'
 import json, sys
 l = open(sys.argv[1]).read().strip().split("\n")
