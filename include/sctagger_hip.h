@@ -208,10 +208,11 @@ int sct_sync(sct_ctx *ctx);
  *                            for the whole call, hipHostRegister, so that the kernels read them in place: one soak run in a few ended
  *                            in "Memory access fault by GPU" on a host address, cause never established.  Removed in round 5: the
  *                            ring is faster than it was and locks nothing of the caller's.)
- *   "ring_rows"        n     rows per chunk of the ring route; 0 (default) = 2^20, an eighth of the call's rows if that is less (at
- *                            least 65 536); "chunk_rows" > 0 overrides.  A slot holds 32 bytes of segments per row of a full chunk; a
+ *   "ring_rows"        n     rows per chunk of the ring route; 0 (default) = 2^20, a third of the call's rows if that is less (at
+ *                            least 2^17); "chunk_rows" > 0 overrides.  A slot holds 32 bytes of segments per row of a full chunk; a
  *                            chunk ends before that many bytes (a single longer row gets a slot of its own size).
- *   "ring_ramp"        0|1   1 (default): the first chunks are smaller — an eighth of "ring_rows", doubling — so that the device starts early
+ *   "ring_ramp"        0..6  r > 0: the first chunk holds 1 / 2^r of "ring_rows", the next ones double, so that the device starts early
+ *                            (default 0: measured without effect at 10 M rows, a loss on small calls)
  *   "ring_lanes"       1..8  chunks of the ring route in flight on the device (default 3)
  *   "ring_slots"       n     slots of the ring; 0 (default) = "ring_lanes" + 2.  Slots are allocated when first needed, sized by the
  *                            call (powers of two), and kept: sct_get_option "ring_bytes" = page-locked bytes the ring holds

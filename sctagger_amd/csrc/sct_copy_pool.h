@@ -52,9 +52,12 @@ static inline int sct_effective_cpus() {
     return cores < 1 ? 1 : cores;
 }
 
-// Jobs that belong together (the parts of one chunk's copy): `remaining` counts the parts not yet finished.
+// Jobs that belong together (the parts of one chunk's copy): `remaining` counts the parts not yet finished — and, while a group
+// waits to be queued by another group's last part (`then`), one more: CopyPool::hold / release.
 struct CopyGroup {
     std::atomic<int> remaining{0};
+    void (*then)(void *) = nullptr;   // run once by the thread that finishes the group's last part (set before the group is queued)
+    void *then_arg = nullptr;
     bool done() const { return remaining.load(std::memory_order_acquire) == 0; }
 };
 
@@ -72,7 +75,7 @@ class CopyPool {
             std::lock_guard<std::mutex> lk(mu_);
             stop_ = true;
         }
-        cv_.notify_all();
+        work_cv_.notify_all();
         for (std::thread &t : th_) t.join();
     }
     CopyPool(const CopyPool &) = delete;
@@ -80,8 +83,7 @@ class CopyPool {
 
     int threads() const { return (int)th_.size(); }
 
-    // queue fn(arg, p, parts) for p = 0 .. parts-1, in this order behind everything queued before (FIFO: a job may therefore wait
-    // for a group queued EARLIER — its parts have all been taken by then — but never for a later one)
+    // queue fn(arg, p, parts) for p = 0 .. parts-1
     void submit(CopyGroup *g, Fn fn, void *arg, int parts) {
         if (parts <= 0) return;
         g->remaining.fetch_add(parts, std::memory_order_acq_rel);
@@ -89,8 +91,15 @@ class CopyPool {
             std::lock_guard<std::mutex> lk(mu_);
             for (int p = 0; p < parts; p++) q_.push_back(Job{fn, arg, p, parts, g});
         }
-        cv_.notify_all();
+        if (parts == 1) work_cv_.notify_one();
+        else work_cv_.notify_all();
+        done_cv_.notify_all();   // (a thread in wait() takes jobs too)
     }
+
+    // A group that somebody else will queue later (a `then` of another group): held open until then, so that wait() on it does
+    // not return early.  release() after the submit().
+    void hold(CopyGroup *g) { g->remaining.fetch_add(1, std::memory_order_acq_rel); }
+    void release(CopyGroup *g) { finished_one(g); }
 
     // until every part of g has finished; the calling thread takes queued jobs meanwhile (a pool of no threads still works)
     void wait(CopyGroup *g) {
@@ -103,7 +112,7 @@ class CopyPool {
                 run(j);
                 lk.lock();
             } else {
-                cv_.wait(lk);
+                done_cv_.wait(lk);
             }
         }
     }
@@ -115,17 +124,23 @@ class CopyPool {
         int part, parts;
         CopyGroup *g;
     };
+    void finished_one(CopyGroup *g) {
+        if (g->remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            // the group's last part.  Its `then` queues what was waiting for it — a group that is held open (hold), so whoever waits
+            // for both cannot be through before `then` has run
+            if (g->then) g->then(g->then_arg);
+            std::lock_guard<std::mutex> lk(mu_);   // (the waiter checks done() under this lock: no lost wake-up)
+            done_cv_.notify_all();
+        }
+    }
     void run(const Job &j) {
         j.fn(j.arg, j.part, j.parts);
-        if (j.g->remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-            std::lock_guard<std::mutex> lk(mu_);   // (the waiter checks done() under this lock: no lost wake-up)
-            cv_.notify_all();
-        }
+        finished_one(j.g);
     }
     void work() {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            while (!stop_ && q_.empty()) cv_.wait(lk);
+            while (!stop_ && q_.empty()) work_cv_.wait(lk);
             if (q_.empty()) return;   // stop_
             Job j = q_.front();
             q_.pop_front();
@@ -136,7 +151,7 @@ class CopyPool {
     }
     std::vector<std::thread> th_;
     std::mutex mu_;
-    std::condition_variable cv_;
+    std::condition_variable work_cv_, done_cv_;
     std::deque<Job> q_;
     bool stop_ = false;
 };

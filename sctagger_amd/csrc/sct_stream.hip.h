@@ -226,12 +226,12 @@ struct RingChunk {
     int64_t k = 0;
     RingSlot *slot = nullptr;
     CopyGroup in, out;
-    CopyGroup *after = nullptr;          // the slot's previous user: its way out must have finished before this chunk's way in starts
+    RingChunk *next_user = nullptr;      // the chunk that takes this chunk's slot next: its way in is queued by the last part of this chunk's way out
     std::atomic<uint64_t> len_bits{0};   // OR of the row lengths that do not fit one byte (top bit: offsets that decrease)
     int idx_format = SCT_IDX_LEN8;       // what the slot's index holds
     int64_t hit_base = 0, n_hits = 0;
     const int64_t *wide_offs = nullptr;  // a row with more than 255 hits: the chunk's 64-bit offsets (relative), instead of the slot's one-byte counts
-    bool submitted_in = false, submitted_out = false;
+    bool submitted_out = false;
     // SCT_TRACE_RING=1: when (ms since the call began) the chunk's copies ran and the calling thread passed its stations
     std::atomic<int64_t> in_first{INT64_MAX}, in_last{0}, out_first{INT64_MAX}, out_last{0};
     double t_in_ready = 0, t_queued = 0, t_wait = 0, t_device_done = 0, t_out_submitted = 0;
@@ -262,13 +262,14 @@ struct StreamCall {
     bool pl_min_e = false, pl_counts = false;   // the caller's min_e / counts arrays are page-locked (a copy to them may be left queued)
     // the plan
     bool ring = false;
-    bool ramp = false;       // ring route: the chunks grow from an eighth of `chunk` rows to `chunk` rows
+    int ramp = 0;            // ring route: the first chunk has chunk >> ramp rows, the next ones double up to `chunk` rows
     int64_t chunk = 0, n_chunks = 0;
     int L = 1, S = 0;
     std::vector<ChunkPlan> plan;
     std::unique_ptr<RingChunk[]> rc;
     int64_t hit_base = 0;
     std::atomic<int64_t> ns_in{0}, ns_out{0};   // the pool's time on this call's copies, all threads added up
+    int64_t first_in_submitted = 0;   // ways in this thread queued itself (the first S chunks)
     bool trace = false;
     int64_t t_begin_ns = 0;
     double since_begin() const;
@@ -332,13 +333,16 @@ int StreamCall::choose_route() {
                 ring ? "ring" : zc_segs ? "zero-copy" : "staged", (const void *)zc_segs, (const void *)zc_index, (void *)zc_min_e, zc_counts);
     chunk = c->chunk_rows;
     if (ring) {
-        // Chunks small enough that the first one's way in and the last one's way out are a small part of the call, large enough
-        // that a chunk's sixteen launches and its ramp (every resident wave asking for its rows at once) stay one too.
+        // A chunk costs about a tenth of a millisecond beyond its rows (its seventeen dispatches, its ramp: every resident wave asking
+        // for its rows at once) — 3 M rows take 2.4 ms in three chunks and 3.2 ms in eight (profiles/r05_pageable_chunk_sweep.jsonl) —
+        // and the first chunk's way in and the last one's way out are not overlapped with anything: a third of the call's rows per
+        // chunk, at most 2^20 (a slot of the ring is sized by it: 38 MB), at least 2^17.
         if (chunk <= 0) {
             chunk = c->ring_rows > 0 ? c->ring_rows : (int64_t)1 << 20;
-            const int64_t eighth = (n + 7) / 8;
-            if (eighth < chunk) chunk = eighth < 65536 ? 65536 : eighth;
-            // the first chunks smaller, doubling up to that size: the device starts as soon as an eighth of a chunk is in its slot
+            const int64_t third = (n + 2) / 3;
+            if (third < chunk) chunk = third < ((int64_t)1 << 17) ? (int64_t)1 << 17 : third;
+            // option "ring_ramp" = r: the first chunk holds 1 / 2^r of that, the next ones double (the device starts earlier; measured
+            // without effect at 10 M rows and a loss on small calls: off by default)
             ramp = c->ring_ramp;
         }
     } else if (chunk <= 0) {
@@ -370,7 +374,7 @@ int StreamCall::make_plan() {
         cp.b1 = seg_bytes;
         plan.push_back(cp);
     } else {
-        int64_t rows = ramp ? (chunk / 8 < 32768 ? 32768 : chunk / 8) : chunk;
+        int64_t rows = ramp > 0 ? ((chunk >> ramp) < 32768 ? (chunk < 32768 ? chunk : 32768) : (chunk >> ramp)) : chunk;
         while (r0 < n) {
             ChunkPlan cp;
             cp.r0 = r0;
@@ -628,8 +632,6 @@ void sct_offs64_to_u32(const int64_t *rel, int64_t n, uint32_t *dst);
 static void ring_copy_in(void *arg, int part, int parts) {
     RingChunk *r = (RingChunk *)arg;
     StreamCall *sc = r->call;
-    if (r->after)
-        while (!r->after->done()) sched_yield();   // (queued before this job: its parts are all taken — CopyPool::submit)
     const int64_t t0 = clk_ns();
     const ChunkPlan &cp = sc->plan[(size_t)r->k];
     RingSlot &s = *r->slot;
@@ -708,7 +710,10 @@ int StreamCall::ring_prepare() {
         r.call = this;
         r.k = k;
         r.slot = &c->ring[(size_t)(k % S)];
-        r.after = k >= S ? &rc[(size_t)(k - S)].out : nullptr;
+        if (k >= S) {
+            rc[(size_t)(k - S)].next_user = &r;
+            c->pool->hold(&r.in);      // (queued by chunk k - S's way out: ring_after_b)
+        }
         r.idx_format = index_format == SCT_IDX_LEN16 ? SCT_IDX_LEN16 : SCT_IDX_LEN8;
     }
     return SCT_OK;
@@ -724,8 +729,15 @@ static inline int copy_parts(sct_ctx *c, int64_t bytes) {
 void StreamCall::ring_submit_in(int64_t k) {
     RingChunk &r = rc[(size_t)k];
     const ChunkPlan &cp = plan[(size_t)k];
-    r.submitted_in = true;
     c->pool->submit(&r.in, ring_copy_in, &r, copy_parts(c, (cp.b1 - cp.b0) + (int64_t)isz * (cp.r1 - cp.r0)));
+}
+
+// run by the thread that finishes the last part of a chunk's way out: the slot is free — its next user's way in may start
+static void ring_slot_handover(void *arg) {
+    RingChunk *next = (RingChunk *)arg;
+    StreamCall *sc = next->call;
+    sc->ring_submit_in(next->k);
+    sc->c->pool->release(&next->in);   // (held open since ring_prepare; nothing of the call is touched after this line)
 }
 
 // the chunk is in its slot; rows whose length does not fit one byte: the index once more, wider (by this thread: rare)
@@ -798,6 +810,10 @@ int StreamCall::ring_after_b(int64_t k, bool slow) {
         HIPCHK(hipStreamSynchronize(l.stream));
     }
     r.submitted_out = true;
+    if (r.next_user) {
+        r.out.then = ring_slot_handover;
+        r.out.then_arg = r.next_user;
+    }
     const int64_t per_row = (zc_min_e ? 0 : 1) + (zc_counts ? 0 : count_format == SCT_CNT_OFFS64 ? 8 : count_format == SCT_CNT_U32 ? 4 : 1);
     int parts = copy_parts(c, per_row * m);
     const int64_t nb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -805,7 +821,6 @@ int StreamCall::ring_after_b(int64_t k, bool slow) {
     c->pool->submit(&r.out, ring_copy_out, &r, parts);
     if (trace) r.t_out_submitted = since_begin();
     if (sync_out) c->pool->wait(&r.out);
-    if (k + S < n_chunks) ring_submit_in(k + S);
     return SCT_OK;
 }
 
@@ -813,8 +828,14 @@ int StreamCall::ring_after_b(int64_t k, bool slow) {
 void StreamCall::ring_quiesce() {
     if (!rc || !c->pool) return;
     for (int64_t k = 0; k < n_chunks; k++) {
-        if (rc[(size_t)k].submitted_in) c->pool->wait(&rc[(size_t)k].in);
-        if (rc[(size_t)k].submitted_out) c->pool->wait(&rc[(size_t)k].out);
+        RingChunk &r = rc[(size_t)k];
+        // a chunk's way in was queued by this thread (the first S chunks) or will be by its slot's previous user's way out, if that
+        // was queued; what was never queued — an error cut the call short — is not waited for
+        if (k < S && first_in_submitted > k) c->pool->wait(&r.in);
+        if (r.submitted_out) {
+            c->pool->wait(&r.out);
+            if (r.next_user) c->pool->wait(&r.next_user->in);
+        }
     }
 }
 
@@ -856,7 +877,10 @@ int StreamCall::run() {
     double host_a = 0, host_b = 0;
     int rc_all = SCT_OK;
     if (ring)
-        for (int64_t k = 0; k < S && k < n_chunks; k++) ring_submit_in(k);
+        for (int64_t k = 0; k < S && k < n_chunks; k++) {
+            ring_submit_in(k);
+            first_in_submitted = k + 1;
+        }
     for (int64_t k = 0; k < n_chunks + (L - 1) && rc_all == SCT_OK; k++) {
         const double t0 = clk_ms();
         if (k < n_chunks) {

@@ -282,8 +282,8 @@ struct sct_ctx {
     int ring_slots = 0;        // slots of the ring; 0 = lanes in use + 2
     int ring_lanes = 3;        // chunks of the ring route in flight on the device
     bool chunk_order = false;  // zero-copy / staged chunks: a chunk's filter launches wait for the previous chunk's (experiment)
-    int64_t ring_rows = 0;     // rows per chunk of the ring route; 0 = 2^20 (fewer for small calls)
-    bool ring_ramp = true;     // ... reached by doubling from an eighth of that: the device starts early
+    int64_t ring_rows = 0;     // rows per chunk of the ring route; 0 = 2^20 (a third of the call's rows if that is less, at least 2^17)
+    int ring_ramp = 0;         // r > 0: the first chunk holds 1 / 2^r of that, the next ones double
     int copy_threads = -1;     // threads of the copy pool; -1 = half of the CPUs the process may use, at most 8
     int last_route = 0;        // route of the last stream call: 0 staged copies, 1 zero copy, 2 ring
     int stream_lanes = 5;      // chunks of a stream call in flight (each on a lane of its own)
@@ -509,7 +509,10 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     } else if (!strcmp(key, "zero_copy")) c->zero_copy = value != 0;
     else if (!strcmp(key, "gather")) c->no_gather = value == 0;
     else if (!strcmp(key, "ring")) c->use_ring = value != 0;
-    else if (!strcmp(key, "ring_ramp")) c->ring_ramp = value != 0;
+    else if (!strcmp(key, "ring_ramp")) {
+        if (value < 0 || value > 6) return fail(SCT_E_ARG, "ring_ramp must be in 0 .. 6");
+        c->ring_ramp = (int)value;
+    }
     else if (!strcmp(key, "chunk_order")) c->chunk_order = value != 0;
     else if (!strcmp(key, "ring_lanes")) {
         if (value < 1 || value > STREAM_LANES_MAX) return fail(SCT_E_ARG, "ring_lanes must be in 1 .. %d", STREAM_LANES_MAX);

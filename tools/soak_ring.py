@@ -65,7 +65,7 @@ with _native.Matcher(0) as m:
         m.release_host_arrays()
         max_cnt = int(np.diff(want[1]).max(initial=0))
         knobs = {"ring_rows": int(rng.choice([0, 0, 997, 4096, 20000, 65536])), "ring_slots": int(rng.choice([0, 0, 2, 4, 9])),
-                 "ring_lanes": int(rng.choice([1, 2, 3, 3, 5])), "copy_threads": int(rng.choice([-1, -1, 0, 1, 3, 8])), "ring_ramp": int(rng.choice([0, 1]))}
+                 "ring_lanes": int(rng.choice([1, 2, 3, 3, 5])), "copy_threads": int(rng.choice([-1, -1, 0, 1, 3, 8])), "ring_ramp": int(rng.choice([0, 1, 3]))}
         for k, v in knobs.items():
             m.set_option(k, v)
         for rep in range(2):
@@ -87,7 +87,7 @@ with _native.Matcher(0) as m:
             calls += 1
             rows_total += n_seg
         for k in knobs:
-            m.set_option(k, {"copy_threads": -1, "ring_ramp": 1, "ring_lanes": 3}.get(k, 0))
+            m.set_option(k, {"copy_threads": -1, "ring_ramp": 0, "ring_lanes": 3}.get(k, 0))
         if (trial + 1) % 50 == 0 or trial + 1 == trials:
             print(json.dumps({"trials": trial + 1, "ring_calls_checked": calls, "rows": rows_total, "routes": routes, "ring_MB": round(m.get_option("ring_bytes") / 1e6, 1),
                               "s": round(time.time() - t0, 1)}), flush=True)
