@@ -507,6 +507,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI end-to-end timing (figure (iii))")
     ap.add_argument("--no-other-configs", action="store_true", help="skip cfg2 / cfg5 (`other_configs`)")
+    ap.add_argument("--no-pageable", action="store_true", help="skip the sct_match-on-numpy-arrays leg (a kernel trace then holds the timed loops' launches only)")
     ap.add_argument("--cli-rows", type=int, default=10_000_000)
     ap.add_argument("--force-exhaustive", action="store_true", help="time the all-barcodes scan instead of the seed filter")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="sct_set_option before the barcodes are set (exploration)")
@@ -575,7 +576,7 @@ def main():
 
     # INTEGRATION.md §2's exact call (pageable numpy arrays, 64-bit formats both ways), for the record
     pageable = None
-    if args.mode == "both" and world == 1:
+    if args.mode == "both" and world == 1 and not args.no_pageable:
         pageable = loops.pageable(max(2, min(args.steps, 5)), 1)
 
     # ---- figure (i): the same kernels on a batch that is resident in HBM (roofline of the dominant kernel) -------------

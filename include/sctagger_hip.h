@@ -213,10 +213,10 @@ int sct_sync(sct_ctx *ctx);
  *                            chunk ends before that many bytes (a single longer row gets a slot of its own size).
  *   "ring_ramp"        0..6  r > 0: the first chunk holds 1 / 2^r of "ring_rows", the next ones double, so that the device starts early
  *                            (default 0: measured without effect at 10 M rows, a loss on small calls)
- *   "ring_lanes"       1..8  chunks of the ring route in flight on the device (default 3)
+ *   "ring_lanes"       1..8  chunks of the ring route in flight on the device (default 4)
  *   "ring_slots"       n     slots of the ring; 0 (default) = "ring_lanes" + 2.  Slots are allocated when first needed, sized by the
  *                            call (powers of two), and kept: sct_get_option "ring_bytes" = page-locked bytes the ring holds
- *                            (200 MB after a 10 M-row call at the defaults; 0.2 ms per MB to allocate, once)
+ *                            (240 MB after a 10 M-row call at the defaults; 0.2 ms per MB to allocate, once)
  *   "copy_threads"    -1|n   threads of the context's copy pool (created at the first call that needs it): -1 (default) = half of
  *                            the CPUs the process may use (affinity mask, cgroup CPU quota; environment SCT_CPUS overrides), at
  *                            most 8; 0 = the calling thread does every copy itself

@@ -26,76 +26,78 @@ template <typename OffT>
 void launch(const SctFilterVariant v, const FilterArgs<OffT> &fa, unsigned g, unsigned g64, hipStream_t st) {
     constexpr int E = SCT_FILTER_E;
     // both mask widths are launched over all rows; a wave leaves a group of rows at once if it is not its kind (k_filter).
+    // g64 == 0: the 64-bit instantiation is not launched at all — the caller speculates that no row of the batch has more than 31
+    // characters; the 32-bit main launch marks CTR_NEED64 if one does, and the batch is then done again with both.
     // g = grid of the 32-bit instantiation, g64 = the (smaller, striding) grid of the 64-bit one; the striding launches
     // (every one but the main launch's 32-bit instantiation) run one wave per block (FilterWavesPerBlock)
 #if !SCT_FILTER_SPECIAL
     if (!v.retry && !v.special) {
         if (v.rt) {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, true, false, OffT><<<g, 256, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, true, false, OffT><<<g64, 64, 0, st>>>(fa);
+            if (g64) k_filter<E, uint64_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, true, false, OffT><<<g64, 64, 0, st>>>(fa);
         } else if (v.thirds) {
             if constexpr (E <= 1) {
                 if (!v.only64) k_filter<E, uint32_t, SCHEME_THIRDS, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
-                k_filter<E, uint64_t, SCHEME_THIRDS, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+                if (g64) k_filter<E, uint64_t, SCHEME_THIRDS, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.wide) {
             if constexpr (E == 2) {
                 k_filter<E, uint32_t, SCHEME_WIDE, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
-                k_filter<E, uint64_t, SCHEME_WIDE, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+                if (g64) k_filter<E, uint64_t, SCHEME_WIDE, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.slots) {
             k_filter<E, uint32_t, SCHEME_QUARTERS, HMAX_SL, HMAX_SL, 64, false, true, OffT><<<g, 256, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, HMAX_SL, HMAX_SL, 64, false, true, OffT><<<g64, 64, 0, st>>>(fa);
+            if (g64) k_filter<E, uint64_t, SCHEME_QUARTERS, HMAX_SL, HMAX_SL, 64, false, true, OffT><<<g64, 64, 0, st>>>(fa);
         } else {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, false, false, OffT><<<g, 256, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+            if (g64) k_filter<E, uint64_t, SCHEME_QUARTERS, K_SLOTS, HMAX, 64, false, false, OffT><<<g64, 64, 0, st>>>(fa);
         }
     } else {
         if (v.rt) {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT><<<g64, 64, 0, st>>>(fa);
+            if (g64) k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT><<<g64, 64, 0, st>>>(fa);
         } else if (v.thirds) {
             if constexpr (E <= 1) {
                 k_filter<E, uint32_t, SCHEME_THIRDS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g, 64, 0, st>>>(fa);
-                k_filter<E, uint64_t, SCHEME_THIRDS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+                if (g64) k_filter<E, uint64_t, SCHEME_THIRDS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.wide) {
             if constexpr (E == 2) {
                 k_filter<E, uint32_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g, 64, 0, st>>>(fa);
-                k_filter<E, uint64_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+                if (g64) k_filter<E, uint64_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.slots) {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, RETRY_RPW_SL, false, true, OffT><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, RETRY_RPW_SL, false, true, OffT><<<g64, 64, 0, st>>>(fa);
+            if (g64) k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, RETRY_RPW_SL, false, true, OffT><<<g64, 64, 0, st>>>(fa);
         } else {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);
+            if (g64) k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT><<<g64, 64, 0, st>>>(fa);
         }
     }
 #else
     if (v.special16) {
         k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, SPECIAL_RPW_SL, false, true, OffT, true><<<g, 64, 0, st>>>(fa);
-        k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, SPECIAL_RPW_SL, false, true, OffT, true><<<g64, 64, 0, st>>>(fa);
+        if (g64) k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, SPECIAL_RPW_SL, false, true, OffT, true><<<g64, 64, 0, st>>>(fa);
     } else if (v.special) {
         if (v.rt) {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT, true><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT, true><<<g64, 64, 0, st>>>(fa);
+            if (g64) k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, true, false, OffT, true><<<g64, 64, 0, st>>>(fa);
         } else if (v.thirds) {
             if constexpr (E <= 1) {
                 k_filter<E, uint32_t, SCHEME_THIRDS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g, 64, 0, st>>>(fa);
-                k_filter<E, uint64_t, SCHEME_THIRDS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g64, 64, 0, st>>>(fa);
+                if (g64) k_filter<E, uint64_t, SCHEME_THIRDS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.wide) {
             if constexpr (E == 2) {
                 k_filter<E, uint32_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g, 64, 0, st>>>(fa);
-                k_filter<E, uint64_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g64, 64, 0, st>>>(fa);
+                if (g64) k_filter<E, uint64_t, SCHEME_WIDE, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g64, 64, 0, st>>>(fa);
             }
         } else if (v.slots) {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, RETRY_RPW_SL, false, true, OffT, true><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, RETRY_RPW_SL, false, true, OffT, true><<<g64, 64, 0, st>>>(fa);
+            if (g64) k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_SL, RETRY_RPW_SL, false, true, OffT, true><<<g64, 64, 0, st>>>(fa);
         } else {
             k_filter<E, uint32_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g, 64, 0, st>>>(fa);
-            k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g64, 64, 0, st>>>(fa);
+            if (g64) k_filter<E, uint64_t, SCHEME_QUARTERS, K_RETRY, H_RETRY_NS, RETRY_RPW_NS, false, false, OffT, true><<<g64, 64, 0, st>>>(fa);
         }
     }
 #endif

@@ -1289,6 +1289,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
             if (len_all > PLANE_MAX) {  // more characters than one lane's planes hold: the special launch cuts the row into windows
                 const uint32_t k = atomicAdd(&a.ctr[CTR_SPECIAL], 1u);
                 a.list_special[k] = (int32_t)r;
+                a.ctr[CTR_NEED64] = 1u;   // ... of PLANE_MAX characters: they belong to the special launch's 64-bit instantiation
                 if (a.rec_out != nullptr && k < a.rec_cap)
                     a.rec_out[k] = gathered_at != ~0ull ? SctSpecialRec{gathered_at, 0, 0, SCT_REC_GATHERED} : SctSpecialRec{0, 0, 0, SCT_REC_NONE};
                 a.cnt[r] = CNT_DEFER;

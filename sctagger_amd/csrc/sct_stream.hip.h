@@ -111,7 +111,8 @@ static int ring_slot_ensure(RingSlot &s, size_t seg_need, int64_t row_need) {
     }
     ring_slot_release(s);
     const size_t o_idx = align256(seg_cap + 64);
-    const size_t o_min = o_idx + align256(4 * (size_t)(row_cap + 1) + 16);
+    const size_t o_isums = o_idx + align256(4 * (size_t)(row_cap + 1) + 16);
+    const size_t o_min = o_isums + align256(8 * (size_t)(row_cap / SCAN_BLOCK + 3));
     const size_t o_cnt = o_min + align256((size_t)row_cap);
     const size_t o_sums = o_cnt + align256((size_t)row_cap);
     const size_t total = o_sums + align256(8 * (size_t)(row_cap / SCAN_BLOCK + 2));
@@ -130,6 +131,7 @@ static int ring_slot_ensure(RingSlot &s, size_t seg_need, int64_t row_need) {
     s.seg_cap = seg_cap;
     s.row_cap = row_cap;
     s.o_idx = o_idx;
+    s.o_isums = o_isums;
     s.o_min = o_min;
     s.o_cnt = o_cnt;
     s.o_sums = o_sums;
@@ -212,6 +214,8 @@ struct ChunkIO {
     const void *idx_dev = nullptr;      // the chunk's index entries in mapped host memory; NULL: uploaded from idx_src
     const void *idx_src = nullptr;
     int idx_format = SCT_IDX_OFFS64;
+    const uint64_t *idx_sums_dev = nullptr;   // row lengths whose block prefix sums the host already has (the ring route narrowed them from offsets):
+                                              // bytes in front of every SCAN_BLOCK rows, then the total — the device need not scan
     uint8_t *min_e_dev = nullptr;       // mapped host memory the kernels write min_e to; NULL: the lane's buffer, copied to min_e_dst
     uint8_t *min_e_dst = nullptr;
     void *cnt_dev = nullptr;            // the same for the compact counts (one or four bytes per row)
@@ -232,6 +236,7 @@ struct RingChunk {
     int64_t hit_base = 0, n_hits = 0;
     const int64_t *wide_offs = nullptr;  // a row with more than 255 hits: the chunk's 64-bit offsets (relative), instead of the slot's one-byte counts
     bool submitted_out = false;
+    bool have_isums = false;             // the slot holds the block prefix sums of the chunk's row lengths (ring_wait_in)
     // SCT_TRACE_RING=1: when (ms since the call began) the chunk's copies ran and the calling thread passed its stations
     std::atomic<int64_t> in_first{INT64_MAX}, in_last{0}, out_first{INT64_MAX}, out_last{0};
     double t_in_ready = 0, t_queued = 0, t_wait = 0, t_device_done = 0, t_out_submitted = 0;
@@ -520,7 +525,13 @@ int StreamCall::phase_a(int64_t k, const ChunkIO &io) {
             // (Tried in round 3: the index in two parts, the head's filter launch beside the rest's lengths on a second stream.
             // Nothing gained, 4.89 -> 5.04 ms per 10 M rows: the lengths are link traffic like the segments — 10 of the
             // 219 MB a 10 M-row call reads — and the link is busy from the call's first microsecond to the start of the tail.)
-            if (ifmt == SCT_IDX_LEN8) {
+            if (io.idx_sums_dev) {
+                // (one pass: the lengths cross the link once, inside k_index_lens)
+                if (ifmt == SCT_IDX_LEN8)
+                    k_index_lens<uint8_t><<<(unsigned)nb, 256, 0, st>>>((const uint8_t *)idx_dev, m, io.idx_sums_dev, io.idx_sums_dev + nb, bytes, l.offs32.as<uint32_t>(), bad);
+                else
+                    k_index_lens<uint16_t><<<(unsigned)nb, 256, 0, st>>>((const uint16_t *)idx_dev, m, io.idx_sums_dev, io.idx_sums_dev + nb, bytes, l.offs32.as<uint32_t>(), bad);
+            } else if (ifmt == SCT_IDX_LEN8) {
                 uint8_t *keep = io.idx_dev ? l.index_in.as<uint8_t>() : nullptr;
                 k_sum_blocks<uint8_t><<<(unsigned)nb, 256, 0, st>>>((const uint8_t *)idx_dev, m, l.sums.as<uint64_t>(), keep);
                 k_scan_sums<<<1, 256, 0, st>>>(l.sums.as<uint64_t>(), nb, total);
@@ -747,6 +758,13 @@ int StreamCall::ring_wait_in(int64_t k) {
     if (!by_offs) return SCT_OK;
     const ChunkPlan &cp = plan[(size_t)k];
     const int64_t m = cp.r1 - cp.r0;
+    {   // bytes in front of every SCAN_BLOCK rows of the chunk, and the total: the device's scan of the lengths, read off the offsets
+        uint64_t *isums = (uint64_t *)(r.slot->base + r.slot->o_isums);
+        const int64_t nb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        for (int64_t b = 0; b < nb; b++) isums[b] = (uint64_t)(offs_at(cp.r0 + b * SCAN_BLOCK) - cp.b0);
+        isums[nb] = (uint64_t)(cp.b1 - cp.b0);
+        r.have_isums = true;
+    }
     const uint64_t bits = r.len_bits.load();
     if (!(bits >> 8)) return SCT_OK;
     int64_t mx = 0;
@@ -778,6 +796,7 @@ ChunkIO StreamCall::ring_io(int64_t k) const {
     io.idx_src = s.base + s.o_idx;
     io.idx_dev = s.dev + s.o_idx;
     io.idx_format = r.idx_format;
+    io.idx_sums_dev = r.have_isums ? (const uint64_t *)(s.dev + s.o_isums) : nullptr;
     io.min_e_dev = zc_min_e ? zc_min_e + cp.r0 : (uint8_t *)(s.dev + s.o_min);
     if (zc_counts) io.cnt_dev = (char *)zc_counts + (count_format == SCT_CNT_U8 ? 1 : 4) * (size_t)cp.r0;
     else io.cnt_dev = s.dev + s.o_cnt;

@@ -187,6 +187,7 @@ struct Lane {
     uint64_t hits_cap = 0;      // entries hits_ptr can take
     uint16_t *hits16_ptr = nullptr;  // 16-bit hits of a one-chunk stream call: the fill kernel writes them itself (hits_cap = their room)
     bool direct_min_e = false, direct_cnt = false, direct_hits = false;
+    bool no64 = false;          // this batch was queued without the 64-bit instantiations of the filter launches (sct_ctx::need64)
     bool cnt8_soft = false;     // a row with more than 255 hits is not an error of this batch: the one-byte counts go into a slot of the ring, whose
                                 // way out takes the chunk's 64-bit offsets instead (sct_stream.hip.h)
     BatchParams bp;
@@ -237,7 +238,7 @@ struct RingSlot {
     size_t bytes = 0;
     size_t seg_cap = 0;       // segment bytes the slot takes (at offset 0)
     int64_t row_cap = 0;      // rows
-    size_t o_idx = 0, o_min = 0, o_cnt = 0, o_sums = 0;   // offsets of the index, min_e, counts and block-sum areas
+    size_t o_idx = 0, o_isums = 0, o_min = 0, o_cnt = 0, o_sums = 0;   // offsets of the index, its block prefix sums, min_e, counts and the hit counts' block sums
 };
 
 struct sct_ctx {
@@ -280,7 +281,15 @@ struct sct_ctx {
     bool zero_copy = true;     // stream API: kernels read page-locked caller buffers in place instead of uploading them
     bool use_ring = true;      // stream API: pageable caller arrays go through the context's page-locked ring (sct_stream.hip.h)
     int ring_slots = 0;        // slots of the ring; 0 = lanes in use + 2
-    int ring_lanes = 3;        // chunks of the ring route in flight on the device
+    int ring_lanes = 4;        // chunks of the ring route in flight on the device (profiles/r05_pageable_lanes_sweep.jsonl: 5.7 ms per 10 M rows; 3: 5.95, 5: 6.1)
+    // Rows of 32 .. 63 characters, and the 63-character windows of longer rows, take the 64-bit instantiations of the filter launches:
+    // four launches of a batch's seventeen that find nothing to do on 22-character segments — and that, being 8 192 one-wave blocks
+    // each, wait 100 - 240 us for the chip when another chunk's main launch holds it (profiles/r05_ring_kernel_timeline.txt).  Until a
+    // batch of this context has needed them they are not launched: the 32-bit main launch marks CTR_NEED64 when it meets such a row,
+    // and finish_batch then does the batch again with both widths and stops speculating.  Option "need64": -1 = this, 1 = always both.
+    bool need64 = false;
+    int need64_mode = -1;
+    int64_t redone64 = 0;      // batches done again because the speculation failed (sct_get_option "redone64")
     bool chunk_order = false;  // zero-copy / staged chunks: a chunk's filter launches wait for the previous chunk's (experiment)
     int64_t ring_rows = 0;     // rows per chunk of the ring route; 0 = 2^20 (a third of the call's rows if that is less, at least 2^17)
     int ring_ramp = 0;         // r > 0: the first chunk holds 1 / 2^r of that, the next ones double
@@ -472,6 +481,8 @@ extern "C" int sct_get_option(sct_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "ring_slots")) *value = c->ring_slots;
     else if (!strcmp(key, "copy_threads")) *value = c->pool ? c->pool->threads() : c->copy_threads;
     else if (!strcmp(key, "last_route")) *value = c->last_route;
+    else if (!strcmp(key, "need64")) *value = c->need64 || c->need64_mode > 0;
+    else if (!strcmp(key, "redone64")) *value = c->redone64;
     else if (!strcmp(key, "ring_bytes")) {
         size_t b = 0;
         for (const RingSlot &sl : c->ring) b += sl.bytes;
@@ -514,6 +525,10 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
         c->ring_ramp = (int)value;
     }
     else if (!strcmp(key, "chunk_order")) c->chunk_order = value != 0;
+    else if (!strcmp(key, "need64")) {
+        c->need64_mode = value > 0 ? 1 : -1;
+        if (value <= 0) c->need64 = false;   // (start speculating again)
+    }
     else if (!strcmp(key, "ring_lanes")) {
         if (value < 1 || value > STREAM_LANES_MAX) return fail(SCT_E_ARG, "ring_lanes must be in 1 .. %d", STREAM_LANES_MAX);
         c->ring_lanes = (int)value;
@@ -907,6 +922,10 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     fa.bl = c->bl;
     fa.prefix_len = bp.prefix_len;
     SctFilterVariant v{false, bp.rt_families, bp.use_slots && !bp.rt_families, bp.use_thirds, bp.use_wide, false, false, false};
+    // (see sct_ctx::need64; the partitioned join launches the 64-bit instantiation alone and marks nothing)
+    const bool join_route = bp.use_join && n < ((int64_t)1 << 30);
+    l.no64 = !c->need64 && c->need64_mode < 0 && !join_route;
+    const auto g64_of = [&](int64_t g) { return l.no64 ? 0u : capped(g); };
     {
         Timer t(c, l, "k_filter", l.index_just_timed);
         l.index_just_timed = false;
@@ -949,7 +968,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
             launch_filter(bp.max_err, v64, fa, 1, capped((n + 63) / 64), st);
         } else {
             fa.skip64_unless_needed = true;     // (both instantiations over all rows, the 32-bit one first)
-            launch_filter(bp.max_err, v, fa, blocks_for(n, 256), capped((n + 63) / 64), st);
+            launch_filter(bp.max_err, v, fa, blocks_for(n, 256), g64_of((n + 63) / 64), st);
             fa.skip64_unless_needed = false;
         }
     }
@@ -970,7 +989,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.defer_count = ctr + CTR_SCAN;
         fa.slot_cursor = reinterpret_cast<unsigned long long *>(ctr + CTR_CURSOR_RETRY);
         fa.arena_cursors = nullptr;
-        launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), capped((n + 3) / 4), st);  // one wave of 4 rows per block, striding
+        launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), g64_of((n + 3) / 4), st);  // one wave of 4 rows per block, striding
     }
     {
         // rows the main launch listed because one lane's planes cannot express them as the reference sees them (restricted window
@@ -1003,7 +1022,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
             fa.list_defer = l.list_special2.as<int32_t>();
             fa.defer_count = ctr + CTR_SPECIAL2;
             fa.rec_out = l.rec_special2.as<SctSpecialRec>();
-            launch_filter(bp.max_err, v, fa, capped((n + 15) / 16), capped((n + 15) / 16), st);
+            launch_filter(bp.max_err, v, fa, capped((n + 15) / 16), g64_of((n + 15) / 16), st);
             v.special16 = false;
             fa.n_dev = ctr + CTR_SPECIAL2;
             fa.rows = l.list_special2.as<int32_t>();
@@ -1012,7 +1031,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         }
         fa.list_defer = l.list_long.as<int32_t>();
         fa.defer_count = ctr + CTR_LONG;
-        launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), capped((n + 3) / 4), st);
+        launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), g64_of((n + 3) / 4), st);
     }
 }
 
@@ -1066,6 +1085,7 @@ static int queue_batch(sct_ctx *c, Lane &l) {
             else queue_filter_launches<uint32_t>(c, l, l.offs32.as<uint32_t>());
             if (l.record_filters_done) HIPCHK(hipEventRecord(l.filters_done, st));
         } else {
+            l.no64 = false;
             Timer t(c, l, "k_route");
             if (l.wide)
                 k_route_all<int64_t><<<blocks_for(n, 256), 256, 0, st>>>(l.segs_ptr, l.offs64.as<int64_t>(), l.seg_bytes, n, c->bl,
@@ -1253,6 +1273,16 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
         // the usual 22 characters, or keys that crowd into one partition): the whole batch once more through the filter kernel
         l.bp.use_join = false;
         c->last_join += ((int64_t)1 << 32) | ((int64_t)h[CTR_JOIN_OVERFLOW] << 40);
+        if (int rc = reset_counters(l)) return rc;
+        if (int rc = queue_batch(c, l)) return rc;
+        HIPCHK(hipStreamSynchronize(l.stream));
+        HIPCHK(hipGetLastError());
+        return finish_batch(c, l, row_base, slow);
+    }
+    if (l.no64 && l.bp.filter_ok && l.n_seg > 0 && h[CTR_NEED64]) {
+        // the batch has rows for the 64-bit instantiations, which were not launched (sct_ctx::need64): once more, with them
+        c->need64 = true;
+        c->redone64++;
         if (int rc = reset_counters(l)) return rc;
         if (int rc = queue_batch(c, l)) return rc;
         HIPCHK(hipStreamSynchronize(l.stream));

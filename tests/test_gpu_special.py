@@ -8,7 +8,7 @@ import pytest
 from oracle import bruteforce, trie_oracle
 from sctagger_amd import _native, synth
 from tests import util
-from tests.test_gpu_parity import ragged, run_both
+from tests.test_gpu_parity import pinned_copy, ragged, run_both
 
 pytestmark = pytest.mark.gpu
 
@@ -108,6 +108,42 @@ def test_goldens_stay_on_the_seed_filter(m):
         assert util.render(bcs, names, segs, offs, *got) == open(exp).read(), (name, e, t)
         seen += 1
     assert seen >= 15
+
+
+def test_batches_without_the_64_bit_launches(m):
+    """Round 5: until a batch of a context has needed them, the filter launches' 64-bit instantiations (rows of 32 .. 63 characters, the
+    63-character windows of longer rows) are not launched at all; the 32-bit main launch marks CTR_NEED64 when it meets such a row and
+    the batch is done again with both widths.  Here the speculation is switched back on before every call (option "need64" = -1)."""
+    bc = synth.make_barcodes(700, seed=95)
+    clean, offs_c = synth.make_segments(30_000, bc, seed=95)                           # 22 characters and empty rows: never needs them
+    noisy, _ = synth.add_noise_bytes(clean, offs_c, 0.02, seed=95)                     # restricted starts: the special launch, 32-bit
+    one_mid, offs_m, _ = synth.lengthen_rows(clean, offs_c, 0.0001, 40, seed=96)       # a few rows of 40 characters: the main launch, 64-bit
+    one_long, offs_l, _ = synth.lengthen_rows(noisy, offs_c, 0.0001, 90, seed=97)      # a few rows of 90: windows in the special launch, 64-bit
+    tail = np.concatenate([clean, np.frombuffer(b"ACGT" * 9, np.uint8)])               # the very last row has 36 characters
+    offs_t = np.concatenate([offs_c, [offs_c[-1] + 36]])
+    m.set_barcodes(bc)
+    for name, segs, offs, needs in (("clean", clean, offs_c, False), ("noisy", noisy, offs_c, False), ("40", one_mid, offs_m, True),
+                                    ("clean again", clean, offs_c, False), ("90", one_long, offs_l, True), ("last row", tail, offs_t, True)):
+        m.set_option("need64", 1)
+        want = m.match(segs, offs, 2, 16)
+        for route in ("ring", "zero copy", "resident"):
+            m.set_option("need64", -1)
+            before = m.get_option("redone64")
+            if route == "ring":
+                got = m.match(segs, offs, 2, 16)
+            elif route == "zero copy":
+                ps, po = pinned_copy(m, segs), pinned_copy(m, offs)
+                me, ho, hits = m.match_stream(ps, po, 2, 16, index_format=_native.IDX_OFFS64, count_format=_native.CNT_OFFS64)
+                got = (me.copy(), ho.copy(), hits.copy())
+            else:
+                m.upload_segments(segs, offs)
+                m.run(2, 16)
+                got = m.download()
+            util.assert_same(got, want, "%s, %s" % (name, route))
+            assert m.get_option("redone64") - before == (1 if needs else 0), (name, route)
+            assert m.get_option("need64") == (1 if needs else 0)
+        m.release_host_arrays()
+    m.set_option("need64", -1)
 
 
 def test_many_ties_in_special_rows(m):

@@ -68,6 +68,7 @@ with _native.Matcher(0) as m:
                  "ring_lanes": int(rng.choice([1, 2, 3, 3, 5])), "copy_threads": int(rng.choice([-1, -1, 0, 1, 3, 8])), "ring_ramp": int(rng.choice([0, 1, 3]))}
         for k, v in knobs.items():
             m.set_option(k, v)
+        m.set_option("need64", int(rng.choice([-1, -1, 1])))      # -1: speculate again that no batch needs the filter's 64-bit launches
         for rep in range(2):
             cfmt = int(rng.choice([_native.CNT_OFFS64, _native.CNT_OFFS64, _native.CNT_U32, _native.CNT_U8]))
             hfmt = _native.HITS_U16 if rng.random() < 0.4 and 2 * len(bc) <= 65536 else _native.HITS_U32
@@ -87,7 +88,7 @@ with _native.Matcher(0) as m:
             calls += 1
             rows_total += n_seg
         for k in knobs:
-            m.set_option(k, {"copy_threads": -1, "ring_ramp": 0, "ring_lanes": 3}.get(k, 0))
+            m.set_option(k, {"copy_threads": -1, "ring_ramp": 0, "ring_lanes": 4}.get(k, 0))
         if (trial + 1) % 50 == 0 or trial + 1 == trials:
             print(json.dumps({"trials": trial + 1, "ring_calls_checked": calls, "rows": rows_total, "routes": routes, "ring_MB": round(m.get_option("ring_bytes") / 1e6, 1),
                               "s": round(time.time() - t0, 1)}), flush=True)
