@@ -223,6 +223,12 @@ int sct_sync(sct_ctx *ctx);
  *                            Environment SCT_TRACE_STREAM=1: one line per call on stderr — the route, and which of the caller's arrays
  *                            the kernels touch in place; SCT_TRACE_RING=1: per chunk of the ring route, when its copies ran and when
  *                            the calling thread passed its stations.
+ *   "need64"          -1|1   -1 (default): the 64-bit instantiations of the filter launches (rows of 32 .. 63 characters, the 63-character
+ *                            windows of longer rows) are not launched until a batch of the context has needed them — the 32-bit main
+ *                            launch marks it, that batch is done again with both widths, and the context launches both from then on;
+ *                            1: always both.  Setting -1 starts guessing again.  sct_get_option "redone64" counts the batches done again.
+ *   "need_special"    -1|1   the same for the special launch (a byte outside ACGT under the reference's prefix rule, more than 63 characters)
+ *   "chunk_order"      0|1   experiment: a chunk's filter launches wait for the previous chunk's; no gain, off
  *   "fail_alloc_at"    k     TEST HOOK for the error paths (error codes instead of the reference's asserts,
  *                            scTagger.py:140-143, :760-761): the k-th allocation attempt the context makes from now on — device
  *                            memory, page-locked host memory (result buffer, ring slots, bounce pieces), a lane's stream — fails once

@@ -407,13 +407,25 @@ static struct {
 
 int64_t sctfd_gzip_member(const uint8_t *in, int64_t n, uint8_t *out, void *scratch_mem);   /* sct_fdeflate.c */
 int64_t sctfd_scratch_bytes(void);
-static __thread void *gz_fast_scratch = NULL;   /* per thread, kept */
+static __thread void *gz_fast_scratch = NULL;   /* per thread, kept while the thread lives */
+/* ... and released when it ends: gz_piece also runs on the threads that call sctio_gzip_members (they take pieces while they wait),
+ * which come and go with the command's workers */
+static pthread_key_t gz_scratch_key;
+static pthread_once_t gz_scratch_once = PTHREAD_ONCE_INIT;
+static void gz_scratch_make_key(void) { (void)pthread_key_create(&gz_scratch_key, free); }
+static void *gz_scratch(void) {
+    if (!gz_fast_scratch) {
+        pthread_once(&gz_scratch_once, gz_scratch_make_key);
+        gz_fast_scratch = malloc((size_t)sctfd_scratch_bytes());
+        if (gz_fast_scratch) (void)pthread_setspecific(gz_scratch_key, gz_fast_scratch);   /* the key's destructor frees it at thread exit */
+    }
+    return gz_fast_scratch;
+}
 
 static void gz_piece(gz_job *j, int k) {
     const int64_t a = (int64_t)k * j->piece, len = j->n - a < j->piece ? j->n - a : j->piece;
     if (j->level < 0) {   /* the command's own fast compressor (sct_fdeflate.c) */
-        if (!gz_fast_scratch) gz_fast_scratch = malloc((size_t)sctfd_scratch_bytes());
-        if (!gz_fast_scratch) {
+        if (!gz_scratch()) {
             __atomic_store_n(&j->failed, 1, __ATOMIC_RELAXED);
             return;
         }

@@ -414,6 +414,7 @@ typedef struct {
     symbuf sym;                /* pass 1's symbols (every chunk but the first) */
     uint8_t *bytes;            /* ... or bytes already (the first chunk, redone stretches): malloc base, data at + SCTIO_PIECE_HEAD */
     int64_t n_bytes;
+    uint32_t bytes_crc;        /* CRC-32 of those bytes, summed by pass 1 (not under the lock: up to 128 MB) */
 } chunk_t;
 
 typedef struct {
@@ -534,7 +535,7 @@ static void chain_advance(pinf_t *h) {
         if (c->bytes) {   /* bytes already */
             it->buf = c->bytes;
             it->n = c->n_bytes;
-            it->crc = sctio_crc32(0, it->buf + SCTIO_PIECE_HEAD, it->n);
+            it->crc = c->bytes_crc;
             it->ready = 1;
             window_push(h->win, &h->win_fill, it->buf + SCTIO_PIECE_HEAD + (it->n > WINDOW ? it->n - WINDOW : 0), it->n > WINDOW ? WINDOW : it->n);
         } else {
@@ -648,6 +649,8 @@ static int64_t piece_limit(const pinf_t *h) {
     return lim;
 }
 
+#define PENDING_MAX ((int64_t)3 << 30)   /* bytes of decoded pieces nobody has fetched yet, beyond which no further chunk is started */
+
 /* pass 1 of chunk k (no lock held) */
 static void pass1(pinf_t *h, int k, sct_inf *s, symbuf b, int64_t hint) {
     chunk_t *c = &h->chunks[k];
@@ -693,6 +696,7 @@ static void pass1(pinf_t *h, int k, sct_inf *s, symbuf b, int64_t hint) {
             }
             c->bytes = buf;
             c->n_bytes = n;
+            c->bytes_crc = sctio_crc32(0, buf + SCTIO_PIECE_HEAD, n);
         } else {
             free(buf);   /* an error in the first chunk: the REDO from bit 0 reports it */
         }
@@ -870,7 +874,14 @@ static void *worker(void *arg) {
         /* 3. pass 1 of the next chunk, not too far ahead of the chain */
         /* (... nor of the consumer: the pieces nobody has fetched yet are whole buffers; without this bound a reader that waits for
          * its own consumers let the decoders run through the file, 3.8 GB of pieces for 10^8 rows) */
-        if (!h->chain_done && h->next_p1 < h->n_chunks && h->next_p1 < h->chain_k + h->lookahead && h->n_items - h->cons < h->lookahead + 8) {
+        /* (... nor by more BYTES than a pipeline needs: pieces are bounded — piece_limit — but a stream that inflates 16 : 1 makes every
+         * one of them that large; what is decoded and not yet fetched, plus what the running passes will add, stays under PENDING_MAX) */
+        int64_t pending = 0;
+        for (int i = h->cons; i < h->n_items; i++) pending += h->items[i]->n * (h->items[i]->ready ? 1 : 3);   /* symbols: 2 bytes + the bytes to come */
+        for (int k = h->chain_k; k < h->next_p1; k++)
+            if (h->chunks[k].state == C_RUNNING || h->chunks[k].state == C_DONE) pending += 3 * (h->chunks[k].state == C_DONE ? h->chunks[k].sym.n + h->chunks[k].n_bytes : h->sym_hint);
+        if (!h->chain_done && h->next_p1 < h->n_chunks && h->next_p1 < h->chain_k + h->lookahead && h->n_items - h->cons < h->lookahead + 8 &&
+            (pending < PENDING_MAX || h->next_p1 == h->chain_k)) {
             const int k = h->next_p1++;
             h->chunks[k].state = C_RUNNING;
             symbuf b = {0, 0, 0};

@@ -188,6 +188,7 @@ struct Lane {
     uint16_t *hits16_ptr = nullptr;  // 16-bit hits of a one-chunk stream call: the fill kernel writes them itself (hits_cap = their room)
     bool direct_min_e = false, direct_cnt = false, direct_hits = false;
     bool no64 = false;          // this batch was queued without the 64-bit instantiations of the filter launches (sct_ctx::need64)
+    bool no_special = false;    // ... without the special launch (sct_ctx::need_special)
     bool cnt8_soft = false;     // a row with more than 255 hits is not an error of this batch: the one-byte counts go into a slot of the ring, whose
                                 // way out takes the chunk's 64-bit offsets instead (sct_stream.hip.h)
     BatchParams bp;
@@ -289,6 +290,11 @@ struct sct_ctx {
     // and finish_batch then does the batch again with both widths and stops speculating.  Option "need64": -1 = this, 1 = always both.
     bool need64 = false;
     int need64_mode = -1;
+    // The same for the special launch (gather + its two stages: three dispatches that find no rows on clean input): not launched until a
+    // batch of the context has listed a row for it (a byte outside ACGT under the reference's prefix rule, more than 63 characters);
+    // that batch is then done again.  Option "need_special": -1 = this, 1 = always launched.
+    bool need_special = false;
+    int need_special_mode = -1;
     int64_t redone64 = 0;      // batches done again because the speculation failed (sct_get_option "redone64")
     bool chunk_order = false;  // zero-copy / staged chunks: a chunk's filter launches wait for the previous chunk's (experiment)
     int64_t ring_rows = 0;     // rows per chunk of the ring route; 0 = 2^20 (a third of the call's rows if that is less, at least 2^17)
@@ -482,6 +488,7 @@ extern "C" int sct_get_option(sct_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "copy_threads")) *value = c->pool ? c->pool->threads() : c->copy_threads;
     else if (!strcmp(key, "last_route")) *value = c->last_route;
     else if (!strcmp(key, "need64")) *value = c->need64 || c->need64_mode > 0;
+    else if (!strcmp(key, "need_special")) *value = c->need_special || c->need_special_mode > 0;
     else if (!strcmp(key, "redone64")) *value = c->redone64;
     else if (!strcmp(key, "ring_bytes")) {
         size_t b = 0;
@@ -528,6 +535,9 @@ extern "C" int sct_set_option(sct_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "need64")) {
         c->need64_mode = value > 0 ? 1 : -1;
         if (value <= 0) c->need64 = false;   // (start speculating again)
+    } else if (!strcmp(key, "need_special")) {
+        c->need_special_mode = value > 0 ? 1 : -1;
+        if (value <= 0) c->need_special = false;
     }
     else if (!strcmp(key, "ring_lanes")) {
         if (value < 1 || value > STREAM_LANES_MAX) return fail(SCT_E_ARG, "ring_lanes must be in 1 .. %d", STREAM_LANES_MAX);
@@ -925,6 +935,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
     // (see sct_ctx::need64; the partitioned join launches the 64-bit instantiation alone and marks nothing)
     const bool join_route = bp.use_join && n < ((int64_t)1 << 30);
     l.no64 = !c->need64 && c->need64_mode < 0 && !join_route;
+    l.no_special = !c->need_special && c->need_special_mode < 0 && !join_route;
     const auto g64_of = [&](int64_t g) { return l.no64 ? 0u : capped(g); };
     {
         Timer t(c, l, "k_filter", l.index_just_timed);
@@ -991,7 +1002,7 @@ static void queue_filter_launches(sct_ctx *c, Lane &l, const OffT *offs) {
         fa.arena_cursors = nullptr;
         launch_filter(bp.max_err, v, fa, capped((n + 3) / 4), g64_of((n + 3) / 4), st);  // one wave of 4 rows per block, striding
     }
-    {
+    if (!l.no_special) {
         // rows the main launch listed because one lane's planes cannot express them as the reference sees them (restricted window
         // starts; more than PLANE_MAX characters): the retry launch's shape with start masks and windows (filter_rows, SP).  Its lists
         // go to the retry launch's slot array; what it cannot hold goes on to list_long -> the scan kernels of the slow path.
@@ -1085,7 +1096,7 @@ static int queue_batch(sct_ctx *c, Lane &l) {
             else queue_filter_launches<uint32_t>(c, l, l.offs32.as<uint32_t>());
             if (l.record_filters_done) HIPCHK(hipEventRecord(l.filters_done, st));
         } else {
-            l.no64 = false;
+            l.no64 = l.no_special = false;
             Timer t(c, l, "k_route");
             if (l.wide)
                 k_route_all<int64_t><<<blocks_for(n, 256), 256, 0, st>>>(l.segs_ptr, l.offs64.as<int64_t>(), l.seg_bytes, n, c->bl,
@@ -1279,9 +1290,11 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
         HIPCHK(hipGetLastError());
         return finish_batch(c, l, row_base, slow);
     }
-    if (l.no64 && l.bp.filter_ok && l.n_seg > 0 && h[CTR_NEED64]) {
-        // the batch has rows for the 64-bit instantiations, which were not launched (sct_ctx::need64): once more, with them
-        c->need64 = true;
+    if (l.bp.filter_ok && l.n_seg > 0 && ((l.no64 && h[CTR_NEED64]) || (l.no_special && h[CTR_SPECIAL]))) {
+        // the batch has rows for launches that were left out on the guess that no row needs them (sct_ctx::need64, need_special):
+        // once more, with them
+        if (l.no64 && h[CTR_NEED64]) c->need64 = true;
+        if (l.no_special && h[CTR_SPECIAL]) c->need_special = true;
         c->redone64++;
         if (int rc = reset_counters(l)) return rc;
         if (int rc = queue_batch(c, l)) return rc;

@@ -5,7 +5,7 @@ set -o pipefail
 per=${1:-300000}; procs=${2:-4}
 R=$(cd "$(dirname "$0")/.." && pwd)
 gcc -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -o /tmp/fuzz_inflate $R/tools/fuzz_inflate.c $R/sctagger_amd/csrc/sct_inflate.c $R/sctagger_amd/csrc/sct_pinflate.c $R/sctagger_amd/csrc/sct_fdeflate.c -lz -lpthread || exit 1
-log=$R/profiles/r04_inflate_fuzz.log
+log=$R/profiles/${FUZZ_LOG:-r05_inflate_fuzz.log}
 { echo "# tools/fuzz_inflate.sh $per $procs   ($(date -u +%Y-%m-%dT%H:%MZ), $(gcc --version | head -1), zlib $(python3 -c 'import zlib; print(zlib.ZLIB_VERSION)'))"
   echo "# gcc -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined; each process: /tmp/fuzz_inflate $per <seed>"; } > $log
 pids=()

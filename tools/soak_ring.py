@@ -69,6 +69,7 @@ with _native.Matcher(0) as m:
         for k, v in knobs.items():
             m.set_option(k, v)
         m.set_option("need64", int(rng.choice([-1, -1, 1])))      # -1: speculate again that no batch needs the filter's 64-bit launches
+        m.set_option("need_special", int(rng.choice([-1, -1, 1])))   # ... nor its special launch
         for rep in range(2):
             cfmt = int(rng.choice([_native.CNT_OFFS64, _native.CNT_OFFS64, _native.CNT_U32, _native.CNT_U8]))
             hfmt = _native.HITS_U16 if rng.random() < 0.4 and 2 * len(bc) <= 65536 else _native.HITS_U32
