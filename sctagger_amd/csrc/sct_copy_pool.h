@@ -125,10 +125,13 @@ class CopyPool {
         CopyGroup *g;
     };
     void finished_one(CopyGroup *g) {
+        // (read while this part still keeps the group open: once `remaining` is 0 a waiter may be through and the group gone)
+        void (*const then)(void *) = g->then;
+        void *const then_arg = g->then_arg;
         if (g->remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {
             // the group's last part.  Its `then` queues what was waiting for it — a group that is held open (hold), so whoever waits
             // for both cannot be through before `then` has run
-            if (g->then) g->then(g->then_arg);
+            if (then) then(then_arg);
             std::lock_guard<std::mutex> lk(mu_);   // (the waiter checks done() under this lock: no lost wake-up)
             done_cv_.notify_all();
         }

@@ -47,6 +47,20 @@ def test_core_header_and_table_builder_under_asan_ubsan():
     assert r.returncode == 0 and out.startswith("OK") and "runtime error" not in out, out[-4000:]
 
 
+def test_copy_pool_protocol_under_tsan_and_asan():
+    """The copy pool of the stream seam's ring route (csrc/sct_copy_pool.h) runs the ring's protocol on the host — ways in, a device that
+    takes a while, ways out whose last part hands the slot to its next user, calls cut short — under ThreadSanitizer (which found that
+    a finished group was read after its waiter could be gone: round 5) and under ASan + UBSan (tests/host_pool_check.cpp)."""
+    build = os.path.join(util.HERE, "_build")
+    os.makedirs(build, exist_ok=True)
+    for name, flags, rounds in (("tsan", ["-fsanitize=thread"], "60"), ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], "120")):
+        exe = os.path.join(build, "host_pool_check_" + name)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fno-omit-frame-pointer"] + flags + ["-o", exe, os.path.join(util.HERE, "host_pool_check.cpp")])
+        r = subprocess.run([exe, rounds], capture_output=True, timeout=1200, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"))
+        out = r.stdout.decode() + r.stderr.decode()
+        assert r.returncode == 0 and out.startswith("OK") and "Sanitizer" not in out and "runtime error" not in out, (name, out[-4000:])
+
+
 def test_inflate_differential_fuzz_short_run():
     """tools/fuzz_inflate.c for 1 000 mutated streams under ASan + UBSan: the serial decoder (csrc/sct_inflate.c), the parallel driver
     (csrc/sct_pinflate.c: threads, chunking, hand-over) and zlib must agree on which streams are valid and on every byte of the valid
