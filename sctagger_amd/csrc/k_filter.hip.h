@@ -1217,6 +1217,11 @@ __device__ __forceinline__ void filter_rows(const FilterArgs<OffT> &a, FilterWav
     }
     if constexpr (COOP) {
         if (anyrow && !mykind && lane == 0 && a.skip64_unless_needed) a.ctr[CTR_NEED64] = 1u;
+        // ... and leaves the rows without hits for now: the 64-bit instantiation behind this launch writes their counts — or nobody
+        // does, when the batch was queued without it on the guess that no row needs it (sct_ctx::need64); the batch is then done again,
+        // but its sums and its fill kernel run first, and what they read must not be whatever the buffer held before (round 5: a
+        // fresh context's counts were a previous context's, and k_offsets_fill ran off the end of the slot array)
+        if (!mykind && inrange && a.skip64_unless_needed) a.cnt[r] = 0u;
     }
     if (!mykind) return;
     if (!anyrow) return;

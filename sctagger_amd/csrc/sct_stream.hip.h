@@ -29,6 +29,7 @@
 //               page-locked goes through the context's two bounce pieces here as everywhere else (copy_up / copy_down), one piece
 //               after the other on the calling thread: 11 - 13 ms per 10 M rows — the ring route without its pipeline.
 #pragma once
+#include <deque>
 #include <memory>
 
 #include "sct_copy_pool.h"
@@ -275,6 +276,19 @@ struct StreamCall {
     int64_t hit_base = 0;
     std::atomic<int64_t> ns_in{0}, ns_out{0};   // the pool's time on this call's copies, all threads added up
     int64_t first_in_submitted = 0;   // ways in this thread queued itself (the first S chunks)
+    // sct_match: its malloc'ed hit array is filled while the call runs — a chunk's hits are copied out of the page-locked result
+    // buffer (on the pool) once the lane's next event says their DMA has landed — instead of in one piece at the end
+    bool want_sink = false;
+    uint32_t *sink = nullptr;
+    size_t sink_entries = 0;
+    struct HitSpan {
+        int64_t base = 0, n = 0;
+    };
+    std::vector<HitSpan> lane_hits;      // per lane: the hits whose DMA was queued last and has not been copied out yet
+    std::deque<ParCopy> hit_copies;      // (stable addresses: the pool's jobs point at them)
+    CopyGroup hit_group;
+    void sink_flush_lane(int lane);
+    void sink_drop();
     bool trace = false;
     int64_t t_begin_ns = 0;
     double since_begin() const;
@@ -293,7 +307,7 @@ struct StreamCall {
     void ring_submit_in(int64_t k);
     int ring_wait_in(int64_t k);
     ChunkIO ring_io(int64_t k) const;
-    int ring_after_b(int64_t k, bool slow);
+    int ring_after_b(int64_t k, bool stale);
     void ring_quiesce();
     int run();
 };
@@ -580,6 +594,27 @@ int StreamCall::phase_a(int64_t k, const ChunkIO &io) {
     return SCT_OK;
 }
 
+void StreamCall::sink_flush_lane(int lane) {
+    HitSpan &hs = lane_hits[(size_t)lane];
+    if (sink && hs.n > 0) {
+        hit_copies.push_back(ParCopy{(char *)(sink + hs.base), (const char *)(c->h_hits + hs.base), 4 * (size_t)hs.n});
+        const size_t bytes = 4 * (size_t)hs.n;
+        size_t parts = bytes >> 19;
+        if (parts > (size_t)c->pool->threads() + 1) parts = (size_t)c->pool->threads() + 1;
+        c->pool->submit(&hit_group, par_copy_part, &hit_copies.back(), (int)(parts < 1 ? 1 : parts));
+    }
+    hs.n = 0;
+}
+
+// the result buffer is about to move (it grew): what was copied out so far came from the old one — finish, and leave the rest to
+// the caller's one copy at the end
+void StreamCall::sink_drop() {
+    if (!sink) return;
+    c->pool->wait(&hit_group);
+    g_hit_arrays.put(sink);
+    sink = nullptr;
+}
+
 // phase B of chunk k: wait for phase A, look at its counters, bring the hits home
 int StreamCall::phase_b(int64_t k) {
     Lane &l = lane_of(k);
@@ -589,9 +624,11 @@ int StreamCall::phase_b(int64_t k) {
     if (trace && ring) rc[(size_t)k].t_wait = since_begin();
     HIPCHK(hipEventSynchronize(l.done));
     if (trace && ring) rc[(size_t)k].t_device_done = since_begin();
-    bool slow = false;
-    if (int rc_ = finish_batch(c, l, cp.r0, &slow)) return rc_;
+    if (sink) sink_flush_lane((int)(k % L));   // (the event behind this lane's previous chunk has passed: its hits have landed)
+    bool slow = false, redone = false;
+    if (int rc_ = finish_batch(c, l, cp.r0, &slow, &redone)) return rc_;
     cp.hit_base = hit_base;
+    if (sink && (size_t)(hit_base + l.n_hits + 1) > c->h_hits_cap) sink_drop();
     if (int rc_ = ensure_host_hits(c, (size_t)(hit_base + l.n_hits + 1))) return rc_;
     {
         Timer t(c, l, "copy_d2h");
@@ -599,9 +636,9 @@ int StreamCall::phase_b(int64_t k) {
             const ChunkIO io = caller_io(k);
             // what phase A copied (into page-locked arrays) was not final if the slow path ran; arrays that are not page-locked get
             // theirs here, through the context's bounce pieces (copy_down: back when the bytes have arrived)
-            if (!l.direct_min_e && (slow || !pl_min_e))
+            if (!l.direct_min_e && (slow || redone || !pl_min_e))
                 if (int rc_ = copy_down(c, io.min_e_dst, l.min_e.p, (size_t)m, st)) return rc_;
-            if (!l.direct_cnt && count_format != SCT_CNT_OFFS64 && (slow || !pl_counts))
+            if (!l.direct_cnt && count_format != SCT_CNT_OFFS64 && (slow || redone || !pl_counts))
                 if (int rc_ = copy_down(c, io.cnt_dst, l.cnt_out.p, (count_format == SCT_CNT_U8 ? 1 : 4) * (size_t)m, st)) return rc_;
             if (count_format == SCT_CNT_OFFS64) {
                 // the chunk's offsets start at 0: add the hits of the chunks before it, then copy (the last entry of a chunk
@@ -630,8 +667,12 @@ int StreamCall::phase_b(int64_t k) {
             HIPCHK(hipMemcpyAsync(c->h_hits + hit_base, l.hits_ptr, 4 * (size_t)l.n_hits, hipMemcpyDeviceToHost, st));
         }
     }
+    if (sink) {
+        if ((size_t)(hit_base + l.n_hits) > sink_entries) sink_drop();
+        else lane_hits[(size_t)(k % L)] = HitSpan{hit_base, l.n_hits};
+    }
     if (ring)
-        if (int rc_ = ring_after_b(k, slow)) return rc_;
+        if (int rc_ = ring_after_b(k, slow || redone)) return rc_;
     hit_base += l.n_hits;
     for (int i = 0; i < 6; i++) c->stats[i] += l.stats[i];
     return SCT_OK;
@@ -817,7 +858,7 @@ ChunkIO StreamCall::ring_io(int64_t k) const {
 
 // chunk k's results are complete in its slot (phase B waited for them): send them on their way out, and the slot's next user
 // on its way in behind them
-int StreamCall::ring_after_b(int64_t k, bool slow) {
+int StreamCall::ring_after_b(int64_t k, bool stale) {
     Lane &l = lane_of(k);
     RingChunk &r = rc[(size_t)k];
     const ChunkPlan &cp = plan[(size_t)k];
@@ -834,8 +875,8 @@ int StreamCall::ring_after_b(int64_t k, bool slow) {
         HIPCHK(hipStreamSynchronize(l.stream));
         r.wide_offs = (const int64_t *)c->h_scratch;
         sync_out = true;   // (one scratch buffer: this chunk is out before the next one may need it)
-    } else if (slot_counts && slow && count_format == SCT_CNT_OFFS64) {
-        // the slow path summed the counts again: the block sums phase A copied are stale
+    } else if (slot_counts && stale && count_format == SCT_CNT_OFFS64) {
+        // the slow path (or a second pass of the batch) summed the counts again: the block sums phase A copied are stale
         const int64_t nb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
         HIPCHK(hipMemcpyAsync(s.base + s.o_sums, l.sums.p, 8 * (size_t)nb, hipMemcpyDeviceToHost, l.stream));
         HIPCHK(hipStreamSynchronize(l.stream));
@@ -902,6 +943,12 @@ int StreamCall::run() {
     if (ring)
         if (int rc_ = ring_prepare()) return rc_;
     const double t_prepared = trace ? since_begin() : 0;
+    if (want_sink && !hits16) {
+        ensure_pool(c);
+        lane_hits.assign((size_t)L, HitSpan{});
+        sink_entries = c->h_hits_cap;
+        sink = inject_alloc_failure() ? nullptr : g_hit_arrays.get(4 * sink_entries);   // (none to be had: the caller makes do with one copy at the end)
+    }
 
     // host time spent queueing (phase A; on the ring route: waiting for a chunk's way in, too) and waiting + collecting (phase B),
     // reported beside the device spans
@@ -932,6 +979,7 @@ int StreamCall::run() {
     }
     if (rc_all != SCT_OK) {
         const std::string keep = g_err;
+        sink_drop();
         ring_quiesce();
         for (Lane *l : c->lanes) (void)hipStreamSynchronize(l->stream);
         (void)hipGetLastError();
@@ -942,6 +990,10 @@ int StreamCall::run() {
     ring_quiesce();
     for (int i = 0; i < L; i++) HIPCHK(hipStreamSynchronize(c->lanes[(size_t)i]->stream));
     HIPCHK(hipGetLastError());
+    if (sink) {   // every lane's last hits have landed now
+        for (int i = 0; i < L; i++) sink_flush_lane(i);
+        c->pool->wait(&hit_group);
+    }
     host_b += clk_ms() - t2;
     for (int i = 0; i < L; i++) collect_timing(c, *c->lanes[(size_t)i]);
     c->last_ms.emplace_back("host_queue", sct_ctx::Span{host_a, (int)n_chunks});
@@ -967,9 +1019,11 @@ int StreamCall::run() {
     return SCT_OK;
 }
 
-extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes, const void *index, int32_t index_format, int64_t n,
-                                int32_t max_err, int32_t threads, uint8_t *min_e, void *counts, int32_t count_format, int32_t hits_format,
-                                const void **hits_out, int64_t *n_hits_out) {
+// sink_out != NULL (sct_match): *sink_out receives a malloc'ed array (g_hit_arrays) that holds the hits already — or NULL, and the
+// caller copies them out of *hits_out itself
+static int match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes, const void *index, int32_t index_format, int64_t n, int32_t max_err,
+                        int32_t threads, uint8_t *min_e, void *counts, int32_t count_format, int32_t hits_format, const void **hits_out,
+                        int64_t *n_hits_out, uint32_t **sink_out) {
     if (!c) return fail(SCT_E_ARG, "ctx is NULL");
     FaultScope fault_scope(&c->fault);
     if (!hits_out || !n_hits_out) return fail(SCT_E_ARG, "sct_match_stream: NULL output pointer");
@@ -1011,8 +1065,16 @@ extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes,
         *hits_out = c->h_hits;
         return SCT_OK;
     }
+    sc.want_sink = sink_out != nullptr;
     if (int rc = sc.run()) return rc;
     *hits_out = c->h_hits;
     *n_hits_out = sc.hit_base;
+    if (sink_out) *sink_out = sc.sink;
     return SCT_OK;
+}
+
+extern "C" int sct_match_stream(sct_ctx *c, const char *segs, int64_t seg_bytes, const void *index, int32_t index_format, int64_t n,
+                                int32_t max_err, int32_t threads, uint8_t *min_e, void *counts, int32_t count_format, int32_t hits_format,
+                                const void **hits_out, int64_t *n_hits_out) {
+    return match_stream(c, segs, seg_bytes, index, index_format, n, max_err, threads, min_e, counts, count_format, hits_format, hits_out, n_hits_out, nullptr);
 }

@@ -1269,8 +1269,9 @@ static int slow_path(sct_ctx *c, Lane &l) {
 
 // After the lane's queued work is done (the caller waited for it): read the counter record, report bad input, run the
 // slow path if rows were listed.  On return the batch's results are complete on the device; *slow says whether the slow
-// path ran (copies of min_e / counts queued before it are then stale).
-static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
+// path ran (copies of min_e / counts queued before it are then stale, and the hits are 32-bit entries in the lane's own array),
+// *redone whether the batch was queued a second time (stale copies likewise; the hits are where the first pass would have put them).
+static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow, bool *redone = nullptr) {
     const uint32_t *h = l.h_ctr;
     if (slow) *slow = false;
     const uint64_t bad_row = ctr64(h, CTR_BAD_ROW), bad_byte = ctr64(h, CTR_BAD_BYTE);
@@ -1288,7 +1289,13 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
         if (int rc = queue_batch(c, l)) return rc;
         HIPCHK(hipStreamSynchronize(l.stream));
         HIPCHK(hipGetLastError());
-        return finish_batch(c, l, row_base, slow);
+        {
+            // the batch was queued again: whatever the caller copied (or had copied) out of the first pass — min_e, counts, the block
+            // sums a ring slot holds — is stale
+            const int rc = finish_batch(c, l, row_base, slow, redone);
+            if (redone) *redone = true;
+            return rc;
+        }
     }
     if (l.bp.filter_ok && l.n_seg > 0 && ((l.no64 && h[CTR_NEED64]) || (l.no_special && h[CTR_SPECIAL]))) {
         // the batch has rows for launches that were left out on the guess that no row needs them (sct_ctx::need64, need_special):
@@ -1300,7 +1307,13 @@ static int finish_batch(sct_ctx *c, Lane &l, int64_t row_base, bool *slow) {
         if (int rc = queue_batch(c, l)) return rc;
         HIPCHK(hipStreamSynchronize(l.stream));
         HIPCHK(hipGetLastError());
-        return finish_batch(c, l, row_base, slow);
+        {
+            // the batch was queued again: whatever the caller copied (or had copied) out of the first pass — min_e, counts, the block
+            // sums a ring slot holds — is stale
+            const int rc = finish_batch(c, l, row_base, slow, redone);
+            if (redone) *redone = true;
+            return rc;
+        }
     }
     const int64_t n_retried = h[CTR_RETRY];
     if (h[CTR_LONG] || h[CTR_SCAN] || h[CTR_DP]) {
@@ -1424,8 +1437,6 @@ extern "C" int sct_download(sct_ctx *c, uint8_t *min_e, int64_t *hit_offs, uint3
     return SCT_OK;
 }
 
-#include "sct_stream.hip.h"
-
 // sct_match's hit arrays: malloc'ed, handed to the caller, given back through sct_free_hits.  The last few that came back are kept
 // for the next call (any context, any thread): 33 MB per 10 M rows at 25 k barcodes are 8 000 pages to map, fault in and unmap
 // again every call otherwise — a millisecond of a call that takes six.
@@ -1485,6 +1496,8 @@ struct HitArrays {
 };
 static HitArrays g_hit_arrays;
 
+#include "sct_stream.hip.h"
+
 extern "C" int sct_match(sct_ctx *c, const char *segs, const int64_t *offs, int64_t n, int32_t max_err, int32_t threads,
                          uint8_t *min_e, int64_t *hit_offs, uint32_t **hits, int64_t *n_hits) {
     if (!hits || !n_hits || !min_e || !hit_offs) return fail(SCT_E_ARG, "sct_match: NULL output pointer");
@@ -1494,12 +1507,16 @@ extern "C" int sct_match(sct_ctx *c, const char *segs, const int64_t *offs, int6
     if (n < 0 || !offs) return fail(SCT_E_ARG, "sct_match: bad offsets");
     const void *h = nullptr;
     int64_t total = 0;
-    int rc = sct_match_stream(c, segs, offs[n], offs, SCT_IDX_OFFS64, n, max_err, threads, min_e, hit_offs, SCT_CNT_OFFS64, SCT_HITS_U32, &h, &total);
+    uint32_t *sink = nullptr;   // the caller's hit array, filled chunk by chunk while the call runs (NULL: it could not be, see below)
+    int rc = match_stream(c, segs, offs[n], offs, SCT_IDX_OFFS64, n, max_err, threads, min_e, hit_offs, SCT_CNT_OFFS64, SCT_HITS_U32, &h, &total, &sink);
     if (rc) return rc;
-    uint32_t *out = inject_alloc_failure() ? nullptr : g_hit_arrays.get(sizeof(uint32_t) * (size_t)(total ? total : 1));
-    if (!out) return fail(SCT_E_NOMEM, "out of host memory for %lld hits", (long long)total);
-    par_copy(c, out, h, sizeof(uint32_t) * (size_t)total);   // (33 MB per 10 M rows at 25 k barcodes: on the copy pool)
-    *hits = out;
+    if (!sink) {
+        // (a call of no rows; an array that could not be had; a result buffer that grew while the call ran)
+        sink = inject_alloc_failure() ? nullptr : g_hit_arrays.get(sizeof(uint32_t) * (size_t)(total ? total : 1));
+        if (!sink) return fail(SCT_E_NOMEM, "out of host memory for %lld hits", (long long)total);
+        par_copy(c, sink, h, sizeof(uint32_t) * (size_t)total);   // (33 MB per 10 M rows at 25 k barcodes: on the copy pool)
+    }
+    *hits = sink;
     *n_hits = total;
     return SCT_OK;
 }

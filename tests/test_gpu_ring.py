@@ -132,6 +132,33 @@ def test_errors_through_the_ring(m):
         m.set_option("ring_rows", 0)
 
 
+def test_a_chunk_that_is_done_again(m):
+    """A chunk whose first pass left out launches it turned out to need (options "need64" / "need_special": the guess that no row has more
+    than 31 characters, none a byte outside ACGT) is queued again; what its slot holds from the first pass — the hit counts' block sums
+    the way out starts its prefix sums from — must be fetched again (found by tools/soak_ring.py: hit_offs wrong from a chunk's second
+    part on).  Chunks large enough for a way out of several parts."""
+    bc = synth.make_barcodes(3000, seed=57)
+    segs, offs = synth.make_segments(400_000, bc, seed=57)
+    segs, offs, _ = synth.lengthen_rows(segs, offs, 0.0005, 40, seed=58)
+    segs, _ = synth.add_noise_bytes(segs, offs, 0.0005, seed=59)
+    m.set_barcodes(bc)
+    m.set_option("need64", 1)
+    m.set_option("need_special", 1)
+    want = m.match(segs, offs, 2, 16)
+    for threads in (-1, 1):
+        m.set_option("copy_threads", threads)
+        for cfmt in (_native.CNT_OFFS64, _native.CNT_U32):
+            m.set_option("need64", -1)
+            m.set_option("need_special", -1)
+            before = m.get_option("redone64")
+            me, cnt, hits = m.match_stream(segs, offs, 2, 16, index_format=_native.IDX_OFFS64, count_format=cfmt)
+            assert m.get_option("last_route") == 2 and m.get_option("redone64") > before
+            util.assert_same((me, counts_to_offsets(cnt, cfmt), hits), want, "redone chunks, count format %d, %d copy threads" % (cfmt, threads))
+    m.set_option("copy_threads", -1)
+    m.set_option("need64", -1)
+    m.set_option("need_special", -1)
+
+
 def test_cfg3_size_equals_zero_copy(m):
     """10 M rows x 25 k barcodes (BASELINE configs[2]) on pageable numpy arrays == the same call on page-locked arrays."""
     bc = synth.make_barcodes(25_000, seed=3)

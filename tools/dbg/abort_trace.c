@@ -11,8 +11,10 @@ static void on_abort(int sig) {
     signal(sig, SIG_DFL);
     raise(sig);
 }
-__attribute__((constructor)) static void init(void) {
+/* also callable later (ctypes): a runtime that installs handlers of its own after start-up would otherwise replace these */
+void sct_install_abort_trace(void) {
     signal(SIGABRT, on_abort);
     signal(SIGSEGV, on_abort);
     signal(SIGBUS, on_abort);
 }
+__attribute__((constructor)) static void init(void) { sct_install_abort_trace(); }
