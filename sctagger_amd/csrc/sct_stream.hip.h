@@ -10,14 +10,16 @@
 //
 //   RING        ordinary (pageable) caller arrays — what the reference's seam hands over (scTagger.py:616-627: RawArray) and
 //               what sct_match gets from numpy.  The context owns a ring of page-locked slots and a pool of copy threads
-//               (sct_copy_pool.h).  The rows are cut into chunks of <= 2^19 rows; for chunk k
+//               (sct_copy_pool.h).  The rows are cut into chunks of a third of the call, at most 2^20 rows; for chunk k
 //                 pool:    memcpy segs[k] into a slot, the 64- / 32-bit offsets narrowed to one-byte lengths on the way
+//                          (sct_hostcopy.c), the lengths' block prefix sums read off the offsets
 //                 device:  the zero-copy kernels on the slot (min_e and one-byte counts written back into it), hits by DMA
 //                          into the context's page-locked result buffer
 //                 pool:    slot -> caller: min_e copied, the counts widened to the caller's format (int64 CSR offsets:
-//                          prefix sums seeded by the device's block sums)
-//               with chunk k+1 .. k+2 on their way in while chunk k computes and chunk k-1 is on its way out.  Nothing of the
-//               caller's is page-locked and no caller pointer is ever given to the runtime: the link carries 220 MB up and
+//                          prefix sums seeded by the device's block sums); sct_match's hit array filled from the result buffer
+//               with chunks k+1 .. on their way in while up to "ring_lanes" chunks are on the device and chunk k-1 is on its way
+//               out; the last part of a chunk's way out hands its slot to the next user (no thread waits for a slot).  Nothing of
+//               the caller's is page-locked and no caller pointer is ever given to the runtime: the link carries 220 MB up and
 //               55 MB down per 10 M rows instead of 289 / 123, and the calling thread no longer sits in staged copies.
 //               (Round 4 locked the caller's pages for the call instead — hipHostRegister, option "register": one soak run in a
 //               few ended in a GPU memory fault on a host address; removed in round 5)
