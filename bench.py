@@ -387,6 +387,16 @@ def other_config(name, device, steps, warmup, seg_seed=None):
         per_seg, alg_bytes, h = loops.algorithmic_bytes()
         paths = m.last_stats()
         extra = {}
+        if n_seg <= 2_000_000:
+            # a small batch: the per-kernel event records of the loops above (seven per batch, ~35 us) are a visible share of the step;
+            # the same two loops without them (option "timing" = 0: what the command's workers run with)
+            m.set_option("timing", 0)
+            try:
+                e0, _ = loops.e2e(max(steps, 10), warmup, "len8", "u8", "u16")
+                r0, _, _ = loops.resident(max(steps, 10), warmup)
+                extra["without_event_records"] = {"ms_per_step": e0["ms_per_step"], "ms_per_step_resident": r0["ms_per_step"]}
+            finally:
+                m.set_option("timing", 1)
         if paths["scheme"] == "thirds" and max_err == 1:
             # the partitioned join (option "join"; csrc/k_join.hip.h) instead of the filter kernel's 32-bit main launch: same
             # results (tests/test_gpu_join.py), about half the HBM traffic, the same time -> an option, timed here for the record
