@@ -37,7 +37,10 @@ def _relaunch_with_huge_pages():
     call that does the same later).  The command touches 4 GB of heap per 10^8 rows: a million page faults, and a TLB entry per 4 KB
     for the decoders' and the compressor's windows; with huge pages 10^8 rows take 1.75 instead of 2.07 s on the GPU box (10^7 rows:
     no difference, so small inputs are not relaunched — the second interpreter costs 0.02 s).  Nothing has touched the GPU yet: this
-    process only waits and passes the child's exit status on."""
+    process only waits and passes the child's exit status on.
+    (Huge-page-backed heap arrays and the GPU: the library never hands memory that is not page-locked to the HIP runtime — a worker's
+    first blocks, parsed into ordinary arrays before its device context exists, go through the context's page-locked ring by memcpy —
+    so no transparent huge page is ever pinned in place under a running kernel: DESIGN.md 5c.)"""
     import sys
     if "glibc.malloc.hugetlb" in os.environ.get("GLIBC_TUNABLES", "") or os.environ.get("SCT_NO_RELAUNCH") or "match_trie" not in sys.argv[1:2]:
         return
