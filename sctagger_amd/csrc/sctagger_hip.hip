@@ -1442,7 +1442,7 @@ extern "C" int sct_download(sct_ctx *c, uint8_t *min_e, int64_t *hit_offs, uint3
 // again every call otherwise — a millisecond of a call that takes six.
 struct HitArrays {
     static constexpr int KEEP = 2;
-    static constexpr size_t KEEP_BYTES_MAX = (size_t)1 << 30;
+    static constexpr size_t KEEP_BYTES_MAX = (size_t)256 << 20;   // (larger arrays go back to the allocator at once)
     std::mutex mu;
     struct Known {
         uint32_t *p;

@@ -140,15 +140,22 @@ class _DeviceContext:
         self.lock = threading.Lock()
         self.m = None
         self.bc_key = None
+        self.sharers = None
 
-    def matcher(self, bc, bl):
-        """-> (Matcher, seconds creating the context, seconds in sct_set_barcodes); the tables are rebuilt only when the barcodes change."""
+    def matcher(self, bc, bl, sharers=1):
+        """-> (Matcher, seconds creating the context, seconds in sct_set_barcodes); the tables are rebuilt only when the barcodes change.
+        sharers: contexts of this call that run side by side — each one's copy pool takes its share of the CPUs."""
         import hashlib
         import time
         t0 = time.perf_counter()
         if self.m is None:
             self.m = _native.Matcher(self.device)
             self.bc_key = None
+            self.sharers = None
+        if sharers != self.sharers:
+            # (the library's default is half of the process's CPUs per context, at most 8: eight contexts would start 64 copy threads)
+            self.m.set_option("copy_threads", -1 if sharers <= 1 else max(1, min(8, _native.host_cpus() // (2 * sharers))))
+            self.sharers = sharers
         t1 = time.perf_counter()
         key = (bl, bc.shape, hashlib.blake2b(bc.tobytes(), digest_size=16).digest())
         if key != self.bc_key:
@@ -222,7 +229,7 @@ def run_get_matches_prefix_arrays(max_error, threads, devices=(0,), barcode_leng
             ctx = _context_for(devices[i], nth[i])
             with ctx.lock:
                 try:
-                    m, t_ctx, t_bc = ctx.matcher(bc, bl)
+                    m, t_ctx, t_bc = ctx.matcher(bc, bl, len(devices))
                     t3 = time.perf_counter()
                     results[i] = m.match(segs, offs, max_error, threads)
                 except BaseException:
