@@ -5,7 +5,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#ifndef SCT_CLONES   /* (tests/test_hostcopy.py builds every clone on its own) */
 #define SCT_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
 
 /* offsets -> one-byte row lengths; returns the OR of all differences: a bit above bit 7 means a row of more than 255 characters
  * (or, top bit, offsets that decrease) — the caller then looks again */
